@@ -1,0 +1,153 @@
+/*
+ * sonde_abi.h -- C ABI of libsonde_mi355.so, the MI355X-native radiosonde demod+FEC path.
+ *
+ * Two layers, both plain C (no torch / HIP types in any signature):
+ *
+ *  B1  the per-sonde decoder triple that /root/reference/src/decode/decoder.hpp:22 fixes as
+ *      template parameters and /root/reference/src/main.hpp:36-42 instantiates:
+ *          T*           X_decoder_init(int samplerate);
+ *          void         X_decoder_deinit(T*);
+ *          ParserStatus X_decode(T*, SondeData *dst, const float *src, size_t len);
+ *      for X in {rs41, dfm09, ims100, m10, imet4, c50, mrzn1}.  These replace the
+ *      un-vendored sondedump library (CMake target `radiosonde`, /root/reference/CMakeLists.txt:18,25)
+ *      and are what "drops in for src/decode/".
+ *
+ *  B0  the batch API the B1 shims sit on: many independent 48 kS/s channels, one HIP workgroup
+ *      per channel, complex IQ (the dsp::stream<dsp::complex_t> of /root/reference/src/main.cpp:57)
+ *      or real FM-discriminator samples (the dsp::stream<float> of decoder.hpp:35) in, corrected
+ *      frames out.
+ *
+ * SondeData / ParserStatus / DATA_* are *defined here*: the reference only uses them
+ * (/root/reference/src/decode/decoder.hpp:54,61,64-104); their definitions lived in the absent
+ * sondedump headers.
+ */
+#ifndef SONDE_ABI_H
+#define SONDE_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <time.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ B1: sondedump surface */
+
+/* decoder.hpp:61 tests `!= PROCEED`; PARSED = "one fragment is in *dst". */
+typedef enum { PROCEED = 0, PARSED = 1 } ParserStatus;
+
+/* validity bitmask of SondeData.fields -- names from decoder.hpp:64,68,74,80,84,93,97,102 */
+#define DATA_SEQ      (1 << 0)
+#define DATA_POS      (1 << 1)
+#define DATA_SPEED    (1 << 2)
+#define DATA_TIME     (1 << 3)
+#define DATA_PTU      (1 << 4)
+#define DATA_SERIAL   (1 << 5)
+#define DATA_SHUTDOWN (1 << 6)
+#define DATA_OZONE    (1 << 7)
+
+/* members and types implied by the assignments at decoder.hpp:65-104 */
+typedef struct {
+	int    fields;
+	int    seq;
+	float  lat, lon, alt;          /* degrees, degrees, metres */
+	float  speed, heading, climb;  /* m/s, degrees, m/s */
+	time_t time;
+	float  calib_percent;
+	float  temp, rh, pressure;     /* degC, %, hPa (<= 0: unknown -> decoder.hpp:108 falls back to ISA) */
+	char   serial[32];
+	int    shutdown;               /* seconds to burst-kill shutdown, -1 inactive */
+	float  o3_mpa;
+} SondeData;
+
+typedef struct SondeB1Decoder RS41Decoder;
+typedef struct SondeB1Decoder DFM09Decoder;
+typedef struct SondeB1Decoder IMS100Decoder;
+typedef struct SondeB1Decoder M10Decoder;
+typedef struct SondeB1Decoder IMET4Decoder;
+typedef struct SondeB1Decoder C50Decoder;
+typedef struct SondeB1Decoder MRZN1Decoder;
+
+#define SONDE_B1_DECL(T, x) \
+	T *x##_decoder_init(int samplerate); \
+	void x##_decoder_deinit(T *d); \
+	ParserStatus x##_decode(T *d, SondeData *dst, const float *src, size_t len);
+
+SONDE_B1_DECL(RS41Decoder,   rs41)    /* main.hpp:36 */
+SONDE_B1_DECL(DFM09Decoder,  dfm09)   /* main.hpp:37 */
+SONDE_B1_DECL(IMS100Decoder, ims100)  /* main.hpp:38 */
+SONDE_B1_DECL(M10Decoder,    m10)     /* main.hpp:39 */
+SONDE_B1_DECL(IMET4Decoder,  imet4)   /* main.hpp:40 */
+SONDE_B1_DECL(C50Decoder,    c50)     /* main.hpp:41 */
+SONDE_B1_DECL(MRZN1Decoder,  mrzn1)   /* main.hpp:42 */
+
+/* ------------------------------------------------------------------ B0: batch API */
+
+/* sonde types, order of supportedTypes[] at main.hpp:44-52 */
+enum { SONDE_RS41 = 0, SONDE_DFM09 = 1, SONDE_IMS100 = 2, SONDE_M10 = 3, SONDE_IMET4 = 4, SONDE_C50 = 5, SONDE_MRZN1 = 6, SONDE_NTYPES = 7 };
+
+enum { SONDE_INPUT_IQ = 0,      /* complex64 interleaved I,Q at 48 kS/s (vfo->output level, main.cpp:57) */
+       SONDE_INPUT_REAL = 1 };  /* float FM-discriminator output at 48 kS/s (decoder.hpp:35 level) */
+
+#define SONDE_TILE       2048   /* samples; submit lengths are multiples of this */
+#define SONDE_FRAME_MAX  528
+
+typedef struct {
+	uint32_t channel;
+	uint32_t type;
+	int32_t  len;            /* bytes valid in data[] */
+	int32_t  nerr[2];        /* RS41: bytes corrected per RS codeword, -1 = uncorrectable */
+	uint32_t flags;          /* bit0: signal polarity was inverted */
+	uint64_t bitpos;         /* absolute index (since create) of the first sync bit */
+	uint8_t  data[SONDE_FRAME_MAX];   /* de-whitened, error-corrected frame */
+} SondeFrame;
+
+typedef struct {
+	uint32_t       n_channels;
+	const uint8_t *types;            /* n_channels entries of SONDE_*; NULL = all SONDE_RS41 */
+	uint32_t       max_samples;      /* largest samples-per-channel of one submit (multiple of SONDE_TILE) */
+	int32_t        input_kind;       /* SONDE_INPUT_IQ or SONDE_INPUT_REAL */
+	int32_t        device;           /* HIP device ordinal */
+} SondeBatchConfig;
+
+typedef struct SondeBatch SondeBatch;
+
+/* All int-returning calls: 0 = ok, negative = error (text via sonde_last_error()). */
+int  sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out);
+void sonde_batch_destroy(SondeBatch *b);
+
+/* Demodulate + frame + FEC n_samples more samples of every channel.
+ * samples: DEVICE pointer, channel-major; channel c starts at element c*channel_stride
+ * (elements = complex samples for IQ, floats for REAL).  n_samples % SONDE_TILE == 0.
+ * stream: hipStream_t (NULL = default stream).  Asynchronous; frames of this submit replace the
+ * previous submit's. */
+int  sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream);
+/* Same, from HOST memory (staged through an internal pinned/device buffer; PCIe-inclusive). */
+int  sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride);
+/* Wait for the last submit; returns number of frames it produced (or negative error). */
+long sonde_batch_sync(SondeBatch *b);
+/* Copy the last submit's frames to host memory, ordered by (channel, bitpos).  Returns count copied. */
+long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap);
+/* Average device time (ms) of the demod and of the framer kernel over the submits since the previous
+ * call of this function (at most the last 128), from HIP events recorded on the submit stream around
+ * each launch.  Synchronises. */
+int  sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *framer_ms);
+
+/* introspection for staged parity tests */
+int      sonde_batch_read_bits(SondeBatch *b, uint32_t channel, uint64_t from, size_t count, uint8_t *out /* one bit per byte */);
+uint64_t sonde_batch_nbits(SondeBatch *b, uint32_t channel);
+int      sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp, float *yprev);
+int      sonde_get_taps(int type, float *out /* 32*32 floats, [phase][tap] */);
+
+/* frame -> SondeData fragments (what one X_decode call sequence yields for this frame).
+ * Returns number of fragments written (<= cap). */
+int  sonde_parse_frame(const SondeFrame *f, SondeData *out, int cap);
+
+const char *sonde_last_error(void);
+const char *sonde_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,253 @@
+/*
+ * or_dsp.c -- oracle stages 1+2: FM discriminator and GFSK demodulator.
+ * TEST INFRASTRUCTURE ONLY (see sonde_oracle.h).  PARITY UNPINNED.
+ *
+ * Stage 1 restates SDR++'s quadrature FM demodulator as wired at
+ * /root/reference/src/main.cpp:57  fmDemod.init(vfo->output, bw, bw/2.0f, false)
+ * (deviation = bandwidth/2 = samplerate/4  =>  gain = samplerate/(2*pi*dev) = 2/pi,
+ *  SURVEY.md section 8a-1), with the libm atan2f replaced by an explicit
+ * polynomial so that CPU and GPU agree bit for bit.
+ *
+ * Stage 2 stands where sondedump's gfsk_demod() sits behind
+ * X_decode(T*, SondeData*, const float*, size_t)  (/root/reference/src/decode/decoder.hpp:22,61):
+ * polyphase low-pass FIR evaluated at the timing loop's sampling instants,
+ * Gardner timing-error detector, PI loop filter, hard slicer.  The loop filter is
+ * updated once per "round" (all symbols that became decodable after one 2048-sample
+ * tile, at most 256) instead of once per symbol; DESIGN.md section 3 gives the contract.
+ *
+ * Build with -ffp-contract=off: every float op below is one IEEE binary32 op.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "sonde_oracle.h"
+
+#define OR_PI_D     3.14159265358979323846
+#define PI_F        3.14159274f   /* 0x40490FDB */
+#define TWO_PI_F    6.28318548f   /* 0x40C90FDB */
+#define HALF_PI_F   1.57079637f   /* 0x3FC90FDB */
+#define TWO_OVER_PI 0.636619747f  /* 0x3F22F983 */
+
+/* Abramowitz & Stegun 4.4.47, |err| <= 1e-5 rad on [0,1] */
+#define AT_A1  0.9998660f
+#define AT_A3 -0.3302995f
+#define AT_A5  0.1801410f
+#define AT_A7 -0.0851330f
+#define AT_A9  0.0208351f
+
+float or_atan2(float y, float x)
+{
+	const float ax = fabsf(x), ay = fabsf(y);
+	const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+	const float r = (mx > 0.0f) ? mn / mx : 0.0f;
+	const float s = r * r;
+	float p = fmaf(s, AT_A9, AT_A7);
+	p = fmaf(s, p, AT_A5);
+	p = fmaf(s, p, AT_A3);
+	p = fmaf(s, p, AT_A1);
+	p = p * r;
+	if (ay > ax) p = HALF_PI_F - p;
+	if (x < 0.0f) p = PI_F - p;
+	if (y < 0.0f) p = -p;
+	return p;
+}
+
+void or_discriminate(const float *iq, size_t n, float *d, float *phi_last)
+{
+	float prev = *phi_last;
+	for (size_t i = 0; i < n; i++) {
+		const float phi = or_atan2(iq[2 * i + 1], iq[2 * i]);
+		float diff = phi - prev;
+		if (diff > PI_F) diff = diff - TWO_PI_F;
+		else if (diff <= -PI_F) diff = diff + TWO_PI_F;
+		d[i] = diff * TWO_OVER_PI;
+		prev = phi;
+	}
+	*phi_last = prev;
+}
+
+/* ---- modem table.  Baud rates: SURVEY.md Appendix B [RECALL]; VFO bandwidths in
+ * /root/reference/src/main.hpp:44-52 bound them from above. ---- */
+static const OrModem g_modems[OR_NTYPES] = {
+	{ OR_RS41,   4800.0, 0, 0.65f },  /* RS41: 4800 Bd GFSK, NRZ */
+	{ OR_DFM09,  5000.0, 0, 0.65f },  /* DFM: 2500 bit/s Manchester => 5000 chips/s */
+	{ OR_IMS100, 4800.0, 0, 0.65f },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
+	{ OR_M10,    9600.0, 0, 0.65f },  /* M10/M20: 9600 chips/s Manchester */
+	{ OR_IMET4,  2400.0, 0, 0.65f },  /* placeholders (AFSK sondes) */
+	{ OR_C50,    2400.0, 0, 0.65f },
+	{ OR_MRZN1,  2400.0, 0, 0.65f },
+};
+static OrModem g_modem_rt[OR_NTYPES];
+
+const OrModem *or_modem(int type)
+{
+	if (type < 0 || type >= OR_NTYPES) return NULL;
+	if (g_modem_rt[type].period0 == 0) {
+		g_modem_rt[type] = g_modems[type];
+		g_modem_rt[type].period0 = (int)llrint(65536.0 * (double)OR_FS / g_modems[type].baud);
+	}
+	return &g_modem_rt[type];
+}
+
+/* Blackman-windowed sinc, cutoff = m->cutoff * baud, one row per polyphase branch,
+ * each row normalised to unit DC gain.  H[p][j] = f(j - N/2 + p/P). */
+void or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS])
+{
+	const double fc = (double)m->cutoff * m->baud / (double)OR_FS; /* cycles/sample */
+	for (int p = 0; p < OR_NPHASE; p++) {
+		double h[OR_NTAPS], sum = 0.0;
+		for (int j = 0; j < OR_NTAPS; j++) {
+			const double t = (double)j - (double)(OR_NTAPS / 2) + (double)p / (double)OR_NPHASE;
+			const double x = (t + (double)(OR_NTAPS / 2)) / (double)OR_NTAPS;
+			const double w = 0.42 - 0.5 * cos(2.0 * OR_PI_D * x) + 0.08 * cos(4.0 * OR_PI_D * x);
+			const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * OR_PI_D * fc * t) / (OR_PI_D * t);
+			h[j] = s * w;
+			sum += h[j];
+		}
+		for (int j = 0; j < OR_NTAPS; j++) taps[p][j] = (float)(h[j] / sum);
+	}
+}
+
+struct OrDemod {
+	const OrModem *m;
+	float taps[OR_NPHASE][OR_NTAPS];
+	float ring[OR_RING];
+	int64_t n0;          /* samples consumed so far */
+	float phi_last;
+	int64_t t_next;      /* Q16 absolute on-time instant of the next symbol */
+	int32_t period;      /* Q16 samples per symbol */
+	float yprev, bias, amp;
+	int32_t nstat;
+	uint8_t *bits;
+	uint64_t nbits, cap;
+};
+
+OrDemod *or_demod_new(int type)
+{
+	OrDemod *d = calloc(1, sizeof(*d));
+	d->m = or_modem(type);
+	or_make_taps(d->m, d->taps);
+	d->period = d->m->period0;
+	d->t_next = ((int64_t)OR_NTAPS << 16) + d->period;
+	d->amp = 0.25f;
+	return d;
+}
+
+void or_demod_free(OrDemod *d) { if (d) { free(d->bits); free(d); } }
+
+static inline float interp(const OrDemod *d, int64_t pos)
+{
+	const int64_t n = pos >> 16;
+	const int p = (int)((pos >> 11) & (OR_NPHASE - 1));
+	float acc = 0.0f;
+	for (int j = 0; j < OR_NTAPS; j++)
+		acc = fmaf(d->taps[p][j], d->ring[(n + OR_NTAPS / 2 - j) & (OR_RING - 1)], acc);
+	return acc;
+}
+
+static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+static void push_bit(OrDemod *d, int b)
+{
+	if (d->nbits == d->cap) {
+		d->cap = d->cap ? d->cap * 2 : 8192;
+		d->bits = realloc(d->bits, d->cap);
+	}
+	d->bits[d->nbits++] = (uint8_t)b;
+}
+
+static void run_rounds(OrDemod *d)
+{
+	const int64_t limit = (((d->n0 - 1 - OR_NTAPS / 2) << 16) | 0xFFFF);
+	float y[OR_ROUND_MAX], m[OR_ROUND_MAX];
+
+	while (d->t_next <= limit) {
+		int64_t K64 = (limit - d->t_next) / d->period + 1;
+		const int K = K64 > OR_ROUND_MAX ? OR_ROUND_MAX : (int)K64;
+		int32_t E = 0, S1 = 0, S0 = 0, C1 = 0;
+
+		for (int k = 0; k < K; k++) {
+			const int64_t t = d->t_next + (int64_t)k * d->period;
+			y[k] = interp(d, t);
+			m[k] = interp(d, t - (d->period >> 1));
+		}
+		for (int k = 0; k < K; k++) {
+			const float prev = k ? y[k - 1] : d->yprev;
+			const float a = prev - y[k];
+			const float b = m[k] - d->bias;
+			float e = a * b;
+			e = clampf(e * 1024.0f, -1.0e6f, 1.0e6f);
+			E += (int32_t)lrintf(e);
+			const int bit = y[k] > d->bias;
+			const int32_t Y = (int32_t)lrintf(clampf(y[k], -8.0f, 8.0f) * 4096.0f);
+			if (bit) { S1 += Y; C1++; } else { S0 += Y; }
+			push_bit(d, bit);
+		}
+		const int32_t C0 = K - C1;
+		if (C1 > 0 && C0 > 0) {
+			const float hi = ((float)S1 / (float)C1) * (1.0f / 4096.0f);
+			const float lo = ((float)S0 / (float)C0) * (1.0f / 4096.0f);
+			const float c = 0.5f * (hi + lo);
+			float a = 0.5f * (hi - lo);
+			if (d->nstat == 0) {
+				d->bias = c;
+				d->amp = a;
+			} else {
+				d->bias = d->bias + 0.5f * (c - d->bias);
+				d->amp = d->amp + 0.5f * (a - d->amp);
+			}
+			if (!(d->amp >= 1.0e-3f)) d->amp = 1.0e-3f;
+			d->nstat = 1;
+		}
+		float err = ((float)E / (float)K) * (1.0f / 1024.0f);
+		err = err / (d->amp * d->amp);
+		err = clampf(err, -1.0f, 1.0f);
+		const float kp = (float)d->m->period0 * 0.159154943f;   /* 0.5/pi of a symbol, Q16 samples */
+		const float ki = kp * (1.0f / 4096.0f);
+		const int32_t dphase = (int32_t)lrintf(err * kp);
+		const int32_t dper = (int32_t)lrintf(err * ki);
+		d->t_next += (int64_t)K * d->period + dphase;
+		d->period += dper;
+		const int32_t pmin = d->m->period0 - (d->m->period0 >> 8);
+		const int32_t pmax = d->m->period0 + (d->m->period0 >> 8);
+		if (d->period < pmin) d->period = pmin;
+		if (d->period > pmax) d->period = pmax;
+		d->yprev = y[K - 1];
+	}
+}
+
+void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
+{
+	float tile[OR_TILE];
+	for (size_t off = 0; off + OR_TILE <= n; off += OR_TILE) {
+		if (is_iq) {
+			or_discriminate(src + 2 * off, OR_TILE, tile, &d->phi_last);
+		} else {
+			memcpy(tile, src + off, sizeof(tile));
+		}
+		for (int i = 0; i < OR_TILE; i++)
+			d->ring[(d->n0 + i) & (OR_RING - 1)] = tile[i];
+		d->n0 += OR_TILE;
+		run_rounds(d);
+	}
+}
+
+uint64_t or_demod_nbits(const OrDemod *d) { return d->nbits; }
+
+void or_demod_getbits(const OrDemod *d, uint64_t from, size_t count, uint8_t *out)
+{
+	for (size_t i = 0; i < count; i++)
+		out[i] = (from + i < d->nbits) ? d->bits[from + i] : 0;
+}
+
+void or_demod_state(const OrDemod *d, int64_t *t_next, int32_t *period, float *bias, float *amp, float *yprev)
+{
+	if (t_next) *t_next = d->t_next;
+	if (period) *period = d->period;
+	if (bias) *bias = d->bias;
+	if (amp) *amp = d->amp;
+	if (yprev) *yprev = d->yprev;
+}
+
+/* internal accessor for the framer */
+const uint8_t *or_demod_bitptr(const OrDemod *d) { return d->bits; }

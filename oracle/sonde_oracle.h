@@ -1,0 +1,125 @@
+/*
+ * sonde_oracle.h -- CPU oracle for the radiosonde demod+FEC hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under sdrpp_radiosonde_amd/ may include,
+ * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker.
+ *
+ * PARITY UNPINNED.  The reference's arithmetic for this path lives in the
+ * un-vendored git submodule dbdexter-dev/sondedump (branch master, SHA
+ * unrecoverable; /root/reference/.gitmodules:1-4, directory empty) and in SDR++
+ * core (dsp::demod::FM, /root/reference/src/main.hpp:33).  Neither is present,
+ * the reference ships no tests or golden vectors, so this
+ * oracle restates the *published* algorithm structure of that path
+ * (FM quadrature discriminator -> GFSK low-pass/matched FIR -> Gardner timing
+ * recovery -> hard slicer -> sync-word correlator -> XOR de-whitening ->
+ * RS(255,231) -> CRC16 per subframe) from the call sites
+ * (/root/reference/src/decode/decoder.hpp:22,53-119, src/main.cpp:54-72) and
+ * public protocol facts.  It is pinned only by the
+ * known-answer tests in tests/ (RS41 header/mask KAT, CRC16 "123456789",
+ * RS encode->corrupt->decode round trips, dewpt/altitude KATs from SURVEY.md).
+ *
+ * The arithmetic contract ("SPEC") that both this oracle and the HIP kernels
+ * implement is written down in DESIGN.md section 3.  Every float operation is an
+ * explicit IEEE-754 binary32 op (compile with -ffp-contract=off; fused
+ * multiply-adds are spelled fmaf()), every cross-symbol reduction is done on
+ * integers, so a sequential C loop and a 256-lane HIP workgroup produce the
+ * same bits.
+ */
+#ifndef SONDE_ORACLE_H
+#define SONDE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- SPEC constants ---- */
+#define OR_FS          48000      /* decoder input rate, src/main.cpp:16 OUT_SAMPLE_RATE */
+#define OR_TILE        2048       /* samples per tile */
+#define OR_RING        4096       /* discriminator ring (floats) */
+#define OR_NTAPS       32         /* taps per polyphase branch */
+#define OR_NPHASE      32         /* polyphase branches (1/32 sample resolution) */
+#define OR_ROUND_MAX   256        /* max symbols per timing-loop round */
+#define OR_FRAME_MAX   528        /* bytes reserved per frame record */
+
+/* sonde types: order of supportedTypes[], /root/reference/src/main.hpp:44-52 */
+enum { OR_RS41 = 0, OR_DFM09 = 1, OR_IMS100 = 2, OR_M10 = 3, OR_IMET4 = 4, OR_C50 = 5, OR_MRZN1 = 6, OR_NTYPES = 7 };
+
+typedef struct {
+	int    type;
+	double baud;        /* on-air symbol (chip) rate */
+	int    period0;     /* Q16 samples per symbol = rint(65536*FS/baud) */
+	float  cutoff;      /* low-pass cutoff, in units of baud */
+} OrModem;
+
+typedef struct {
+	uint32_t channel;
+	uint32_t type;
+	int32_t  len;            /* frame length in bytes */
+	int32_t  nerr[2];        /* RS41: corrected byte errors per codeword, -1 = uncorrectable. Others: per-type error counts */
+	uint32_t flags;          /* bit0: inverted polarity */
+	uint64_t bitpos;         /* absolute bit index of the first sync bit */
+	uint8_t  data[OR_FRAME_MAX];
+} OrFrame;
+
+/* ---- stage 1: FM discriminator (SDR++ dsp::demod::FM<float>, src/main.cpp:57) ---- */
+float or_atan2(float y, float x);
+/* d[n] = wrap(phi[n]-phi[n-1]) * 2/pi ; *phi_last is carried state (0 at init) */
+void  or_discriminate(const float *iq, size_t n, float *d, float *phi_last);
+
+/* ---- stage 2: GFSK demod (sondedump gfsk.c equivalent; SPEC) ---- */
+void  or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS]);
+const OrModem *or_modem(int type);
+
+typedef struct OrDemod OrDemod;
+OrDemod *or_demod_new(int type);
+void     or_demod_free(OrDemod *d);
+/* n must be a multiple of OR_TILE.  is_iq: src is interleaved I,Q (2n floats); else n real discriminator samples */
+void     or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq);
+uint64_t or_demod_nbits(const OrDemod *d);
+/* copy bits [from, from+count) one per byte */
+void     or_demod_getbits(const OrDemod *d, uint64_t from, size_t count, uint8_t *out);
+/* debug taps for staged parity tests */
+void     or_demod_state(const OrDemod *d, int64_t *t_next, int32_t *period, float *bias, float *amp, float *yprev);
+
+/* ---- stage 3: framer + FEC ---- */
+void     or_gf256_init(void);
+uint8_t  or_gf256_mul(uint8_t a, uint8_t b);
+/* RS(255,231), poly 0x11d, roots alpha^0..alpha^23.  cw[0..23]=parity, cw[24..]=message, n = used length (<=255).
+ * returns number of corrected bytes or -1. */
+int      or_rs255_decode(uint8_t *cw, int n);
+void     or_rs255_encode(uint8_t *cw, int n);   /* fills cw[0..23] from cw[24..n) */
+uint16_t or_crc16_ccitt(const uint8_t *p, size_t n);
+
+typedef struct OrFramer OrFramer;
+OrFramer *or_framer_new(int type, uint32_t channel);
+void      or_framer_free(OrFramer *f);
+/* consume bits from the demod up to its current write position; returns number of new frames appended */
+int       or_framer_run(OrFramer *f, const OrDemod *d);
+size_t    or_framer_nframes(const OrFramer *f);
+const OrFrame *or_framer_frame(const OrFramer *f, size_t i);
+
+/* ---- whole channel convenience (= what one GPU workgroup does) ---- */
+typedef struct OrChannel OrChannel;
+OrChannel *or_channel_new(int type, uint32_t channel);
+void       or_channel_free(OrChannel *c);
+void       or_channel_feed(OrChannel *c, const float *src, size_t n, int is_iq);
+size_t     or_channel_nframes(const OrChannel *c);
+const OrFrame *or_channel_frame(const OrChannel *c, size_t i);
+OrDemod   *or_channel_demod(OrChannel *c);
+
+/* batch helper for timing: channels [0,nch) each n samples, channel-major; returns total frames.
+ * nthreads<=1: serial.  Used by bench.py cpu_baseline. */
+size_t     or_batch_run(int type, const float *iq, size_t nch, size_t n, int nthreads, OrFrame *out, size_t cap);
+
+/* ---- post-FEC derived values, restating /root/reference/src/decode/decoder.hpp:132-174 ---- */
+float or_dewpt(float temp, float rh);
+float or_altitude_to_pressure(float alt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,99 @@
+"""ctypes binding of libsonde_mi355.so (include/sonde_abi.h).
+
+The HIP library is the product: if it is missing or cannot be loaded this module raises --
+there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libsonde_mi355.so")
+
+TILE = 2048
+FRAME_MAX = 528
+(RS41, DFM09, IMS100, M10, IMET4, C50, MRZN1) = range(7)
+INPUT_IQ, INPUT_REAL = 0, 1
+PROCEED, PARSED = 0, 1
+DATA_SEQ, DATA_POS, DATA_SPEED, DATA_TIME, DATA_PTU, DATA_SERIAL, DATA_SHUTDOWN, DATA_OZONE = (1 << i for i in range(8))
+
+
+class SondeFrame(C.Structure):
+    _fields_ = [("channel", C.c_uint32), ("type", C.c_uint32), ("len", C.c_int32), ("nerr", C.c_int32 * 2),
+                ("flags", C.c_uint32), ("bitpos", C.c_uint64), ("data", C.c_uint8 * FRAME_MAX)]
+
+
+FRAME_DTYPE = np.dtype([("channel", "<u4"), ("type", "<u4"), ("len", "<i4"), ("nerr", "<i4", (2,)),
+                        ("flags", "<u4"), ("bitpos", "<u8"), ("data", "u1", (FRAME_MAX,))])
+assert FRAME_DTYPE.itemsize == C.sizeof(SondeFrame)
+
+
+class SondeData(C.Structure):
+    _fields_ = [("fields", C.c_int), ("seq", C.c_int), ("lat", C.c_float), ("lon", C.c_float), ("alt", C.c_float),
+                ("speed", C.c_float), ("heading", C.c_float), ("climb", C.c_float), ("time", C.c_int64),
+                ("calib_percent", C.c_float), ("temp", C.c_float), ("rh", C.c_float), ("pressure", C.c_float),
+                ("serial", C.c_char * 32), ("shutdown", C.c_int), ("o3_mpa", C.c_float)]
+
+
+class SondeBatchConfig(C.Structure):
+    _fields_ = [("n_channels", C.c_uint32), ("types", C.POINTER(C.c_uint8)), ("max_samples", C.c_uint32),
+                ("input_kind", C.c_int32), ("device", C.c_int32)]
+
+
+# every symbol include/sonde_abi.h declares; tests check the .so exports all of them
+ABI_SYMBOLS = [
+    "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
+    "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_kernel_ms", "sonde_batch_read_bits",
+    "sonde_batch_nbits", "sonde_batch_read_state", "sonde_get_taps", "sonde_parse_frame",
+    "sonde_last_error", "sonde_version",
+] + [f"{x}_{fn}" for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1")
+     for fn in ("decoder_init", "decoder_deinit", "decode")]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libsonde_mi355.so; raises if it was not built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C sdrpp_radiosonde_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.sonde_last_error.restype = C.c_char_p
+    L.sonde_version.restype = C.c_char_p
+    L.sonde_batch_create.argtypes = [C.POINTER(SondeBatchConfig), C.POINTER(vp)]
+    L.sonde_batch_destroy.argtypes = [vp]
+    L.sonde_batch_destroy.restype = None
+    L.sonde_batch_submit.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
+    L.sonde_batch_submit_host.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+    L.sonde_batch_sync.argtypes = [vp]
+    L.sonde_batch_sync.restype = C.c_long
+    L.sonde_batch_frames.argtypes = [vp, vp, C.c_size_t]
+    L.sonde_batch_frames.restype = C.c_long
+    L.sonde_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.sonde_batch_read_bits.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_size_t, vp]
+    L.sonde_batch_nbits.argtypes = [vp, C.c_uint32]
+    L.sonde_batch_nbits.restype = C.c_uint64
+    L.sonde_batch_read_state.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.sonde_get_taps.argtypes = [C.c_int, vp]
+    L.sonde_parse_frame.argtypes = [vp, C.POINTER(SondeData), C.c_int]
+    for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1"):
+        getattr(L, f"{x}_decoder_init").argtypes = [C.c_int]
+        getattr(L, f"{x}_decoder_init").restype = vp
+        getattr(L, f"{x}_decoder_deinit").argtypes = [vp]
+        getattr(L, f"{x}_decoder_deinit").restype = None
+        getattr(L, f"{x}_decode").argtypes = [vp, C.POINTER(SondeData), vp, C.c_size_t]
+        getattr(L, f"{x}_decode").restype = C.c_int
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().sonde_last_error().decode()

@@ -1,0 +1,107 @@
+"""Python face of the B0 batch API (include/sonde_abi.h): thin, no compute -- every call goes
+through the C ABI of libsonde_mi355.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FRAME_DTYPE, INPUT_IQ, INPUT_REAL, TILE
+
+
+class SondeError(RuntimeError):
+    pass
+
+
+class SondeBatch:
+    """Many independent 48 kS/s channels on one GPU; one HIP workgroup per channel.
+
+    submit() takes a device tensor (torch, any object with data_ptr()) shaped
+    [C, n, 2] float32 (IQ) or [C, n] float32 (discriminator samples), n % 2048 == 0.
+    """
+
+    def __init__(self, n_channels: int, max_samples: int, *, types=None, input_kind: int = INPUT_IQ, device: int = 0):
+        self.L = _lib.load()
+        self.n_channels = int(n_channels)
+        self.max_samples = int(max_samples)
+        self.input_kind = input_kind
+        cfg = _lib.SondeBatchConfig()
+        cfg.n_channels = self.n_channels
+        self._types = None
+        if types is not None:
+            self._types = np.ascontiguousarray(types, dtype=np.uint8)
+            assert self._types.shape == (self.n_channels,)
+            cfg.types = self._types.ctypes.data_as(C.POINTER(C.c_uint8))
+        cfg.max_samples = self.max_samples
+        cfg.input_kind = input_kind
+        cfg.device = device
+        h = C.c_void_p()
+        if self.L.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0:
+            raise SondeError(_lib.last_error())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sonde_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise SondeError(_lib.last_error())
+        return rc
+
+    def submit(self, samples, stream: int | None = None):
+        shape = tuple(samples.shape)
+        n = shape[1]
+        if shape[0] != self.n_channels:
+            raise SondeError("first dimension must be n_channels")
+        if self.input_kind == INPUT_IQ and (len(shape) != 3 or shape[2] != 2):
+            raise SondeError("IQ input must be [C, n, 2] float32")
+        stride = samples.stride(0) // (2 if self.input_kind == INPUT_IQ else 1)
+        self._keep = samples   # keep the device buffer alive until sync
+        self._chk(self.L.sonde_batch_submit(self.h, C.c_void_p(samples.data_ptr()), n, stride, C.c_void_p(stream or 0)))
+
+    def submit_host(self, samples: np.ndarray):
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        n = samples.shape[1]
+        self._chk(self.L.sonde_batch_submit_host(self.h, samples.ctypes.data_as(C.c_void_p), n, n))
+
+    def sync(self) -> int:
+        return self._chk(self.L.sonde_batch_sync(self.h))
+
+    def frames(self) -> np.ndarray:
+        n = self.sync()
+        out = np.zeros(n, dtype=FRAME_DTYPE)
+        if n:
+            got = self._chk(self.L.sonde_batch_frames(self.h, out.ctypes.data_as(C.c_void_p), n))
+            out = out[:got]
+        return out
+
+    def kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.L.sonde_batch_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def nbits(self, channel: int) -> int:
+        return int(self.L.sonde_batch_nbits(self.h, channel))
+
+    def read_bits(self, channel: int, start: int, count: int) -> np.ndarray:
+        out = np.zeros(count, dtype=np.uint8)
+        self._chk(self.L.sonde_batch_read_bits(self.h, channel, start, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def state(self, channel: int) -> dict:
+        t, p = C.c_int64(), C.c_int32()
+        b, a, y = C.c_float(), C.c_float(), C.c_float()
+        self._chk(self.L.sonde_batch_read_state(self.h, channel, C.byref(t), C.byref(p), C.byref(b), C.byref(a), C.byref(y)))
+        return dict(t_next=t.value, period=p.value, bias=b.value, amp=a.value, yprev=y.value)
+
+
+def get_taps(sonde_type: int) -> np.ndarray:
+    out = np.zeros((32, 32), dtype=np.float32)
+    if _lib.load().sonde_get_taps(sonde_type, out.ctypes.data_as(C.c_void_p)) != 0:
+        raise SondeError(_lib.last_error())
+    return out

@@ -1,0 +1,358 @@
+// batch.hip -- host engine of libsonde_mi355.so: the B0 batch API of include/sonde_abi.h.
+//
+// Owns the per-channel device state (demod state, ring tail, bit ring, framer state, frame slots),
+// launches kernel A (demod_kernel.hip) and kernel B (framer_kernel.hip) back to back on the caller's
+// HIP stream, and hands corrected frames back.  There is no CPU fallback: every entry point fails
+// with an error if HIP is unavailable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "sonde_dev.h"
+#include "../../include/sonde_abi.h"
+
+#include "launch.h"
+
+static thread_local std::string g_err;
+static int fail(const char *what, hipError_t e = hipSuccess)
+{
+	g_err = what;
+	if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
+	return -1;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(#x, e_); } while (0)
+
+extern "C" const char *sonde_last_error(void) { return g_err.c_str(); }
+extern "C" const char *sonde_version(void) { return "sonde_mi355 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------- modem table (SPEC)
+// Symbol (chip) rates: SURVEY.md Appendix B; the VFO bandwidths of /root/reference/src/main.hpp:44-52
+// bound them from above.
+struct ModemDef { double baud; float cutoff; };
+static const ModemDef k_modems[SONDE_NTYPES] = {
+	{ 4800.0, 0.65f },   // RS41   4800 Bd GFSK NRZ
+	{ 5000.0, 0.65f },   // DFM    2500 bit/s Manchester -> 5000 chips/s
+	{ 4800.0, 0.65f },   // iMS100 2400 bit/s biphase    -> 4800 chips/s
+	{ 9600.0, 0.65f },   // M10    9600 chips/s Manchester
+	{ 2400.0, 0.65f },   // iMet-4  (AFSK, SURVEY 8f-4: not implemented)
+	{ 2400.0, 0.65f },   // SRS-C50 (AFSK, not implemented)
+	{ 2400.0, 0.65f },   // MRZ-N1  (not implemented)
+};
+
+static int32_t modem_period0(int type) { return (int32_t)llrint(65536.0 * (double)SD_FS / k_modems[type].baud); }
+
+static void make_taps(int type, float *out /* [32][32] */)
+{
+	const double PI = 3.14159265358979323846;
+	const double fc = (double)k_modems[type].cutoff * k_modems[type].baud / (double)SD_FS;
+	for (int p = 0; p < SD_NPHASE; p++) {
+		double h[SD_NTAPS], sum = 0.0;
+		for (int j = 0; j < SD_NTAPS; j++) {
+			const double t = (double)j - (double)(SD_NTAPS / 2) + (double)p / (double)SD_NPHASE;
+			const double x = (t + (double)(SD_NTAPS / 2)) / (double)SD_NTAPS;
+			const double w = 0.42 - 0.5 * cos(2.0 * PI * x) + 0.08 * cos(4.0 * PI * x);
+			const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * PI * fc * t) / (PI * t);
+			h[j] = s * w;
+			sum += h[j];
+		}
+		for (int j = 0; j < SD_NTAPS; j++) out[p * SD_NTAPS + j] = (float)(h[j] / sum);
+	}
+}
+
+extern "C" int sonde_get_taps(int type, float *out)
+{
+	if (type < 0 || type >= SONDE_NTYPES || !out) return fail("sonde_get_taps: bad argument");
+	make_taps(type, out);
+	return 0;
+}
+
+// ---------------------------------------------------------------- batch object
+struct SondeBatch {
+	uint32_t n_channels = 0, max_samples = 0;
+	int input_kind = 0, device = 0;
+	uint32_t ring_words = 0, max_frames = 0;
+	std::vector<uint8_t> types;
+	std::vector<uint32_t> chlist[SONDE_NTYPES];
+
+	SdChanState *d_states = nullptr;
+	SdFramerState *d_fstates = nullptr;
+	float *d_hist = nullptr;
+	uint32_t *d_bitring = nullptr;
+	SondeFrame *d_frames = nullptr;
+	uint32_t *d_counts = nullptr;
+	float *d_taps = nullptr;
+	SdModem *d_modems = nullptr;
+	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr;
+	uint32_t *d_chlist[SONDE_NTYPES] = {};
+	void *d_stage = nullptr;
+	size_t stage_bytes = 0;
+
+	static const int kEvSlots = 128;       // submits timed between two sonde_batch_kernel_ms() calls
+	hipEvent_t ev[3 * kEvSlots] = {};
+	int ev_used = 0;
+	hipStream_t last_stream = nullptr;
+	bool pending = false, have_counts = false;
+	std::vector<uint32_t> h_counts;
+	long n_frames = 0;
+};
+
+static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" void sonde_batch_destroy(SondeBatch *b)
+{
+	if (!b) return;
+	(void)hipSetDevice(b->device);
+	if (b->pending) (void)hipStreamSynchronize(b->last_stream);
+	(void)hipFree(b->d_states); (void)hipFree(b->d_fstates); (void)hipFree(b->d_hist); (void)hipFree(b->d_bitring);
+	(void)hipFree(b->d_frames); (void)hipFree(b->d_counts); (void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
+	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_stage);
+	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
+	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+	delete b;
+}
+
+extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
+{
+	if (!cfg || !out) return fail("sonde_batch_create: null argument");
+	*out = nullptr;
+	if (cfg->n_channels == 0) return fail("sonde_batch_create: n_channels == 0");
+	if (cfg->max_samples == 0 || cfg->max_samples % SONDE_TILE) return fail("sonde_batch_create: max_samples must be a positive multiple of SONDE_TILE");
+	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL) return fail("sonde_batch_create: bad input_kind");
+	int ndev = 0;
+	HIPCHK(hipGetDeviceCount(&ndev));
+	if (cfg->device < 0 || cfg->device >= ndev) return fail("sonde_batch_create: no such HIP device");
+	HIPCHK(hipSetDevice(cfg->device));
+
+	SondeBatch *b = new SondeBatch;
+	b->n_channels = cfg->n_channels;
+	b->max_samples = cfg->max_samples;
+	b->input_kind = cfg->input_kind;
+	b->device = cfg->device;
+	b->types.assign(cfg->n_channels, SONDE_RS41);
+	if (cfg->types) b->types.assign(cfg->types, cfg->types + cfg->n_channels);
+	int32_t pmin = INT32_MAX;
+	for (uint32_t c = 0; c < b->n_channels; c++) {
+		const int t = b->types[c];
+		if (t < 0 || t >= SONDE_NTYPES) { delete b; return fail("sonde_batch_create: bad sonde type"); }
+		b->chlist[t].push_back(c);
+		pmin = std::min(pmin, modem_period0(t));
+	}
+	pmin -= pmin >> 8;
+	const uint64_t max_bits = ((uint64_t)cfg->max_samples << 16) / (uint64_t)pmin + 2;
+	b->ring_words = pow2ceil((uint32_t)((max_bits + 8 * SONDE_FRAME_MAX + 1024 + 31) / 32));
+	b->max_frames = (uint32_t)(max_bits / 1600) + 2;
+
+	const size_t C = b->n_channels;
+#define ALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void **)&(p), (bytes)); if (e_ != hipSuccess) { sonde_batch_destroy(b); return fail("hipMalloc " #p, e_); } } while (0)
+	ALLOC(b->d_states, C * sizeof(SdChanState));
+	ALLOC(b->d_fstates, C * sizeof(SdFramerState));
+	ALLOC(b->d_hist, C * SD_HIST * sizeof(float));
+	ALLOC(b->d_bitring, C * (size_t)b->ring_words * sizeof(uint32_t));
+	ALLOC(b->d_frames, C * (size_t)b->max_frames * sizeof(SondeFrame));
+	ALLOC(b->d_counts, C * sizeof(uint32_t));
+	ALLOC(b->d_taps, (size_t)SONDE_NTYPES * SD_NPHASE * SD_NTAPS * sizeof(float));
+	ALLOC(b->d_modems, SONDE_NTYPES * sizeof(SdModem));
+	ALLOC(b->d_gfexp, 512);
+	ALLOC(b->d_gflog, 256);
+	for (int t = 0; t < SONDE_NTYPES; t++)
+		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
+#undef ALLOC
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { sonde_batch_destroy(b); return fail(#x, e_); } } while (0)
+	// modem tables
+	std::vector<float> taps((size_t)SONDE_NTYPES * SD_NPHASE * SD_NTAPS);
+	SdModem modems[SONDE_NTYPES];
+	for (int t = 0; t < SONDE_NTYPES; t++) {
+		make_taps(t, &taps[(size_t)t * SD_NPHASE * SD_NTAPS]);
+		const int32_t p0 = modem_period0(t);
+		modems[t].period0 = p0;
+		modems[t].kp = (float)p0 * 0.159154943f;       // half of 1/pi symbol per unit error
+		modems[t].ki = modems[t].kp * (1.0f / 4096.0f);
+		modems[t].pmin = p0 - (p0 >> 8);
+		modems[t].pmax = p0 + (p0 >> 8);
+	}
+	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
+	CHK(hipMemcpy(b->d_modems, modems, sizeof(modems), hipMemcpyHostToDevice));
+	// GF(2^8) tables, primitive polynomial 0x11D
+	uint8_t gexp[512], glog[256];
+	{
+		int x = 1;
+		memset(glog, 0, sizeof(glog));
+		for (int i = 0; i < 255; i++) { gexp[i] = (uint8_t)x; glog[x] = (uint8_t)i; x <<= 1; if (x & 0x100) x ^= 0x11D; }
+		for (int i = 255; i < 512; i++) gexp[i] = gexp[i - 255];
+	}
+	CHK(hipMemcpy(b->d_gfexp, gexp, 512, hipMemcpyHostToDevice));
+	CHK(hipMemcpy(b->d_gflog, glog, 256, hipMemcpyHostToDevice));
+	// initial channel state
+	std::vector<SdChanState> st(C);
+	for (size_t c = 0; c < C; c++) {
+		memset(&st[c], 0, sizeof(SdChanState));
+		const int t = b->types[c];
+		st[c].type = t;
+		st[c].period = modems[t].period0;
+		st[c].t_next = ((int64_t)SD_NTAPS << 16) + modems[t].period0;
+		st[c].amp = 0.25f;
+	}
+	CHK(hipMemcpy(b->d_states, st.data(), C * sizeof(SdChanState), hipMemcpyHostToDevice));
+	CHK(hipMemset(b->d_fstates, 0, C * sizeof(SdFramerState)));
+	CHK(hipMemset(b->d_hist, 0, C * SD_HIST * sizeof(float)));
+	CHK(hipMemset(b->d_bitring, 0, C * (size_t)b->ring_words * sizeof(uint32_t)));
+	CHK(hipMemset(b->d_counts, 0, C * sizeof(uint32_t)));
+	for (int t = 0; t < SONDE_NTYPES; t++)
+		if (!b->chlist[t].empty())
+			CHK(hipMemcpy(b->d_chlist[t], b->chlist[t].data(), b->chlist[t].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) CHK(hipEventCreate(&b->ev[i]));
+#undef CHK
+	b->h_counts.assign(C, 0);
+	*out = b;
+	return 0;
+}
+
+extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_)
+{
+	if (!b || !samples) return fail("sonde_batch_submit: null argument");
+	if (n_samples == 0 || n_samples % SONDE_TILE || n_samples > b->max_samples) return fail("sonde_batch_submit: n_samples must be a multiple of SONDE_TILE and <= max_samples");
+	if (channel_stride < n_samples) return fail("sonde_batch_submit: channel_stride < n_samples");
+	HIPCHK(hipSetDevice(b->device));
+	hipStream_t stream = (hipStream_t)stream_;
+	const int n_tiles = (int)(n_samples / SONDE_TILE);
+	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
+	HIPCHK(hipEventRecord(ev[0], stream));
+	sd_launch_demod(b->input_kind == SONDE_INPUT_IQ, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
+		b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(ev[1], stream));
+	HIPCHK(hipMemsetAsync(b->d_counts, 0, b->n_channels * sizeof(uint32_t), stream));
+	if (!b->chlist[SONDE_RS41].empty()) {
+		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
+			b->d_states, b->d_fstates, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog,
+			b->d_frames, b->d_counts, b->max_frames, b->d_chlist[SONDE_RS41]);
+		HIPCHK(hipGetLastError());
+	}
+	HIPCHK(hipEventRecord(ev[2], stream));
+	b->ev_used++;
+	b->last_stream = stream;
+	b->pending = true;
+	b->have_counts = false;
+	return 0;
+}
+
+extern "C" int sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride)
+{
+	if (!b || !samples) return fail("sonde_batch_submit_host: null argument");
+	if (n_samples == 0 || n_samples % SONDE_TILE || n_samples > b->max_samples) return fail("sonde_batch_submit_host: bad n_samples");
+	HIPCHK(hipSetDevice(b->device));
+	const size_t elem = b->input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : sizeof(float);
+	const size_t need = (size_t)b->n_channels * b->max_samples * elem;
+	if (b->stage_bytes < need) {
+		(void)hipFree(b->d_stage);
+		b->d_stage = nullptr;
+		b->stage_bytes = 0;
+		HIPCHK(hipMalloc(&b->d_stage, need));
+		b->stage_bytes = need;
+	}
+	if (b->pending) HIPCHK(hipStreamSynchronize(b->last_stream));
+	HIPCHK(hipMemcpy2D(b->d_stage, n_samples * elem, samples, channel_stride * elem, n_samples * elem, b->n_channels, hipMemcpyHostToDevice));
+	return sonde_batch_submit(b, b->d_stage, n_samples, n_samples, nullptr);
+}
+
+extern "C" long sonde_batch_sync(SondeBatch *b)
+{
+	if (!b) return fail("sonde_batch_sync: null argument");
+	if (hipSetDevice(b->device) != hipSuccess) return fail("hipSetDevice");
+	if (b->pending) {
+		hipError_t e = hipStreamSynchronize(b->last_stream);
+		if (e != hipSuccess) return fail("hipStreamSynchronize", e);
+		b->pending = false;
+	}
+	if (!b->have_counts) {
+		hipError_t e = hipMemcpy(b->h_counts.data(), b->d_counts, b->n_channels * sizeof(uint32_t), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return fail("hipMemcpy counts", e);
+		long n = 0;
+		for (uint32_t c = 0; c < b->n_channels; c++) n += std::min(b->h_counts[c], b->max_frames);
+		b->n_frames = n;
+		b->have_counts = true;
+	}
+	return b->n_frames;
+}
+
+extern "C" long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap)
+{
+	const long n = sonde_batch_sync(b);
+	if (n < 0) return n;
+	if (n == 0 || !out || cap == 0) return 0;
+	// frames sit in per-channel slot groups: gather the used slots (already ordered by channel, then time)
+	size_t k = 0;
+	for (uint32_t c = 0; c < b->n_channels && k < cap; c++) {
+		const uint32_t cnt = std::min(b->h_counts[c], b->max_frames);
+		if (!cnt) continue;
+		const size_t take = std::min((size_t)cnt, cap - k);
+		hipError_t e = hipMemcpy(out + k, b->d_frames + (size_t)c * b->max_frames, take * sizeof(SondeFrame), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return fail("hipMemcpy frames", e);
+		k += take;
+	}
+	return (long)k;
+}
+
+extern "C" int sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *framer_ms)
+{
+	if (!b) return fail("sonde_batch_kernel_ms: null argument");
+	if (sonde_batch_sync(b) < 0) return -1;
+	float a = 0.0f, c = 0.0f;
+	const int n = std::min(b->ev_used, (int)SondeBatch::kEvSlots);
+	if (n == 0) return fail("sonde_batch_kernel_ms: no submit since the last query");
+	for (int i = 0; i < n; i++) {
+		float x = 0.0f, y = 0.0f;
+		HIPCHK(hipEventElapsedTime(&x, b->ev[3 * i], b->ev[3 * i + 1]));
+		HIPCHK(hipEventElapsedTime(&y, b->ev[3 * i + 1], b->ev[3 * i + 2]));
+		a += x; c += y;
+	}
+	a /= (float)n; c /= (float)n;
+	b->ev_used = 0;
+	if (demod_ms) *demod_ms = a;
+	if (framer_ms) *framer_ms = c;
+	return 0;
+}
+
+// ---------------------------------------------------------------- introspection (staged parity tests)
+extern "C" uint64_t sonde_batch_nbits(SondeBatch *b, uint32_t channel)
+{
+	if (!b || channel >= b->n_channels) { fail("sonde_batch_nbits: bad argument"); return 0; }
+	if (sonde_batch_sync(b) < 0) return 0;
+	SdChanState st;
+	if (hipMemcpy(&st, b->d_states + channel, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) { fail("hipMemcpy state"); return 0; }
+	return st.wpos;
+}
+
+extern "C" int sonde_batch_read_bits(SondeBatch *b, uint32_t channel, uint64_t from, size_t count, uint8_t *out)
+{
+	if (!b || channel >= b->n_channels || !out) return fail("sonde_batch_read_bits: bad argument");
+	if (sonde_batch_sync(b) < 0) return -1;
+	SdChanState st;
+	HIPCHK(hipMemcpy(&st, b->d_states + channel, sizeof(st), hipMemcpyDeviceToHost));
+	const uint64_t ring_bits = (uint64_t)b->ring_words * 32;
+	if (from + count > st.wpos || st.wpos - from > ring_bits) return fail("sonde_batch_read_bits: range not in the ring");
+	std::vector<uint32_t> ring(b->ring_words);
+	HIPCHK(hipMemcpy(ring.data(), b->d_bitring + (size_t)channel * b->ring_words, (size_t)b->ring_words * 4, hipMemcpyDeviceToHost));
+	for (size_t i = 0; i < count; i++) {
+		const uint64_t p = from + i;
+		out[i] = (ring[(p >> 5) & (b->ring_words - 1)] >> (p & 31)) & 1u;
+	}
+	return 0;
+}
+
+extern "C" int sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp, float *yprev)
+{
+	if (!b || channel >= b->n_channels) return fail("sonde_batch_read_state: bad argument");
+	if (sonde_batch_sync(b) < 0) return -1;
+	SdChanState st;
+	HIPCHK(hipMemcpy(&st, b->d_states + channel, sizeof(st), hipMemcpyDeviceToHost));
+	if (t_next) *t_next = st.t_next;
+	if (period) *period = st.period;
+	if (bias) *bias = st.bias;
+	if (amp) *amp = st.amp;
+	if (yprev) *yprev = st.yprev;
+	return 0;
+}

@@ -1,0 +1,14 @@
+// launch.h -- host-side launchers of the HIP kernels (one per kernel translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sonde_dev.h"
+#include "../../include/sonde_abi.h"
+
+void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
+	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
+	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems);
+
+void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,
+	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
+	const uint8_t *gf_exp, const uint8_t *gf_log, SondeFrame *frames, uint32_t *counts, uint32_t max_frames,
+	const uint32_t *chlist);

@@ -1,0 +1,20 @@
+// parse.h -- frame -> SondeData fragments (host side, after FEC; tiny per-frame work).
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "../../include/sonde_abi.h"
+
+// Stateful per-channel parser: RS41 calibration data arrives as 51 fragments spread over 51 frames.
+class SondeParser {
+public:
+	explicit SondeParser(int type) : m_type(type) {}
+	// Appends the fragments of one frame (one per valid subframe, in frame order).
+	void feed(const SondeFrame &f, std::vector<SondeData> &out);
+private:
+	void feed_rs41(const SondeFrame &f, std::vector<SondeData> &out);
+	int m_type;
+	uint64_t m_calib_mask = 0;         // RS41: which of the 51 calibration fragments have been seen
+	uint8_t m_calib[51 * 16] = {};
+};
+
+uint16_t sonde_crc16_ccitt(const uint8_t *p, size_t n);

@@ -1,0 +1,46 @@
+// sonde_dev.h -- device-side state layout and SPEC constants shared by the HIP kernels and the
+// host engine of libsonde_mi355.so.  (Product code: never includes anything from oracle/.)
+//
+// The arithmetic contract these kernels implement is DESIGN.md section 3; it stands where sondedump's
+// gfsk_demod/framer/rs sit behind X_decode (/root/reference/src/decode/decoder.hpp:22,61).
+#pragma once
+#include <stdint.h>
+
+#define SD_FS         48000
+#define SD_TILE       2048        // samples per tile
+#define SD_RING       4096        // discriminator ring, floats (LDS)
+#define SD_NTAPS      32
+#define SD_NPHASE     32
+#define SD_TAPS_LD    33          // padded leading dimension of the tap table in LDS
+#define SD_ROUND_MAX  256         // = workgroup size of the demod kernel
+#define SD_HIST       256         // ring samples carried between submits
+#define SD_WG         256
+
+struct SdModem {            // per sonde type, built on the host
+	int32_t period0;        // Q16 samples per symbol
+	float   kp;             // proportional gain, Q16 samples per unit error
+	float   ki;             // integral gain
+	int32_t pmin, pmax;     // period clamp
+};
+
+struct SdChanState {        // demodulator state, one per channel (64 B)
+	int64_t  t_next;        // Q16 absolute on-time instant of the next symbol
+	int64_t  n0;            // samples consumed
+	uint64_t wpos;          // bits produced
+	int32_t  period;        // Q16
+	float    yprev;
+	float    bias;
+	float    amp;
+	float    phi_last;
+	int32_t  nstat;
+	int32_t  type;
+	int32_t  pad[3];
+};
+
+struct SdFramerState {      // framer state, one per channel (32 B)
+	uint64_t rpos;
+	uint64_t fstart;
+	int32_t  collecting;
+	int32_t  inv;
+	int32_t  pad[2];
+};

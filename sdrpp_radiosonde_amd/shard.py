@@ -1,0 +1,45 @@
+"""Channel sharding across the GPUs of one node.
+
+Channels are independent units: rank r of W owns the contiguous range
+[r*C/W, (r+1)*C/W).  The only exchange step the path has is the ingest scatter of IQ blocks from
+the rank that holds them (RCCL grouped send/recv over xGMI on GPUs, gloo on CPU in the tests) and
+the small gather of decoded frames; there is no all-reduce anywhere on the data path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def channel_range(n_channels: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced partition; the first (n % world) ranks get one extra channel."""
+    base, extra = divmod(n_channels, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def scatter_iq(full: torch.Tensor | None, channels_per_rank: int, n_samples: int, device, src: int = 0,
+               group=None) -> torch.Tensor:
+    """Scatter [W*C, n, 2] float32 IQ held by `src` so that every rank gets its [C, n, 2] shard."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    out = torch.empty((channels_per_rank, n_samples, 2), dtype=torch.float32, device=device)
+    chunks = None
+    if rank == src:
+        assert full is not None and full.shape[0] == world * channels_per_rank
+        chunks = [c.contiguous() for c in full.chunk(world, dim=0)]
+    dist.scatter(out, scatter_list=chunks, src=src, group=group)
+    return out
+
+
+def gather_frames(frames: np.ndarray, dst: int = 0, group=None) -> np.ndarray | None:
+    """Gather per-rank frame records (structured array, channel ids already global) on `dst`."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    objs = [None] * world if rank == dst else None
+    dist.gather_object(frames, objs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    allf = np.concatenate(objs)
+    return allf[np.lexsort((allf["bitpos"], allf["channel"]))]

@@ -1,0 +1,285 @@
+"""Synthetic radiosonde signal generator (test/bench input, not part of the decode path).
+
+Builds valid RS41-SG frames (header, RS(255,231) parity, frame type, CRC16'd
+subframes, XOR whitening -- SURVEY.md Appendix B.2), serialises them LSB-first
+and modulates them as Gaussian-filtered 2-FSK complex baseband IQ at 48 kS/s
+(SURVEY.md section 8d "Synthetic signal").  The Reed-Solomon *encoder* here is an
+independent numpy implementation; the decoders (oracle C, HIP) never share
+code with it, so generator -> decoder round trips are a real cross-check.
+
+The modulator runs on any torch device: CPU for the parity tests, the GPU for
+bench.py's large batches.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+FS = 48000  # /root/reference/src/main.cpp:16  OUT_SAMPLE_RATE
+
+# ---------------------------------------------------------------- GF(2^8) / RS(255,231)
+_GF_EXP = np.zeros(512, dtype=np.int32)
+_GF_LOG = np.zeros(256, dtype=np.int32)
+_x = 1
+for _i in range(255):
+    _GF_EXP[_i] = _x
+    _GF_LOG[_x] = _i
+    _x <<= 1
+    if _x & 0x100:
+        _x ^= 0x11D
+_GF_EXP[255:510] = _GF_EXP[0:255]
+
+
+def gf_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.int32)
+    b = np.asarray(b, dtype=np.int32)
+    out = _GF_EXP[(_GF_LOG[a] + _GF_LOG[b]) % 255]
+    return np.where((a == 0) | (b == 0), 0, out).astype(np.int32)
+
+
+def _rs_generator(nroots: int = 24) -> np.ndarray:
+    g = np.array([1], dtype=np.int32)
+    for j in range(nroots):
+        # multiply by (x + alpha^j); little-endian coefficients
+        shifted = np.concatenate([[0], g])
+        scaled = np.concatenate([gf_mul(g, _GF_EXP[j]), [0]])
+        g = shifted ^ scaled
+    return g.astype(np.int32)
+
+
+_RS_G = _rs_generator()
+
+
+def rs_parity(msg: np.ndarray) -> np.ndarray:
+    """msg: [F, k] bytes (coefficient of x^(24+i) is msg[:, i]).  Returns [F, 24] parity
+    (coefficients of x^0..x^23) such that the codeword has roots alpha^0..alpha^23."""
+    msg = np.asarray(msg, dtype=np.int32)
+    F, k = msg.shape
+    rem = np.zeros((F, 24), dtype=np.int32)
+    for i in range(k - 1, -1, -1):
+        fb = msg[:, i] ^ rem[:, 23]
+        new = np.zeros_like(rem)
+        new[:, 1:] = rem[:, :-1]
+        new ^= gf_mul(fb[:, None], _RS_G[None, :24])
+        rem = new
+    return rem
+
+
+def crc16_ccitt(data: np.ndarray) -> np.ndarray:
+    """data: [F, n] bytes -> [F] CRC16-CCITT (0x1021, init 0xFFFF)."""
+    data = np.asarray(data, dtype=np.uint32)
+    crc = np.full(data.shape[0], 0xFFFF, dtype=np.uint32)
+    for i in range(data.shape[1]):
+        crc ^= data[:, i] << 8
+        for _ in range(8):
+            hi = (crc & 0x8000) != 0
+            crc = (crc << 1) & 0xFFFF
+            crc = np.where(hi, crc ^ 0x1021, crc)
+    return crc
+
+
+# ---------------------------------------------------------------- RS41 frame builder
+RS41_HEADER_AIR = np.array([0x10, 0xB6, 0xCA, 0x11, 0x22, 0x96, 0x12, 0xF8], dtype=np.uint8)
+RS41_MASK = np.array([
+    0x96, 0x83, 0x3E, 0x51, 0xB1, 0x49, 0x08, 0x98, 0x32, 0x05, 0x59, 0x0E, 0xF9, 0x44, 0xC6, 0x26,
+    0x21, 0x60, 0xC2, 0xEA, 0x79, 0x5D, 0x6D, 0xA1, 0x54, 0x69, 0x47, 0x0C, 0xDC, 0xE8, 0x5C, 0xF1,
+    0xF7, 0x76, 0x82, 0x7F, 0x07, 0x99, 0xA2, 0x2C, 0x93, 0x7C, 0x30, 0x63, 0xF5, 0x10, 0x2E, 0x61,
+    0xD0, 0xBC, 0xB4, 0xB6, 0x06, 0xAA, 0xF4, 0x23, 0x78, 0x6E, 0x3B, 0xAE, 0xBF, 0x7B, 0x4C, 0xC1,
+], dtype=np.uint8)
+RS41_STD_LEN = 320
+RS41_EXT_LEN = 518
+# (type, payload length) of the standard RS41-SG frame; 57 + sum(len+4) = 320
+RS41_SUBFRAMES_STD = [(0x79, 0x28), (0x7A, 0x2A), (0x7C, 0x1E), (0x7D, 0x59), (0x7B, 0x15), (0x76, 0x11)]
+# extended frame carries an XDATA (0x7E) block and a longer pad; 57 + sum(len+4) = 518
+RS41_SUBFRAMES_EXT = [(0x79, 0x28), (0x7A, 0x2A), (0x7C, 0x1E), (0x7D, 0x59), (0x7B, 0x15), (0x7E, 0x3C), (0x76, 0x97)]
+
+
+def _put_le(buf: np.ndarray, off: int, val: np.ndarray, nbytes: int) -> None:
+    v = np.asarray(val).astype(np.int64)
+    for b in range(nbytes):
+        buf[:, off + b] = (v >> (8 * b)) & 0xFF
+
+
+def rs41_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray, extended: bool = False) -> np.ndarray:
+    """Return unscrambled RS41 frames [F, len] (uint8) for the (channel, frame number) pairs.
+
+    Telemetry values are deterministic functions of (seed, channel, frame) so any
+    frame can be regenerated alone; they are physically plausible (ECEF position
+    near 47N 8E climbing at 5 m/s) so the field parsers have something to chew on.
+    """
+    channel_ids = np.asarray(channel_ids, dtype=np.int64)
+    frame_idx = np.asarray(frame_idx, dtype=np.int64)
+    F = channel_ids.shape[0]
+    flen = RS41_EXT_LEN if extended else RS41_STD_LEN
+    layout = RS41_SUBFRAMES_EXT if extended else RS41_SUBFRAMES_STD
+    fr = np.zeros((F, flen), dtype=np.uint8)
+    fr[:, 0:8] = RS41_HEADER_AIR ^ RS41_MASK[0:8]
+    fr[:, 56] = 0xF0 if extended else 0x0F
+
+    rng = np.random.Generator(np.random.Philox(key=seed & 0xFFFFFFFFFFFFFFFF))
+    # per-frame random filler, reproducible from (seed, channel, frame): hash into a Philox counter
+    filler = np.zeros((F, flen), dtype=np.uint8)
+    for i in range(F):
+        g = np.random.Generator(np.random.Philox(key=(seed ^ (int(channel_ids[i]) << 20) ^ int(frame_idx[i])) & 0xFFFFFFFFFFFFFFFF))
+        filler[i] = g.integers(0, 256, size=flen, dtype=np.uint8)
+    del rng
+
+    off = 57
+    for (stype, slen) in layout:
+        fr[:, off] = stype
+        fr[:, off + 1] = slen
+        body = fr[:, off + 2: off + 2 + slen]
+        body[:] = filler[:, off + 2: off + 2 + slen]
+        if stype == 0x79:  # status: frame number, serial, calibration fragment
+            seq = 1000 + frame_idx
+            _put_le(body, 0, seq, 2)
+            for i in range(F):
+                body[i, 2:10] = np.frombuffer(("S%07d" % (int(channel_ids[i]) % 10000000)).encode(), dtype=np.uint8)
+            body[:, 23] = (seq % 51).astype(np.uint8)  # calibration fragment index
+        elif stype == 0x7C:  # GPS info: week, ms of week
+            _put_le(body, 0, np.full(F, 2200), 2)
+            _put_le(body, 2, (frame_idx * 1000 + 123456000) % 604800000, 4)
+        elif stype == 0x7B:  # GPS position: ECEF cm, velocity cm/s
+            lat = math.radians(47.0) + 1e-5 * channel_ids
+            lon = math.radians(8.0) + 1e-6 * frame_idx
+            alt = 1000.0 + 5.0 * frame_idx
+            a, e2 = 6378137.0, 6.69437999014e-3
+            Nn = a / np.sqrt(1 - e2 * np.sin(lat) ** 2)
+            X = (Nn + alt) * np.cos(lat) * np.cos(lon)
+            Y = (Nn + alt) * np.cos(lat) * np.sin(lon)
+            Z = (Nn * (1 - e2) + alt) * np.sin(lat)
+            _put_le(body, 0, np.round(X * 100).astype(np.int64) & 0xFFFFFFFF, 4)
+            _put_le(body, 4, np.round(Y * 100).astype(np.int64) & 0xFFFFFFFF, 4)
+            _put_le(body, 8, np.round(Z * 100).astype(np.int64) & 0xFFFFFFFF, 4)
+            up = np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)], axis=1)
+            east = np.stack([-np.sin(lon), np.cos(lon), np.zeros(F)], axis=1)
+            v = 5.0 * up + 12.0 * east
+            for k in range(3):
+                _put_le(body, 12 + 2 * k, np.round(v[:, k] * 100).astype(np.int64) & 0xFFFF, 2)
+            body[:, 18] = 9  # sats
+        elif stype == 0x76:
+            body[:] = 0
+        crc = crc16_ccitt(body)
+        fr[:, off + 2 + slen] = crc & 0xFF
+        fr[:, off + 3 + slen] = (crc >> 8) & 0xFF
+        off += slen + 4
+    assert off == flen, (off, flen)
+
+    for c in range(2):
+        msg = fr[:, 56 + c::2]
+        fr[:, 8 + 24 * c: 32 + 24 * c] = rs_parity(msg).astype(np.uint8)
+    return fr
+
+
+def rs41_scramble(frames: np.ndarray) -> np.ndarray:
+    n = frames.shape[1]
+    mask = np.tile(RS41_MASK, (n + 63) // 64)[:n]
+    return frames ^ mask[None, :]
+
+
+def bytes_to_bits_lsb(b: np.ndarray) -> np.ndarray:
+    """[F, n] bytes -> [F, 8n] bits, least significant bit of each byte first (RS41 air order)."""
+    return np.unpackbits(b[..., None], axis=-1, bitorder="little").reshape(b.shape[0], -1)
+
+
+@dataclass
+class SynthBatch:
+    iq: torch.Tensor            # [C, n, 2] float32 (I, Q) on `device`
+    frames: list                # per channel: list of (bit_offset, unscrambled frame bytes np.uint8)
+    bits: np.ndarray            # [C, nbits] transmitted bit stream
+    cfo_hz: np.ndarray
+    tau: np.ndarray
+    amp: np.ndarray
+
+
+def rs41_bitstreams(seed: int, channels: np.ndarray, nbits: int, extended: bool = False, preamble_bytes: int = 40):
+    """Continuous on-air bit streams: random lead-in of alternating bits, then
+    [40-byte alternating preamble | whitened frame] back to back."""
+    channels = np.asarray(channels, dtype=np.int64)
+    C = channels.shape[0]
+    flen = RS41_EXT_LEN if extended else RS41_STD_LEN
+    stride = 8 * (flen + preamble_bytes)
+    nfr = nbits // stride + 2
+    rng = np.random.Generator(np.random.Philox(key=(seed * 7919 + 17) & 0xFFFFFFFFFFFFFFFF))
+    lead = rng.integers(64, stride, size=C)
+    ch_rep = np.repeat(channels, nfr)
+    fi_rep = np.tile(np.arange(nfr), C)
+    frames = rs41_build_frames(seed, ch_rep, fi_rep, extended).reshape(C, nfr, flen)
+    air = rs41_scramble(frames.reshape(C * nfr, flen))
+    fbits = bytes_to_bits_lsb(air).reshape(C, nfr, 8 * flen)
+    alt = (np.arange(stride + 8 * preamble_bytes) & 1).astype(np.uint8)
+    bits = np.zeros((C, nbits + stride * 2), dtype=np.uint8)
+    out_frames = []
+    for c in range(C):
+        pos = int(lead[c])
+        bits[c, :pos] = alt[:pos]
+        lst = []
+        for f in range(nfr):
+            if pos >= nbits:
+                break
+            bits[c, pos: pos + 8 * preamble_bytes] = alt[: 8 * preamble_bytes]
+            pos += 8 * preamble_bytes
+            bits[c, pos: pos + 8 * flen] = fbits[c, f]
+            if pos + 8 * flen <= nbits:
+                lst.append((pos, frames[c, f].copy()))
+            pos += 8 * flen
+        out_frames.append(lst)
+    return bits[:, :nbits], out_frames
+
+
+def gfsk_modulate(bits: np.ndarray, n_samples: int, baud: float, *, seed: int = 0, ebn0_db: float = 30.0,
+                  h: float = 1.0, bt: float = 0.5, cfo_max_hz: float = 500.0, amp_range=(0.25, 1.0),
+                  device: str | torch.device = "cpu", chunk: int = 256, invert: bool = False):
+    """bits: [C, nbits] -> IQ [C, n_samples, 2] float32.  Per channel: CFO ~ U(-cfo_max, cfo_max),
+    timing offset ~ U(0, 1) symbol, amplitude ~ U(amp_range), complex AWGN at Eb/N0."""
+    C, nbits = bits.shape
+    sps = FS / baud
+    assert nbits >= int(n_samples / sps) + 4, "need more bits"
+    rng = np.random.Generator(np.random.Philox(key=(seed * 104729 + 5) & 0xFFFFFFFFFFFFFFFF))
+    cfo = rng.uniform(-cfo_max_hz, cfo_max_hz, size=C)
+    tau = rng.uniform(0.0, 1.0, size=C)
+    amp = rng.uniform(amp_range[0], amp_range[1], size=C)
+    dev = h * baud / 2.0
+    sigma_t = math.sqrt(math.log(2.0)) / (2.0 * math.pi * bt)  # in symbols
+    k_erf = 1.0 / (sigma_t * math.sqrt(2.0))
+    out = torch.empty((C, n_samples, 2), dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed * 2654435761 % (2 ** 63))
+    n = torch.arange(n_samples, device=device, dtype=torch.float64)
+    for c0 in range(0, C, chunk):
+        c1 = min(C, c0 + chunk)
+        nrz = torch.from_numpy(bits[c0:c1].astype(np.float32) * 2.0 - 1.0).to(device)
+        if invert:
+            nrz = -nrz
+        u = n[None, :] / sps - torch.from_numpy(tau[c0:c1]).to(device)[:, None]  # symbol units
+        k0 = torch.floor(u).to(torch.int64)
+        f = torch.zeros_like(u)
+        for j in range(-2, 3):
+            k = k0 + j
+            valid = (k >= 0) & (k < nbits)
+            a = torch.gather(nrz, 1, k.clamp(0, nbits - 1)).to(torch.float64) * valid
+            x = u - k.to(torch.float64) - 0.5
+            f += a * 0.5 * (torch.erf(k_erf * (x + 0.5)) - torch.erf(k_erf * (x - 0.5)))
+        f = f * dev + torch.from_numpy(cfo[c0:c1]).to(device)[:, None]
+        ph = torch.cumsum(f, dim=1) * (2.0 * math.pi / FS)
+        a_t = torch.from_numpy(amp[c0:c1]).to(device)[:, None]
+        sig = a_t * math.sqrt(sps / (2.0 * 10.0 ** (ebn0_db / 10.0)))
+        noise = torch.randn((c1 - c0, n_samples, 2), generator=gen, device=device, dtype=torch.float32)
+        out[c0:c1, :, 0] = (a_t * torch.cos(ph)).to(torch.float32) + sig.to(torch.float32) * noise[:, :, 0]
+        out[c0:c1, :, 1] = (a_t * torch.sin(ph)).to(torch.float32) + sig.to(torch.float32) * noise[:, :, 1]
+    return out, cfo, tau, amp
+
+
+def make_rs41_batch(n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
+                    device: str | torch.device = "cpu", first_channel: int = 0, extended: bool = False,
+                    invert: bool = False, **mod_kw) -> SynthBatch:
+    baud = 4800.0
+    nbits = int(n_samples * baud / FS) + 16
+    channels = np.arange(first_channel, first_channel + n_channels)
+    bits, frames = rs41_bitstreams(seed, channels, nbits, extended)
+    iq, cfo, tau, amp = gfsk_modulate(bits, n_samples, baud, seed=seed + first_channel, ebn0_db=ebn0_db,
+                                      device=device, invert=invert, **mod_kw)
+    return SynthBatch(iq=iq, frames=frames, bits=bits, cfo_hz=cfo, tau=tau, amp=amp)
