@@ -1,0 +1,89 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/sonde_abi.h declares,
+its host-side tables equal the oracle's, and it fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from sdrpp_radiosonde_amd import _lib
+from sdrpp_radiosonde_amd.batch import SondeBatch, SondeError, get_taps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "sonde_abi.h")).read()
+    declared = set(re.findall(r"\b(sonde_[a-z0-9_]+)\s*\(", hdr))
+    for x in re.findall(r"^SONDE_B1_DECL\(\w+,\s*(\w+)\)", hdr, flags=re.M):
+        declared |= {f"{x}_decoder_init", f"{x}_decoder_deinit", f"{x}_decode"}
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.sonde_version()
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.SondeFrame) == 560 and _lib.FRAME_DTYPE.itemsize == 560
+    assert _lib.SondeFrame.bitpos.offset == 24 and _lib.SondeFrame.data.offset == 32
+    assert C.sizeof(_lib.SondeBatchConfig) == 32
+
+
+def test_tap_tables_equal_oracle_bit_for_bit(lib, oracle):
+    L = oracle.lib()
+    for t in range(4):
+        ref = np.zeros((32, 32), dtype=np.float32)
+        L.or_make_taps(L.or_modem(t), oracle.fptr(ref.reshape(-1)))
+        got = get_taps(t)
+        assert got.tobytes() == ref.tobytes()
+        assert np.allclose(got.sum(axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback(lib):
+    with pytest.raises(SondeError):
+        SondeBatch(4, 2048)
+    assert lib.rs41_decoder_init(48000) is None        # init fails, it does not fall back
+
+
+def test_argument_validation(lib):
+    cfg = _lib.SondeBatchConfig()
+    h = C.c_void_p()
+    cfg.n_channels, cfg.max_samples = 0, 2048
+    assert lib.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0 and b"n_channels" in lib.sonde_last_error()
+    cfg.n_channels, cfg.max_samples = 4, 1000
+    assert lib.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0 and b"multiple" in lib.sonde_last_error()
+    assert lib.rs41_decoder_init(44100) is None        # reference always passes 48000 (main.cpp:16,62-68)
+
+
+def test_parse_frame_fields(lib):
+    """Frame -> SondeData fragments: seq/serial, time, position+speed of a generated frame."""
+    from sdrpp_radiosonde_amd import synth
+    fr = synth.rs41_build_frames(3, np.array([42]), np.array([7]))[0]
+    f = _lib.SondeFrame()
+    f.type, f.len = 0, 320
+    C.memmove(f.data, fr.ctypes.data, 320)
+    out = (_lib.SondeData * 8)()
+    n = lib.sonde_parse_frame(C.byref(f), out, 8)
+    frags = {out[i].fields: out[i] for i in range(n)}
+    a = frags[_lib.DATA_SEQ | _lib.DATA_SERIAL]
+    assert a.seq == 1007 and a.serial == b"S0000042"
+    t = frags[_lib.DATA_TIME]
+    assert t.time == 315964800 + 2200 * 604800 + (123456000 + 7000) // 1000 - 18
+    p = frags[_lib.DATA_POS | _lib.DATA_SPEED]
+    assert abs(p.lat - np.degrees(np.radians(47.0) + 42e-5)) < 1e-4 and abs(p.lon - np.degrees(np.radians(8.0) + 7e-6)) < 1e-4
+    assert abs(p.alt - 1035.0) < 0.5 and abs(p.climb - 5.0) < 0.02 and abs(p.speed - 12.0) < 0.02 and abs(p.heading - 90.0) < 0.2
+    # a corrupted subframe is dropped (CRC), the others survive
+    f.data[60] ^= 0xFF
+    n2 = lib.sonde_parse_frame(C.byref(f), out, 8)
+    assert n2 == n - 1

@@ -1,0 +1,182 @@
+"""CPU tests (no GPU): known-answer tests that pin the oracle, since the reference ships no golden
+vectors for this path ("parity unpinned").  KATs listed there are all here."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sdrpp_radiosonde_amd import synth
+
+
+def test_atan2_polynomial_accuracy_and_quadrants(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    xy = rng.standard_normal((20000, 2)).astype(np.float32)
+    got = np.array([L.or_atan2(float(y), float(x)) for x, y in xy], dtype=np.float64)
+    ref = np.arctan2(xy[:, 1].astype(np.float64), xy[:, 0].astype(np.float64))
+    assert np.max(np.abs(got - ref)) < 2e-5          # Abramowitz-Stegun 4.4.47: 1e-5 + float rounding
+    assert L.or_atan2(0.0, 0.0) == 0.0
+    assert L.or_atan2(0.0, 1.0) == 0.0
+    assert abs(L.or_atan2(1.0, 0.0) - np.pi / 2) < 1e-6
+    assert abs(L.or_atan2(0.0, -1.0) - np.pi) < 1e-6
+    assert abs(L.or_atan2(-1.0, 0.0) + np.pi / 2) < 1e-6
+    assert abs(L.or_atan2(-1e-30, -1.0) + np.pi) < 1e-6
+
+
+def test_discriminator_tone_and_gain(oracle):
+    """FM<float>.init(vfo->output, bw, bw/2) => gain 2/pi: a tone at +fs/8 reads 2*pi/8 * 2/pi = 0.5."""
+    L = oracle.lib()
+    n = 4096
+    ph = 2 * np.pi * (np.arange(n) / 8.0)
+    iq = np.stack([np.cos(ph), np.sin(ph)], axis=1).astype(np.float32).reshape(-1)
+    d = np.zeros(n, dtype=np.float32)
+    last = np.zeros(1, dtype=np.float32)
+    L.or_discriminate(oracle.fptr(iq), n, oracle.fptr(d), oracle.fptr(last))
+    assert np.allclose(d[1:], 0.5, atol=3e-5)
+    # negative frequency near -fs/2 exercises the wrap
+    ph = -2 * np.pi * 0.45 * np.arange(n)
+    iq = np.stack([np.cos(ph), np.sin(ph)], axis=1).astype(np.float32).reshape(-1)
+    last[:] = 0
+    L.or_discriminate(oracle.fptr(iq), n, oracle.fptr(d), oracle.fptr(last))
+    assert np.allclose(d[1:], -0.9 * 2, atol=1e-3) is False or True   # value check below
+    assert np.allclose(d[1:], -2 * 0.45 * 2, atol=2e-4)
+    # carried state: two halves == one call
+    d2 = np.zeros(n, dtype=np.float32)
+    last[:] = 0
+    L.or_discriminate(oracle.fptr(iq[: n]), n // 2, oracle.fptr(d2[: n // 2]), oracle.fptr(last))
+    L.or_discriminate(oracle.fptr(iq[n:]), n // 2, oracle.fptr(d2[n // 2:]), oracle.fptr(last))
+    assert d2.tobytes() == d.tobytes()
+
+
+def test_rs41_header_mask_kat():
+    """on-air header ^ mask[0..7] = 86 35 F4 40 93 DF 1A 60; LSB-first stream packs
+    MSB-first to 0x086D53884469481F; (518-56)/2 = 231; 56-8 = 2*24."""
+    clear = synth.RS41_HEADER_AIR ^ synth.RS41_MASK[:8]
+    assert bytes(clear) == bytes.fromhex("8635F44093DF1A60")
+    bits = synth.bytes_to_bits_lsb(synth.RS41_HEADER_AIR[None, :])[0]
+    v = 0
+    for b in bits:
+        v = (v << 1) | int(b)
+    assert v == 0x086D53884469481F
+    assert (synth.RS41_EXT_LEN - 56) // 2 == 231 and 56 - 8 == 2 * 24
+    assert 57 + sum(l + 4 for _, l in synth.RS41_SUBFRAMES_STD) == 320
+    assert 57 + sum(l + 4 for _, l in synth.RS41_SUBFRAMES_EXT) == 518
+
+
+def test_crc16_ccitt_kat(oracle):
+    msg = np.frombuffer(b"123456789", dtype=np.uint8).copy()
+    assert oracle.lib().or_crc16_ccitt(oracle.u8ptr(msg), 9) == 0x29B1
+    assert int(synth.crc16_ccitt(msg[None, :])[0]) == 0x29B1
+
+
+def test_gf256_tables(oracle):
+    L = oracle.lib()
+    assert L.or_gf256_mul(2, 0x80) == 0x1D            # x * x^7 = x^8 = 0x11D - 0x100
+    assert L.or_gf256_mul(0, 77) == 0 and L.or_gf256_mul(1, 77) == 77
+    rng = np.random.default_rng(1)
+    for a, b, c in rng.integers(1, 256, size=(200, 3)):
+        ab = L.or_gf256_mul(int(a), int(b))
+        assert L.or_gf256_mul(ab, int(c)) == L.or_gf256_mul(int(a), L.or_gf256_mul(int(b), int(c)))
+        assert ab == int(synth.gf_mul(a, b))
+
+
+@pytest.mark.parametrize("msglen", [231, 132])
+def test_rs255_encode_corrupt_decode_round_trip(oracle, msglen):
+    L = oracle.lib()
+    rng = np.random.default_rng(msglen)
+    n = 24 + msglen
+    for trial in range(60):
+        msg = rng.integers(0, 256, size=(1, msglen)).astype(np.uint8)
+        cw = np.zeros(255, dtype=np.uint8)
+        cw[24:n] = msg[0]
+        cw[:24] = synth.rs_parity(msg)[0]              # independent numpy encoder
+        enc = cw.copy()
+        enc[:24] = 0
+        L.or_rs255_encode(oracle.u8ptr(enc), n)        # oracle's own encoder agrees with it
+        assert np.array_equal(enc, cw)
+        assert L.or_rs255_decode(oracle.u8ptr(cw.copy()), n) == 0
+        nerr = trial % 13                              # 0..12 errors are always corrected
+        bad = cw.copy()
+        pos = rng.choice(n, size=nerr, replace=False)
+        bad[pos] ^= rng.integers(1, 256, size=nerr).astype(np.uint8)
+        fixed = bad.copy()
+        assert L.or_rs255_decode(oracle.u8ptr(fixed), n) == nerr
+        assert np.array_equal(fixed, cw)
+    # 13 errors: never "corrected" into the transmitted word
+    for trial in range(40):
+        msg = rng.integers(0, 256, size=(1, msglen)).astype(np.uint8)
+        cw = np.zeros(255, dtype=np.uint8)
+        cw[24:n] = msg[0]
+        cw[:24] = synth.rs_parity(msg)[0]
+        bad = cw.copy()
+        pos = rng.choice(n, size=13, replace=False)
+        bad[pos] ^= rng.integers(1, 256, size=13).astype(np.uint8)
+        out = bad.copy()
+        r = L.or_rs255_decode(oracle.u8ptr(out), n)
+        assert r == -1 or not np.array_equal(out, cw)
+        if r == -1:
+            assert np.array_equal(out, bad)            # failure leaves the word untouched
+
+
+def test_physics_kats(oracle):
+    """values the surveyor got by running the reference bodies
+    (/root/reference/src/decode/decoder.hpp:132-174)."""
+    L = oracle.lib()
+    assert abs(L.or_dewpt(-50.0, 30.0) - (-59.7688)) < 1e-4
+    assert abs(L.or_altitude_to_pressure(12000.0) - 193.3049) < 1e-3
+    # sea level, and continuity across the 7 layer edges (decoder.hpp:145)
+    assert abs(L.or_altitude_to_pressure(0.0) - 1013.25) < 1e-3
+    for edge in (11000.0, 20000.0, 32000.0, 47000.0, 51000.0):
+        lo, hi = L.or_altitude_to_pressure(edge - 0.5), L.or_altitude_to_pressure(edge + 0.5)
+        assert lo > hi and (lo - hi) / hi < 2e-3
+    # the reference's last layer starts at 77 km with the 71 km base pressure (decoder.hpp:145,147), so
+    # its table jumps UP there; the restatement keeps that quirk
+    assert L.or_altitude_to_pressure(77000.5) > L.or_altitude_to_pressure(76999.5)
+    assert L.or_altitude_to_pressure(90000.0) > 0.0
+
+
+@pytest.mark.parametrize("ebn0,min_ok", [(30.0, 1.0), (18.0, 1.0), (15.5, 0.5)])
+def test_oracle_decodes_what_the_generator_sent(oracle, ebn0, min_ok):
+    C, n = 6, 2048 * 50
+    sb = synth.make_rs41_batch(C, n, seed=77, ebn0_db=ebn0)
+    fr = oracle.batch_run(0, sb.iq.numpy(), nthreads=4)
+    sent = sum(len(f) for f in sb.frames)
+    ok = 0
+    for f in fr:
+        if (f["nerr"] >= 0).all():
+            assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in sb.frames[f["channel"]])
+            ok += 1
+    assert ok >= min_ok * sent and sent >= C
+    # bit positions are where the generator put the frames (up to the demod's constant latency)
+    for f in fr:
+        d = [int(f["bitpos"]) - pos for pos, _ in sb.frames[f["channel"]]]
+        assert min(abs(x) for x in d) <= 8
+
+
+def test_oracle_streaming_equals_one_shot(oracle):
+    C, n = 1, 2048 * 40
+    sb = synth.make_rs41_batch(C, n, seed=4, ebn0_db=20.0)
+    iq = sb.iq.numpy()[0]
+    a = oracle.Channel(0, 0)
+    a.feed(iq)
+    b = oracle.Channel(0, 0)
+    off = 0
+    for k in (3, 1, 20, 16):
+        b.feed(iq[off: off + 2048 * k])
+        off += 2048 * k
+    assert a.frames().tobytes() == b.frames().tobytes()
+    assert np.array_equal(a.bits(), b.bits()) and a.state() == b.state()
+
+
+def test_timing_loop_locks(oracle):
+    """Gardner loop: after acquisition the recovered bit stream equals the transmitted one."""
+    sb = synth.make_rs41_batch(4, 2048 * 30, seed=8, ebn0_db=40.0)
+    for c in range(4):
+        ch = oracle.Channel(0, c)
+        ch.feed(sb.iq.numpy()[c])
+        rx, tx = ch.bits(), sb.bits[c]
+        lags = range(0, 8)
+        best = min(lags, key=lambda s: np.sum(rx[1500: 5000] != tx[1500 + s: 5000 + s]))
+        assert np.sum(rx[1500: 5000] != tx[1500 + best: 5000 + best]) == 0
+        st = ch.state()
+        assert abs(st["period"] - 655360) < 200        # 4800 Bd at 48 kS/s, Q16
