@@ -1,0 +1,2 @@
+/* compat shim: the reference includes "sondedump/include/ims100.h" (src/decode/decoder.hpp:6-14) */
+#include "../../../sonde_abi.h"
