@@ -35,21 +35,47 @@
 #define AT_A7 -0.0851330f
 #define AT_A9  0.0208351f
 
+/* Reciprocal by Newton-Raphson from an integer-subtract seed: 1 integer op + 6 fmaf, the same
+ * sequence on CPU and GPU (an IEEE divide costs the GPU ~13 issue slots and does not pack into
+ * v_pk_fma_f32; this does).  Relative error ~1e-7 for normal x > 0.  SPEC 3.1. */
+float or_recip(float x)
+{
+	union { float f; uint32_t u; } v;
+	v.f = x;
+	v.u = 0x7EF311C7u - v.u;
+	float r = v.f;
+	float e = fmaf(-x, r, 1.0f);
+	r = fmaf(r, e, r);
+	e = fmaf(-x, r, 1.0f);
+	r = fmaf(r, e, r);
+	e = fmaf(-x, r, 1.0f);
+	r = fmaf(r, e, r);
+	return r;
+}
+
+static inline uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
+static inline float u2f(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
+#define TINY_BITS 0x0DA24260u   /* 1e-30f: floor of the divisor, so that atan2p(0,0) = 0 without a select */
+
+/* atan2p (SPEC 3.1): max/min of |x|,|y| are taken on the bit patterns (integer max/min: exact for all
+ * non-NaN floats and defined for every input), the octant fix-ups are written as |offset - p| and a
+ * final copysign, which is what the GPU does in 7 ALU ops per sample. */
 float or_atan2(float y, float x)
 {
-	const float ax = fabsf(x), ay = fabsf(y);
-	const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-	const float r = (mx > 0.0f) ? mn / mx : 0.0f;
+	const uint32_t ax = f2u(x) & 0x7FFFFFFFu, ay = f2u(y) & 0x7FFFFFFFu;
+	uint32_t mxb = ax > ay ? ax : ay;
+	if (mxb < TINY_BITS) mxb = TINY_BITS;
+	const uint32_t mnb = ax < ay ? ax : ay;
+	const float r = u2f(mnb) * or_recip(u2f(mxb));
 	const float s = r * r;
 	float p = fmaf(s, AT_A9, AT_A7);
 	p = fmaf(s, p, AT_A5);
 	p = fmaf(s, p, AT_A3);
 	p = fmaf(s, p, AT_A1);
 	p = p * r;
-	if (ay > ax) p = HALF_PI_F - p;
-	if (x < 0.0f) p = PI_F - p;
-	if (y < 0.0f) p = -p;
-	return p;
+	const float q2 = ((ay > ax) ? HALF_PI_F : 0.0f) - p;        /* |q2| = pi/2 - p  or  p */
+	const float q = ((f2u(x) >> 31) ? PI_F : 0.0f) - fabsf(q2);  /* |q| = pi - |q2|  or  |q2| */
+	return copysignf(q, y);
 }
 
 void or_discriminate(const float *iq, size_t n, float *d, float *phi_last)
@@ -57,10 +83,9 @@ void or_discriminate(const float *iq, size_t n, float *d, float *phi_last)
 	float prev = *phi_last;
 	for (size_t i = 0; i < n; i++) {
 		const float phi = or_atan2(iq[2 * i + 1], iq[2 * i]);
-		float diff = phi - prev;
-		if (diff > PI_F) diff = diff - TWO_PI_F;
-		else if (diff <= -PI_F) diff = diff + TWO_PI_F;
-		d[i] = diff * TWO_OVER_PI;
+		const float diff = phi - prev;
+		const float w = diff - copysignf(TWO_PI_F, diff);
+		d[i] = ((fabsf(diff) > PI_F) ? w : diff) * TWO_OVER_PI;
 		prev = phi;
 	}
 	*phi_last = prev;
@@ -139,10 +164,13 @@ static inline float interp(const OrDemod *d, int64_t pos)
 {
 	const int64_t n = pos >> 16;
 	const int p = (int)((pos >> 11) & (OR_NPHASE - 1));
-	float acc = 0.0f;
-	for (int j = 0; j < OR_NTAPS; j++)
-		acc = fmaf(d->taps[p][j], d->ring[(n + OR_NTAPS / 2 - j) & (OR_RING - 1)], acc);
-	return acc;
+	/* even and odd taps accumulate separately (one v_pk_fma_f32 per tap pair on the GPU) */
+	float acc_e = 0.0f, acc_o = 0.0f;
+	for (int j = 0; j < OR_NTAPS; j += 2) {
+		acc_e = fmaf(d->taps[p][j], d->ring[(n + OR_NTAPS / 2 - j) & (OR_RING - 1)], acc_e);
+		acc_o = fmaf(d->taps[p][j + 1], d->ring[(n + OR_NTAPS / 2 - j - 1) & (OR_RING - 1)], acc_o);
+	}
+	return acc_e + acc_o;
 }
 
 static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -156,15 +184,20 @@ static void push_bit(OrDemod *d, int b)
 	d->bits[d->nbits++] = (uint8_t)b;
 }
 
+/* One tile's worth of symbols.  The number of symbols is fixed when the tile arrives
+ * (K_total, from the timing state at that moment) and is split into rounds of at most 256;
+ * the loop filter is updated after every round.  OR_LOOKAHEAD_MARGIN samples of slack keep the
+ * FIR support inside the data when a mid-tile correction moves the instants later. */
 static void run_rounds(OrDemod *d)
 {
-	const int64_t limit = (((d->n0 - 1 - OR_NTAPS / 2) << 16) | 0xFFFF);
+	const int64_t limit = (((d->n0 - 1 - OR_NTAPS / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
 	float y[OR_ROUND_MAX], m[OR_ROUND_MAX];
+	int64_t K_total = (d->t_next <= limit) ? (limit - d->t_next) / d->period + 1 : 0;
 
-	while (d->t_next <= limit) {
-		int64_t K64 = (limit - d->t_next) / d->period + 1;
-		const int K = K64 > OR_ROUND_MAX ? OR_ROUND_MAX : (int)K64;
+	while (K_total > 0) {
+		const int K = K_total > OR_ROUND_MAX ? OR_ROUND_MAX : (int)K_total;
 		int32_t E = 0, S1 = 0, S0 = 0, C1 = 0;
+		K_total -= K;
 
 		for (int k = 0; k < K; k++) {
 			const int64_t t = d->t_next + (int64_t)k * d->period;
@@ -185,8 +218,8 @@ static void run_rounds(OrDemod *d)
 		}
 		const int32_t C0 = K - C1;
 		if (C1 > 0 && C0 > 0) {
-			const float hi = ((float)S1 / (float)C1) * (1.0f / 4096.0f);
-			const float lo = ((float)S0 / (float)C0) * (1.0f / 4096.0f);
+			const float hi = ((float)S1 * or_recip((float)C1)) * (1.0f / 4096.0f);
+			const float lo = ((float)S0 * or_recip((float)C0)) * (1.0f / 4096.0f);
 			const float c = 0.5f * (hi + lo);
 			float a = 0.5f * (hi - lo);
 			if (d->nstat == 0) {
@@ -199,8 +232,8 @@ static void run_rounds(OrDemod *d)
 			if (!(d->amp >= 1.0e-3f)) d->amp = 1.0e-3f;
 			d->nstat = 1;
 		}
-		float err = ((float)E / (float)K) * (1.0f / 1024.0f);
-		err = err / (d->amp * d->amp);
+		float err = ((float)E * or_recip((float)K)) * (1.0f / 1024.0f);
+		err = err * or_recip(d->amp * d->amp);
 		err = clampf(err, -1.0f, 1.0f);
 		const float kp = (float)d->m->period0 * 0.159154943f;   /* 0.5/pi of a symbol, Q16 samples */
 		const float ki = kp * (1.0f / 4096.0f);

@@ -43,6 +43,7 @@ extern "C" {
 #define OR_NTAPS       32         /* taps per polyphase branch */
 #define OR_NPHASE      32         /* polyphase branches (1/32 sample resolution) */
 #define OR_ROUND_MAX   256        /* max symbols per timing-loop round */
+#define OR_LOOKAHEAD_MARGIN 4     /* samples of slack behind the newest sample */
 #define OR_FRAME_MAX   528        /* bytes reserved per frame record */
 
 /* sonde types: order of supportedTypes[], /root/reference/src/main.hpp:44-52 */
@@ -66,6 +67,7 @@ typedef struct {
 } OrFrame;
 
 /* ---- stage 1: FM discriminator (SDR++ dsp::demod::FM<float>, src/main.cpp:57) ---- */
+float or_recip(float x);
 float or_atan2(float y, float x);
 /* d[n] = wrap(phi[n]-phi[n-1]) * 2/pi ; *phi_last is carried state (0 at init) */
 void  or_discriminate(const float *iq, size_t n, float *d, float *phi_last);

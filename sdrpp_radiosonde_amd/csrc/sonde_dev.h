@@ -11,9 +11,10 @@
 #define SD_RING       4096        // discriminator ring, floats (LDS)
 #define SD_NTAPS      32
 #define SD_NPHASE     32
-#define SD_TAPS_LD    33          // padded leading dimension of the tap table in LDS
+#define SD_TAPS_LD    36          // padded leading dimension of the tap table in LDS (16-B aligned rows)
 #define SD_ROUND_MAX  256         // = workgroup size of the demod kernel
-#define SD_HIST       256         // ring samples carried between submits
+#define SD_HIST       64          // discriminator samples carried between submits
+#define SD_MARGIN     4           // look-ahead slack (samples) behind the newest sample, SPEC 3.2
 #define SD_WG         256
 
 struct SdModem {            // per sonde type, built on the host

@@ -36,6 +36,8 @@ def lib():
         build()
     L = C.CDLL(path)
     f32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    L.or_recip.restype = C.c_float
+    L.or_recip.argtypes = [C.c_float]
     L.or_atan2.restype = C.c_float
     L.or_atan2.argtypes = [C.c_float, C.c_float]
     L.or_discriminate.argtypes = [f32p, C.c_size_t, f32p, f32p]
