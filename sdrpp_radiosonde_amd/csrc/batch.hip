@@ -85,7 +85,8 @@ struct SondeBatch {
 	uint32_t *d_counts = nullptr;
 	float *d_taps = nullptr;
 	SdModem *d_modems = nullptr;
-	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr;
+	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_gfmulk = nullptr;
+	void *d_descs = nullptr;
 	uint32_t *d_chlist[SONDE_NTYPES] = {};
 	void *d_stage = nullptr;
 	size_t stage_bytes = 0;
@@ -108,7 +109,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	if (b->pending) (void)hipStreamSynchronize(b->last_stream);
 	(void)hipFree(b->d_states); (void)hipFree(b->d_fstates); (void)hipFree(b->d_hist); (void)hipFree(b->d_bitring);
 	(void)hipFree(b->d_frames); (void)hipFree(b->d_counts); (void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
-	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_stage);
+	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfmulk); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	delete b;
@@ -157,6 +158,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_modems, SONDE_NTYPES * sizeof(SdModem));
 	ALLOC(b->d_gfexp, 512);
 	ALLOC(b->d_gflog, 256);
+	ALLOC(b->d_gfmulk, 24 * 256);
+	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
 #undef ALLOC
@@ -185,6 +188,12 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	}
 	CHK(hipMemcpy(b->d_gfexp, gexp, 512, hipMemcpyHostToDevice));
 	CHK(hipMemcpy(b->d_gflog, glog, 256, hipMemcpyHostToDevice));
+	{	// mulk[j][v] = v * alpha^j for the 24 syndrome roots
+		std::vector<uint8_t> mulk(24 * 256);
+		for (int j = 0; j < 24; j++)
+			for (int v = 0; v < 256; v++) mulk[256 * j + v] = v ? gexp[glog[v] + j] : 0;
+		CHK(hipMemcpy(b->d_gfmulk, mulk.data(), mulk.size(), hipMemcpyHostToDevice));
+	}
 	// initial channel state
 	std::vector<SdChanState> st(C);
 	for (size_t c = 0; c < C; c++) {
@@ -227,7 +236,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	HIPCHK(hipMemsetAsync(b->d_counts, 0, b->n_channels * sizeof(uint32_t), stream));
 	if (!b->chlist[SONDE_RS41].empty()) {
 		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
-			b->d_states, b->d_fstates, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog,
+			b->d_states, b->d_fstates, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfmulk, b->d_descs,
 			b->d_frames, b->d_counts, b->max_frames, b->d_chlist[SONDE_RS41]);
 		HIPCHK(hipGetLastError());
 	}

@@ -1,5 +1,7 @@
-// framer_kernel.hip -- kernel B: bit ring -> sync search -> de-whitening -> RS(255,231) -> frame records.
-// One 64-lane wave per channel.
+// framer_kernel.hip -- kernels B1/B2: bit ring -> sync search -> de-whitening -> RS(255,231) -> frame records.
+// B1 (sd_sync_rs41_kernel): one 64-lane wave per channel walks the new bits and lists frame starts.
+// B2 (sd_rsdec_rs41_kernel): one 64-lane wave per listed frame extracts, de-whitens and RS-decodes it,
+//     so the latency-bound GF(2^8) chains of thousands of frames overlap.
 //
 //   K4  frame-sync correlator: 64-bit window XOR sync word, popcount, both polarities; the 64
 //       candidate offsets of one step are tested one per lane and reduced with a ballot
@@ -32,6 +34,7 @@ __constant__ uint8_t c_rs41_mask[64] = {
 };
 
 struct FramerLds {
+	uint8_t mulk[RS_R * 256];      // mulk[j][v] = v * alpha^j : one dependent lookup per Horner step
 	uint8_t exp[512];
 	uint8_t log[256];
 	uint8_t frame[SONDE_FRAME_MAX];
@@ -78,8 +81,9 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 	uint8_t syn = 0;
 	if (lane < 2 * RS_R) {
 		const int c = lane / RS_R, j = lane % RS_R;
+		const uint8_t *mj = s.mulk + 256 * j;
 		for (int i = n - 1; i >= 0; i--)
-			syn = (uint8_t)((syn ? s.exp[s.log[syn] + j] : 0) ^ s.cw[c][i]);
+			syn = (uint8_t)(mj[syn] ^ s.cw[c][i]);
 		s.S[c][j] = syn;
 	}
 	const unsigned long long nzm = __ballot(syn != 0);
@@ -90,43 +94,50 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 	}
 		__syncthreads();
 
-	// ---- Berlekamp-Massey: lane 0 -> codeword 0, lane 32 -> codeword 1
-	if ((lane & 31) == 0) {
-		const int c = lane >> 5;
-		if (s.status[c] > 0) {
-			uint8_t *lam = s.lam[c], *B = s.B[c], *T = s.T[c];
-			const uint8_t *S = s.S[c];
-			for (int i = 0; i < RS_R + 2; i++) { lam[i] = 0; B[i] = 0; }
-			lam[0] = 1; B[0] = 1;
-			int L = 0, m = 1;
-			uint8_t b = 1;
-			for (int r = 0; r < RS_R; r++) {
-				uint8_t delta = S[r];
-				for (int i = 1; i <= L; i++) delta ^= gmul(s, lam[i], S[r - i]);
-				if (!delta) {
-					m++;
-				} else {
-					const uint8_t f = gdiv(s, delta, b);
-					if (2 * L <= r) {
-						for (int i = 0; i < RS_R + 2; i++) T[i] = lam[i];
-						for (int i = 0; i + m < RS_R + 2; i++) lam[i + m] ^= gmul(s, f, B[i]);
-						L = r + 1 - L;
-						for (int i = 0; i < RS_R + 2; i++) B[i] = T[i];
-						b = delta;
-						m = 1;
-					} else {
-						for (int i = 0; i + m < RS_R + 2; i++) lam[i + m] ^= gmul(s, f, B[i]);
-						m++;
-					}
-				}
+	// ---- Berlekamp-Massey, one coefficient per lane: half-wave h handles codeword h, lane idx = lane&31
+	// holds lam[idx] and Bp[idx] where Bp = x^m * B.  Same recurrence as the sequential form
+	// (delta, then lam -= delta/b * x^m B, length change iff 2L <= r), so the same Lambda comes out.
+	{
+		const int h = lane >> 5, idx = lane & 31;
+		const bool live = s.status[h] > 0;
+		uint8_t lam = (idx == 0) ? 1 : 0;
+		uint8_t Bp = (idx == 1) ? 1 : 0;
+		int L = 0;
+		uint8_t bb = 1;
+		for (int r = 0; r < RS_R; r++) {
+			const uint8_t sv = (live && idx <= r && idx <= L && idx < RS_R + 1) ? s.S[h][r - idx] : 0;
+			int t = gmul(s, lam, sv);
+			// xor-reduce over the 32 lanes of this half (two DPP rows)
+			t ^= __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true);
+			t ^= __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xF, 0xF, true);
+			t ^= __builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, true);
+			t ^= __builtin_amdgcn_update_dpp(0, t, 0x140, 0xF, 0xF, true);
+			t ^= __builtin_amdgcn_update_dpp(0, t, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1 and 3
+			const int d0 = __builtin_amdgcn_readlane(t, 31), d1 = __builtin_amdgcn_readlane(t, 63);
+			const uint8_t delta = (uint8_t)(h ? d1 : d0);
+			const uint8_t lam_old = lam;
+			bool change = false;
+			if (delta) {
+				const uint8_t f = gdiv(s, delta, bb);
+				lam = (uint8_t)(lam ^ gmul(s, f, Bp));
+				change = 2 * L <= r;
 			}
-			int deg = 0;
-			for (int i = 0; i < RS_R + 2; i++) if (lam[i]) deg = i;
-			s.L[c] = L;
-			if (L > RS_T || deg != L) s.status[c] = -1;
+			const int shifted_src = change ? (int)lam_old : (int)Bp;
+			int up = __shfl_up(shifted_src, 1, 32);
+			if (idx == 0) up = 0;
+			Bp = (uint8_t)up;
+			if (change) { L = r + 1 - L; bb = delta; }
+		}
+		if (idx < RS_R + 2) s.lam[h][idx] = lam;
+		const unsigned long long nzl = __ballot(lam != 0);
+		const uint32_t halfmask = (uint32_t)(h ? (nzl >> 32) : nzl);
+		const int deg = halfmask ? 31 - __clz(halfmask) : 0;
+		if (idx == 0 && live) {
+			s.L[h] = L;
+			if (L > RS_T || deg != L) s.status[h] = -1;
 		}
 	}
-		__syncthreads();
+	__syncthreads();
 
 	for (int c = 0; c < 2; c++) {
 		if (s.status[c] <= 0) continue;          // wave-uniform
@@ -189,101 +200,91 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 	}
 }
 
-__global__ __launch_bounds__(64) void sd_framer_rs41_kernel(
+struct SdFrameDesc {            // one frame located by B1, decoded by B2
+	uint64_t fstart;            // absolute bit index of the first sync bit
+	int32_t  flen;              // bytes
+	int32_t  inv;               // polarity
+};
+
+#define RS41_SYNC_LO 0x11CAB610u
+#define RS41_SYNC_HI 0xF8129622u
+
+// ---------------------------------------------------------------- B1: sync search
+__global__ __launch_bounds__(64) void sd_sync_rs41_kernel(
 	const SdChanState *__restrict__ states, SdFramerState *__restrict__ fstates,
 	const uint32_t *__restrict__ bitring, uint32_t ring_words,
-	const uint8_t *__restrict__ gf_exp, const uint8_t *__restrict__ gf_log,
-	SondeFrame *__restrict__ frames, uint32_t *__restrict__ counts, uint32_t max_frames,
+	SdFrameDesc *__restrict__ descs, uint32_t *__restrict__ counts, uint32_t max_frames,
 	const uint32_t *__restrict__ chlist)
 {
-	__shared__ FramerLds s;
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_ring[];   // the channel's whole bit ring
 	const int lane = threadIdx.x;
 	const uint32_t ch = chlist ? chlist[blockIdx.x] : blockIdx.x;
-	const uint32_t *ring = bitring + (size_t)ch * ring_words;
 	const uint32_t mask = ring_words - 1;
-
-	for (int i = lane; i < 512; i += 64) s.exp[i] = gf_exp[i];
-	for (int i = lane; i < 256; i += 64) s.log[i] = gf_log[i];
-		__syncthreads();
-
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(bitring + (size_t)ch * ring_words);
+		uint4 *dst = reinterpret_cast<uint4 *>(s_ring);
+		for (uint32_t i = lane; i < ring_words / 4; i += 64) dst[i] = src[i];
+	}
 	const uint64_t wpos = states[ch].wpos;
 	SdFramerState fs = fstates[ch];
 	uint32_t nout = 0;
+	__syncthreads();
 
 	for (;;) {
 		if (!fs.collecting) {
 			bool found = false;
 			while (fs.rpos + 64 <= wpos) {
-				const uint64_t p = fs.rpos + (uint64_t)lane;
-				const bool valid = p + 64 <= wpos;
-				int hd = 32;
-				if (valid) hd = __popcll(window64(ring, mask, p) ^ RS41_SYNC64);
-				const bool hit = valid && (hd <= RS41_SYNC_THR || hd >= 64 - RS41_SYNC_THR);
-				const unsigned long long hm = __ballot(hit);
+				// lane l owns the 32 positions of ring word (rpos>>5)+l
+				const uint64_t pos0 = (fs.rpos & ~31ull) + 32ull * (uint64_t)lane;
+				const uint32_t wi = (uint32_t)(pos0 >> 5);
+				const uint32_t w0 = s_ring[wi & mask], w1 = s_ring[(wi + 1) & mask], w2 = s_ring[(wi + 2) & mask];
+				// valid offsets s: pos0+s >= rpos and pos0+s+64 <= wpos
+				const int s_lo = pos0 >= fs.rpos ? 0 : (int)(fs.rpos - pos0);
+				const int64_t room = (int64_t)(wpos - 64) - (int64_t)pos0;
+				const int s_hi = room < 0 ? -1 : (room > 31 ? 31 : (int)room);
+				int first = 64, hd_first = 0;
+#pragma unroll 4
+				for (int sft = 31; sft >= 0; sft--) {
+					const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sft);
+					const uint32_t c = __popc(lo ^ RS41_SYNC_LO);
+					// necessary condition on the low half: c <= THR or c >= 32-THR
+					if ((uint32_t)(c - (RS41_SYNC_THR + 1)) >= (uint32_t)(32 - 2 * RS41_SYNC_THR - 1) && sft >= s_lo && sft <= s_hi) {
+						const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sft);
+						const int hd = (int)c + __popc(hi ^ RS41_SYNC_HI);
+						if (hd <= RS41_SYNC_THR || hd >= 64 - RS41_SYNC_THR) { first = sft; hd_first = hd; }
+					}
+				}
+				const unsigned long long hm = __ballot(first < 64);
 				if (hm) {
-					const int first = __ffsll((long long)hm) - 1;
-					const int hd1 = __shfl(hd, first, 64);
-					fs.fstart = fs.rpos + (uint64_t)first;
+					const int fl = __ffsll((long long)hm) - 1;
+					const int sf = __shfl(first, fl, 64);
+					const int hd1 = __shfl(hd_first, fl, 64);
+					fs.fstart = (fs.rpos & ~31ull) + 32ull * (uint64_t)fl + (uint64_t)sf;
 					fs.inv = hd1 >= 64 - RS41_SYNC_THR;
 					fs.collecting = 1;
 					found = true;
 					break;
 				}
-				const uint64_t remain = wpos - 63 - fs.rpos;    // candidates left
-				fs.rpos += remain < 64 ? remain : 64;
+				uint64_t next = (fs.rpos & ~31ull) + 32ull * 64ull;
+				if (next > wpos - 63) next = wpos - 63;
+				fs.rpos = next;
 			}
 			if (!found) break;
 		}
 		if (wpos < fs.fstart + 8 * (RS41_TYPE_POS + 1)) break;
 		const uint8_t xinv = fs.inv ? 0xFF : 0x00;
-		const uint8_t tb = (uint8_t)(byte_at(ring, mask, fs.fstart + 8 * RS41_TYPE_POS) ^ xinv ^ c_rs41_mask[RS41_TYPE_POS & 63]);
+		const uint8_t tb = (uint8_t)(byte_at(s_ring, mask, fs.fstart + 8 * RS41_TYPE_POS) ^ xinv ^ c_rs41_mask[RS41_TYPE_POS & 63]);
 		const bool ext = __popc(tb ^ 0xF0u) < __popc(tb ^ 0x0Fu);
 		const int flen = ext ? RS41_LEN_EXT : RS41_LEN_STD;
 		if (wpos < fs.fstart + 8 * (uint64_t)flen) break;
-
-		// K5: extract + de-whiten
-		for (int i = lane; i < flen; i += 64)
-			s.frame[i] = (uint8_t)(byte_at(ring, mask, fs.fstart + 8 * (uint64_t)i) ^ xinv ^ c_rs41_mask[i & 63]);
-				__syncthreads();
-		// K6: de-interleave into two shortened codewords
-		const int msglen = (flen - 56) / 2;
-		const int n = RS_R + msglen;
-		for (int i = lane; i < 2 * 256; i += 64) {
-			const int c = i >> 8, k = i & 255;
-			uint8_t v = 0;
-			if (k < RS_R) v = s.frame[8 + RS_R * c + k];
-			else if (k < n) v = s.frame[56 + 2 * (k - RS_R) + c];
-			s.cw[c][k] = v;
-		}
-				__syncthreads();
-		rs255_decode_pair(s, n, lane);
-		for (int c = 0; c < 2; c++) {
-			if (s.status[c] > 0) {
-				for (int k = lane; k < n; k += 64) {
-					if (k < RS_R) s.frame[8 + RS_R * c + k] = s.cw[c][k];
-					else s.frame[56 + 2 * (k - RS_R) + c] = s.cw[c][k];
-				}
-			}
-		}
-				__syncthreads();
-
-		if (nout < max_frames) {
-			SondeFrame *fr = frames + (size_t)ch * max_frames + nout;
-			if (lane == 0) {
-				fr->channel = ch;
-				fr->type = SONDE_RS41;
-				fr->len = flen;
-				fr->nerr[0] = s.status[0];
-				fr->nerr[1] = s.status[1];
-				fr->flags = fs.inv ? 1u : 0u;
-				fr->bitpos = fs.fstart;
-			}
-			for (int i = lane; i < SONDE_FRAME_MAX; i += 64) fr->data[i] = i < flen ? s.frame[i] : 0;
+		if (nout < max_frames && lane == 0) {
+			SdFrameDesc d;
+			d.fstart = fs.fstart; d.flen = flen; d.inv = fs.inv;
+			descs[(size_t)ch * max_frames + nout] = d;
 		}
 		nout++;
 		fs.rpos = fs.fstart + 8 * (uint64_t)flen;
 		fs.collecting = 0;
-				__syncthreads();
 	}
 	if (lane == 0) {
 		fstates[ch] = fs;
@@ -291,11 +292,80 @@ __global__ __launch_bounds__(64) void sd_framer_rs41_kernel(
 	}
 }
 
+// ---------------------------------------------------------------- B2: per-frame de-whitening + RS
+__global__ __launch_bounds__(64) void sd_rsdec_rs41_kernel(
+	const uint32_t *__restrict__ bitring, uint32_t ring_words,
+	const uint8_t *__restrict__ gf_exp, const uint8_t *__restrict__ gf_log, const uint8_t *__restrict__ gf_mulk,
+	const SdFrameDesc *__restrict__ descs, const uint32_t *__restrict__ counts, uint32_t max_frames,
+	SondeFrame *__restrict__ frames, const uint32_t *__restrict__ chlist)
+{
+	const uint32_t ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
+	const uint32_t k = blockIdx.x;
+	if (k >= counts[ch] || k >= max_frames) return;
+	__shared__ __attribute__((aligned(16))) FramerLds s;
+	const int lane = threadIdx.x;
+	const uint32_t *ring = bitring + (size_t)ch * ring_words;
+	const uint32_t mask = ring_words - 1;
+	const SdFrameDesc d = descs[(size_t)ch * max_frames + k];
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(gf_mulk);
+		uint4 *dst = reinterpret_cast<uint4 *>(s.mulk);
+		for (int i = lane; i < RS_R * 256 / 16; i += 64) dst[i] = src[i];
+		for (int i = lane; i < 512 / 4; i += 64) reinterpret_cast<uint32_t *>(s.exp)[i] = reinterpret_cast<const uint32_t *>(gf_exp)[i];
+		if (lane < 256 / 4) reinterpret_cast<uint32_t *>(s.log)[lane] = reinterpret_cast<const uint32_t *>(gf_log)[lane];
+	}
+	const int flen = d.flen;
+	const uint8_t xinv = d.inv ? 0xFF : 0x00;
+	// K5: extract + de-whiten
+	for (int i = lane; i < flen; i += 64)
+		s.frame[i] = (uint8_t)(byte_at(ring, mask, d.fstart + 8 * (uint64_t)i) ^ xinv ^ c_rs41_mask[i & 63]);
+	__syncthreads();
+	// K6: de-interleave into two shortened codewords
+	const int msglen = (flen - 56) / 2;
+	const int n = RS_R + msglen;
+	for (int i = lane; i < 2 * 256; i += 64) {
+		const int c = i >> 8, kk = i & 255;
+		uint8_t v = 0;
+		if (kk < RS_R) v = s.frame[8 + RS_R * c + kk];
+		else if (kk < n) v = s.frame[56 + 2 * (kk - RS_R) + c];
+		s.cw[c][kk] = v;
+	}
+	__syncthreads();
+	rs255_decode_pair(s, n, lane);
+	for (int c = 0; c < 2; c++) {
+		if (s.status[c] > 0) {
+			for (int kk = lane; kk < n; kk += 64) {
+				if (kk < RS_R) s.frame[8 + RS_R * c + kk] = s.cw[c][kk];
+				else s.frame[56 + 2 * (kk - RS_R) + c] = s.cw[c][kk];
+			}
+		}
+	}
+	__syncthreads();
+	SondeFrame *fr = frames + (size_t)ch * max_frames + k;
+	if (lane == 0) {
+		fr->channel = ch;
+		fr->type = SONDE_RS41;
+		fr->len = flen;
+		fr->nerr[0] = s.status[0];
+		fr->nerr[1] = s.status[1];
+		fr->flags = d.inv ? 1u : 0u;
+		fr->bitpos = d.fstart;
+	}
+	for (int i = lane; i < SONDE_FRAME_MAX / 4; i += 64) {
+		const int b = 4 * i;
+		uint32_t w = 0;
+		for (int q = 0; q < 4; q++) w |= (uint32_t)(b + q < flen ? s.frame[b + q] : 0) << (8 * q);
+		reinterpret_cast<uint32_t *>(fr->data)[i] = w;
+	}
+}
+
 void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
-	const uint8_t *gf_exp, const uint8_t *gf_log, SondeFrame *frames, uint32_t *counts, uint32_t max_frames,
-	const uint32_t *chlist)
+	const uint8_t *gf_exp, const uint8_t *gf_log, const uint8_t *gf_mulk, void *descs,
+	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist)
 {
-	hipLaunchKernelGGL(sd_framer_rs41_kernel, dim3(n_list), dim3(64), 0, stream,
-		states, fstates, bitring, ring_words, gf_exp, gf_log, frames, counts, max_frames, chlist);
+	hipLaunchKernelGGL(sd_sync_rs41_kernel, dim3(n_list), dim3(64), ring_words * sizeof(uint32_t), stream,
+		states, fstates, bitring, ring_words, (SdFrameDesc *)descs, counts, max_frames, chlist);
+	hipLaunchKernelGGL(sd_rsdec_rs41_kernel, dim3(max_frames, n_list), dim3(64), 0, stream,
+		bitring, ring_words, gf_exp, gf_log, gf_mulk, (const SdFrameDesc *)descs, counts, max_frames, frames, chlist);
 }

@@ -8,7 +8,8 @@ void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems);
 
+#define SD_DESC_BYTES 16   // sizeof(SdFrameDesc)
 void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
-	const uint8_t *gf_exp, const uint8_t *gf_log, SondeFrame *frames, uint32_t *counts, uint32_t max_frames,
-	const uint32_t *chlist);
+	const uint8_t *gf_exp, const uint8_t *gf_log, const uint8_t *gf_mulk, void *descs,
+	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist);
