@@ -23,17 +23,15 @@
 #include "sonde_oracle.h"
 
 #define OR_PI_D     3.14159265358979323846
-#define PI_F        3.14159274f   /* 0x40490FDB */
-#define TWO_PI_F    6.28318548f   /* 0x40C90FDB */
-#define HALF_PI_F   1.57079637f   /* 0x3FC90FDB */
-#define TWO_OVER_PI 0.636619747f  /* 0x3F22F983 */
 
-/* Abramowitz & Stegun 4.4.47, |err| <= 1e-5 rad on [0,1] */
-#define AT_A1  0.9998660f
-#define AT_A3 -0.3302995f
-#define AT_A5  0.1801410f
-#define AT_A7 -0.0851330f
-#define AT_A9  0.0208351f
+/* Abramowitz & Stegun 4.4.47 (|err| <= 1e-5 rad on [0,1]) with the discriminator gain 2/pi folded in:
+ * A_k * 2/pi rounded to binary32.  Angles are therefore in units of pi/2 ("quadrants"): pi/2 -> 1,
+ * pi -> 2, and the discriminator output needs no further scaling. */
+#define AT_A1  0.636534452f    /* 0x3F22F3EC */
+#define AT_A3 -0.210275188f    /* 0xBE575261 */
+#define AT_A5  0.114681326f    /* 0x3DEADE0B */
+#define AT_A7 -0.0541973524f   /* 0xBD5DFE0B */
+#define AT_A9  0.0132640367f   /* 0x3C595167 */
 
 /* Reciprocal by Newton-Raphson from an integer-subtract seed: 1 integer op + 6 fmaf, the same
  * sequence on CPU and GPU (an IEEE divide costs the GPU ~13 issue slots and does not pack into
@@ -55,11 +53,11 @@ float or_recip(float x)
 
 static inline uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
 static inline float u2f(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
-#define TINY_BITS 0x0DA24260u   /* 1e-30f: floor of the divisor, so that atan2p(0,0) = 0 without a select */
+#define TINY_BITS 0x0DA24260u   /* 1e-30f: floor of the divisor, so that atan2q(0,0) = 0 without a select */
 
-/* atan2p (SPEC 3.1): max/min of |x|,|y| are taken on the bit patterns (integer max/min: exact for all
- * non-NaN floats and defined for every input), the octant fix-ups are written as |offset - p| and a
- * final copysign, which is what the GPU does in 7 ALU ops per sample. */
+/* atan2q(y, x) = atan2(y, x) * 2/pi, in [-2, 2]  (SPEC 3.1).  max/min of |x|,|y| are taken on the bit
+ * patterns (exact for all non-NaN floats, defined for every input); the octant fix-ups are
+ * 1 - p, 2 - p and a final copysign.  NaN inputs are outside the contract. */
 float or_atan2(float y, float x)
 {
 	const uint32_t ax = f2u(x) & 0x7FFFFFFFu, ay = f2u(y) & 0x7FFFFFFFu;
@@ -73,22 +71,28 @@ float or_atan2(float y, float x)
 	p = fmaf(s, p, AT_A3);
 	p = fmaf(s, p, AT_A1);
 	p = p * r;
-	const float q2 = ((ay > ax) ? HALF_PI_F : 0.0f) - p;        /* |q2| = pi/2 - p  or  p */
-	const float q = ((f2u(x) >> 31) ? PI_F : 0.0f) - fabsf(q2);  /* |q| = pi - |q2|  or  |q2| */
-	return copysignf(q, y);
+	if (ay > ax) p = 1.0f - p;
+	if (f2u(x) >> 31) p = 2.0f - p;
+	return copysignf(p, y);
 }
 
-void or_discriminate(const float *iq, size_t n, float *d, float *phi_last)
+/* Quadrature FM discriminator: d[n] = arg(x[n] * conj(x[n-1])) * 2/pi.  In real arithmetic this is
+ * the wrapped phase difference SDR++'s dsp::demod::FM computes (main.cpp:57, gain 2/pi); the
+ * product form needs neither a cross-lane phase exchange nor a wrap on the GPU.
+ * last[2] = previous sample (I, Q), carried state, (0,0) at init. */
+void or_discriminate(const float *iq, size_t n, float *d, float *last)
 {
-	float prev = *phi_last;
+	float x0 = last[0], y0 = last[1];
 	for (size_t i = 0; i < n; i++) {
-		const float phi = or_atan2(iq[2 * i + 1], iq[2 * i]);
-		const float diff = phi - prev;
-		const float w = diff - copysignf(TWO_PI_F, diff);
-		d[i] = ((fabsf(diff) > PI_F) ? w : diff) * TWO_OVER_PI;
-		prev = phi;
+		const float x1 = iq[2 * i], y1 = iq[2 * i + 1];
+		const float cross = fmaf(-x1, y0, y1 * x0);
+		const float dot = fmaf(y1, y0, x1 * x0);
+		d[i] = or_atan2(cross, dot);
+		x0 = x1;
+		y0 = y1;
 	}
-	*phi_last = prev;
+	last[0] = x0;
+	last[1] = y0;
 }
 
 /* ---- modem table.  Baud rates: SURVEY.md Appendix B [RECALL]; VFO bandwidths in
@@ -138,7 +142,7 @@ struct OrDemod {
 	float taps[OR_NPHASE][OR_NTAPS];
 	float ring[OR_RING];
 	int64_t n0;          /* samples consumed so far */
-	float phi_last;
+	float iq_last[2];
 	int64_t t_next;      /* Q16 absolute on-time instant of the next symbol */
 	int32_t period;      /* Q16 samples per symbol */
 	float yprev, bias, amp;
@@ -254,7 +258,7 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 	float tile[OR_TILE];
 	for (size_t off = 0; off + OR_TILE <= n; off += OR_TILE) {
 		if (is_iq) {
-			or_discriminate(src + 2 * off, OR_TILE, tile, &d->phi_last);
+			or_discriminate(src + 2 * off, OR_TILE, tile, d->iq_last);
 		} else {
 			memcpy(tile, src + off, sizeof(tile));
 		}

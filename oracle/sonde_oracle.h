@@ -69,8 +69,8 @@ typedef struct {
 /* ---- stage 1: FM discriminator (SDR++ dsp::demod::FM<float>, src/main.cpp:57) ---- */
 float or_recip(float x);
 float or_atan2(float y, float x);
-/* d[n] = wrap(phi[n]-phi[n-1]) * 2/pi ; *phi_last is carried state (0 at init) */
-void  or_discriminate(const float *iq, size_t n, float *d, float *phi_last);
+/* d[n] = arg(x[n]*conj(x[n-1])) * 2/pi ; last[2] = previous (I,Q), carried state ((0,0) at init) */
+void  or_discriminate(const float *iq, size_t n, float *d, float *last);
 
 /* ---- stage 2: GFSK demod (sondedump gfsk.c equivalent; SPEC) ---- */
 void  or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS]);

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libsonde_mi355.so")
+# SONDE_MI355_LIB: developer override used for A/B timing of kernel variants (still a HIP build of this tree)
+LIB_PATH = os.environ.get("SONDE_MI355_LIB") or os.path.join(PKG_DIR, "libsonde_mi355.so")
 
 TILE = 2048
 FRAME_MAX = 528

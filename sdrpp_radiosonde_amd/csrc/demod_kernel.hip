@@ -14,16 +14,13 @@
 #include <hip/hip_runtime.h>
 #include "sonde_dev.h"
 
-#define PI_F        3.14159274f
-#define TWO_PI_F    6.28318548f
-#define HALF_PI_F   1.57079637f
-#define TWO_OVER_PI 0.636619747f
-// Abramowitz & Stegun 4.4.47
-#define AT_A1  0.9998660f
-#define AT_A3 -0.3302995f
-#define AT_A5  0.1801410f
-#define AT_A7 -0.0851330f
-#define AT_A9  0.0208351f
+// Abramowitz & Stegun 4.4.47 with the discriminator gain 2/pi folded in (angles in quadrants:
+// pi/2 -> 1, pi -> 2); same binary32 constants as the oracle
+#define AT_A1  0.636534452f
+#define AT_A3 -0.210275188f
+#define AT_A5  0.114681326f
+#define AT_A7 -0.0541973524f
+#define AT_A9  0.0132640367f
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -57,39 +54,41 @@ __device__ __forceinline__ float sd_recip(float x)
 	return r;
 }
 
-#define TINY_BITS 0x0DA24260u   // 1e-30f: floor of the divisor, so that atan2p(0,0) = 0 without a select
-
-// atan2p of two samples (y0,x0), (y1,x1): SPEC 3.1.  max/min on the bit patterns, A&S 4.4.47
-// polynomial of min/max (packed), octant fix-ups as |offset - p| and a final copysign.
-__device__ __forceinline__ f32x2 sd_atan2x2(float y0, float x0, float y1, float x1)
+// atan2q(y, x) in quadrants, [-2, 2]: SPEC 3.1.  Scalar on purpose: on gfx950 a v_pk_fma_f32 costs as
+// much VALU time as two v_fmac_f32 (measured, tools/ubench/valu_rate.hip) and packing needs operand
+// shuffles; the eight samples of a lane give the scheduler independent chains instead.
+// max/min of the magnitudes are single VOP3 instructions with |.| source modifiers (equal to the
+// oracle's integer max/min of the bit patterns for every non-NaN input); 1e-30 floors the divisor
+// so atan2q(0,0) = 0 with no select.
+__device__ __forceinline__ float sd_atan2q(float y, float x)
 {
-	const uint32_t ax0 = __float_as_uint(x0) & 0x7FFFFFFFu, ay0 = __float_as_uint(y0) & 0x7FFFFFFFu;
-	const uint32_t ax1 = __float_as_uint(x1) & 0x7FFFFFFFu, ay1 = __float_as_uint(y1) & 0x7FFFFFFFu;
-	const f32x2 mx = {__uint_as_float(max(max(ax0, ay0), TINY_BITS)), __uint_as_float(max(max(ax1, ay1), TINY_BITS))};
-	const f32x2 mn = {__uint_as_float(min(ax0, ay0)), __uint_as_float(min(ax1, ay1))};
-	const f32x2 r = mn * sd_recip2(mx);
-	const f32x2 sq = r * r;
-	const f32x2 c9 = {AT_A9, AT_A9}, c7 = {AT_A7, AT_A7}, c5 = {AT_A5, AT_A5}, c3 = {AT_A3, AT_A3}, c1 = {AT_A1, AT_A1};
-	f32x2 p = pk_fma(sq, c9, c7);
-	p = pk_fma(sq, p, c5);
-	p = pk_fma(sq, p, c3);
-	p = pk_fma(sq, p, c1);
+	const float tiny = 1.0e-30f;
+	float mx, mn;
+	asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mx) : "v"(y), "v"(x), "v"(tiny));
+	asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(y), "v"(x));
+	const float r = mn * sd_recip(mx);
+	const float sq = r * r;
+	float p = __builtin_fmaf(sq, AT_A9, AT_A7);
+	p = __builtin_fmaf(sq, p, AT_A5);
+	p = __builtin_fmaf(sq, p, AT_A3);
+	p = __builtin_fmaf(sq, p, AT_A1);
 	p = p * r;
-	const float q20 = ((ay0 > ax0) ? HALF_PI_F : 0.0f) - p.x;
-	const float q21 = ((ay1 > ax1) ? HALF_PI_F : 0.0f) - p.y;
-	const float q0 = __uint_as_float((uint32_t)((int32_t)__float_as_uint(x0) >> 31) & 0x40490FDBu) - __builtin_fabsf(q20);
-	const float q1 = __uint_as_float((uint32_t)((int32_t)__float_as_uint(x1) >> 31) & 0x40490FDBu) - __builtin_fabsf(q21);
-	f32x2 out;
-	out.x = __builtin_copysignf(q0, y0);
-	out.y = __builtin_copysignf(q1, y1);
-	return out;
+	// octant fix-ups, arithmetic form (cheap 2-operand ALU ops instead of compare+select pairs):
+	//   |y|>|x|: p = 1 - p      x<0: p = 2 - p      sign from y
+	const float dxy = __builtin_fabsf(x) - __builtin_fabsf(y);                                   // < 0 iff |y| > |x|
+	const float s1 = __uint_as_float((uint32_t)((int32_t)__float_as_uint(dxy) >> 31) & 0x3F800000u);   // 1.0 or 0.0
+	const float q1 = s1 - p;                                                                     // |q1| = 1-p or p
+	const float s2 = __uint_as_float((uint32_t)((int32_t)__float_as_uint(x) >> 31) & 0x40000000u);     // 2.0 or 0.0
+	const float q2 = s2 - __builtin_fabsf(q1);                                                   // |q2| = 2-|q1| or |q1|
+	return __builtin_copysignf(q2, y);
 }
 
-// wrap a phase difference into [-pi, pi] and scale by 2/pi (SPEC 3.1)
-__device__ __forceinline__ float sd_wrap(float diff)
+// (cross, dot) of x1 * conj(x0): cross = fmaf(-x1, y0, y1*x0), dot = fmaf(y1, y0, x1*x0)  (SPEC 3.1)
+__device__ __forceinline__ float sd_disc(float x1, float y1, float x0, float y0)
 {
-	const float w = diff - __builtin_copysignf(TWO_PI_F, diff);
-	return (__builtin_fabsf(diff) > PI_F) ? w : diff;
+	const float cross = __builtin_fmaf(-x1, y0, y1 * x0);
+	const float dot = __builtin_fmaf(y1, y0, x1 * x0);
+	return sd_atan2q(cross, dot);
 }
 
 __device__ __forceinline__ float sd_clamp(float v, float lo, float hi)
@@ -121,8 +120,8 @@ struct DemodLds {
 	float B[SD_BUF];
 	float taps[SD_NPHASE * SD_TAPS_LD];     // rows padded to 36 floats: 16-byte aligned ds_read_b128
 	float y[SD_WG];
-	float P[1 + SD_TILE / 2];               // P[1 + 256r + tid] = phase of the 2nd sample of load (r, tid); P[0] = previous tile's last
-	int red[4][3];
+	int4 red[4];                            // per wave: (E, S1, S0, C1)
+	float iq_last[2];
 	uint32_t chunk[10];
 	uint32_t partial[2];                    // bits already in the ring word that wpos points into (ping-pong)
 };
@@ -191,37 +190,46 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 		s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
 	}
 	int par = 0;
-	float carry = st.phi_last;             // thread 255: phase of the last sample stored so far
-	if (IS_IQ && tid == SD_WG - 1) s.P[0] = carry;
 
 	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
 	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
 	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)ch * ch_stride);
+	const float2 *src2 = reinterpret_cast<const float2 *>(src);
 	float4 v[NLD];
-	f32x2 ph[NLD];                         // IQ: phases of the two samples of each load
+	float2 pv[NLD];                        // IQ: the sample just before each load's first sample
+	f32x2 dd[NLD];                         // IQ: the two discriminator outputs of each load
+	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);   // thread 255: newest sample seen
 
-	// K1 first half: raw samples -> phases (pure ALU); the 2nd phase of each load goes to P[] so that the
-	// next sample's owner (tid+1, or tid 0 of the next load group) can read it after the barrier
-	auto k1_phase = [&]() {
-		if (IS_IQ) {
+	auto load_tile = [&](int tile) {
 #pragma unroll
-			for (int r = 0; r < NLD; r++) {
-				ph[r] = sd_atan2x2(v[r].y, v[r].x, v[r].w, v[r].z);
-				s.P[1 + SD_WG * r + tid] = ph[r].y;
+		for (int r = 0; r < NLD; r++) {
+			v[r] = src[(size_t)tile * TILE_F4 + tid + SD_WG * r];
+			if (IS_IQ && lane == 0) {
+				// only each wave's first lane fetches its predecessor sample; the others shuffle it in
+				const long idx = (long)tile * SD_TILE + 2 * (tid + SD_WG * r) - 1;
+				pv[r] = idx >= 0 ? src2[idx] : make_float2(st.iq_last[0], st.iq_last[1]);
 			}
 		}
 	};
-	// K1 second half (after a barrier): phase differences -> both LDS copies
+	// K1, lane-local: d[n] = atan2q(x[n] * conj(x[n-1])) for the lane's 8 samples (registers only)
+	auto k1_compute = [&](int r0, int r1) {
+		if (IS_IQ) {
+#pragma unroll
+			for (int r = r0; r < r1; r++) {
+				float px = __shfl_up(v[r].z, 1, 64), py = __shfl_up(v[r].w, 1, 64);
+				if (lane == 0) { px = pv[r].x; py = pv[r].y; }
+				dd[r].x = sd_disc(v[r].x, v[r].y, px, py);
+				dd[r].y = sd_disc(v[r].z, v[r].w, v[r].x, v[r].y);
+			}
+			last_iq = make_float2(v[NLD - 1].z, v[NLD - 1].w);
+		}
+	};
+	// after the barrier that ends the FIR reads of the previous tile: both LDS copies
 	auto k1_store = [&]() {
 		if (IS_IQ) {
 #pragma unroll
-			for (int r = 0; r < NLD; r++) {
-				const float prev = s.P[SD_WG * r + tid];
-				const float d0 = sd_wrap(ph[r].x - prev) * TWO_OVER_PI;
-				const float d1 = sd_wrap(ph[r].y - ph[r].x) * TWO_OVER_PI;
-				store_pair(s, 2u * (uint32_t)(tid + SD_WG * r), d0, d1);
-			}
-			carry = ph[NLD - 1].y;               // meaningful in thread 255: phase of the tile's last sample
+			for (int r = 0; r < NLD; r++)
+				store_pair(s, 2u * (uint32_t)(tid + SD_WG * r), dd[r].x, dd[r].y);
 		} else {
 #pragma unroll
 			for (int r = 0; r < NLD; r++) {
@@ -230,14 +238,6 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 				store_pair(s, i + 2u, v[r].z, v[r].w);
 			}
 		}
-	};
-	// after the barrier that follows k1_store: roll the last phase into P[0] for the next tile
-	auto k1_carry = [&]() {
-		if (IS_IQ && tid == SD_WG - 1) s.P[0] = carry;
-	};
-	auto load_tile = [&](int tile) {
-#pragma unroll
-		for (int r = 0; r < NLD; r++) v[r] = src[(size_t)tile * TILE_F4 + tid + SD_WG * r];
 	};
 
 	// timing-loop round, first part: both FIR evaluations of this lane's symbol
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 		S1i = wave_sum(S1i);
 		S0i = wave_sum(S0i);
 		if (lane == 0) {
-			s.red[wave][0] = Ei; s.red[wave][1] = S1i; s.red[wave][2] = S0i;
+			s.red[wave] = make_int4(Ei, S1i, S0i, __popcll(bal));
 			s.chunk[1 + 2 * wave] = (uint32_t)bal;
 			s.chunk[2 + 2 * wave] = (uint32_t)(bal >> 32);
 		}
@@ -282,12 +282,11 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 	// third part (after a barrier): append the bits, update slicer levels and the PI loop filter
 	auto round_update = [&](int K) {
 		if (K <= 0) return;
-		const int E = s.red[0][0] + s.red[1][0] + s.red[2][0] + s.red[3][0];
-		const int S1 = s.red[0][1] + s.red[1][1] + s.red[2][1] + s.red[3][1];
-		const int S0 = s.red[0][2] + s.red[1][2] + s.red[2][2] + s.red[3][2];
-		int C1 = 0;
-#pragma unroll
-		for (int w = 1; w <= 8; w++) C1 += __popc(s.chunk[w]);
+		const int4 r0 = s.red[0], r1 = s.red[1], r2 = s.red[2], r3 = s.red[3];
+		const int E = r0.x + r1.x + r2.x + r3.x;
+		const int S1 = r0.y + r1.y + r2.y + r3.y;
+		const int S0 = r0.z + r1.z + r2.z + r3.z;
+		const int C1 = r0.w + r1.w + r2.w + r3.w;
 		const int C0 = K - C1;
 		if (tid < 9) {
 			const uint32_t sh = (uint32_t)st.wpos & 31u;
@@ -338,13 +337,12 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 
 	// ---- prologue: tile 0 into LDS, tile 1 in flight
 	load_tile(0);
-	k1_phase();
+	k1_compute(0, NLD);
 	__syncthreads();
 	k1_store();
 	if (n_tiles > 1) load_tile(1);
 	st.n0 += SD_TILE;
 	__syncthreads();
-	k1_carry();
 
 	for (int tile = 0; tile < n_tiles; tile++) {
 		// LDS holds tile `tile` (+64 samples of history); v[] holds the raw samples of tile+1
@@ -365,7 +363,7 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 		round_interp(K);
 		float rollA = 0.0f, rollB = 0.0f;
 		if (has_next) {
-			k1_phase();                                   // ALU work that covers the LDS latency above
+			k1_compute(0, NLD / 2);                       // ALU work that covers the LDS latency above
 			if (tid < SD_LH) rollA = s.A[SD_TILE + tid];
 			else if (tid < 2 * SD_LH - 1) rollB = s.B[SD_TILE + tid - SD_LH];
 		}
@@ -374,19 +372,21 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 		if (has_next) {
 			if (tid < SD_LH) s.A[tid] = rollA;            // history roll: last 64 samples to the front
 			else if (tid < 2 * SD_LH - 1) s.B[tid - SD_LH] = rollB;
+			k1_compute(NLD / 2, NLD);                     // ... and the DPP reduction latency here
 			k1_store();                                   // tile+1 replaces tile in LDS
 			if (tile + 2 < n_tiles) load_tile(tile + 2);
 		}
 		__syncthreads();                                  // (2) statistics + next tile visible
-		if (has_next) k1_carry();
 		round_update(K);
 		if (has_next) st.n0 += SD_TILE;
 	}
 
+	if (IS_IQ && tid == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
+	__syncthreads();
 	// carry the history and the scalar state to the next submit
 	if (tid < SD_LH) hist[(size_t)ch * SD_HIST + tid] = s.A[SD_TILE + tid];
 	if (tid == 0) {
-		if (IS_IQ) st.phi_last = s.P[0];     // written by thread 255 behind the last barrier
+		if (IS_IQ) { st.iq_last[0] = s.iq_last[0]; st.iq_last[1] = s.iq_last[1]; }
 		states[ch] = st;
 	}
 }

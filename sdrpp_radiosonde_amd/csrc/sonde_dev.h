@@ -32,10 +32,10 @@ struct SdChanState {        // demodulator state, one per channel (64 B)
 	float    yprev;
 	float    bias;
 	float    amp;
-	float    phi_last;
+	float    iq_last[2];    // previous IQ sample (I, Q) of the discriminator
 	int32_t  nstat;
 	int32_t  type;
-	int32_t  pad[3];
+	int32_t  pad[2];
 };
 
 struct SdFramerState {      // framer state, one per channel (32 B)

@@ -84,7 +84,7 @@ def test_real_input_equals_oracle(oracle):
     L = oracle.lib()
     d = np.zeros((C, n), dtype=np.float32)
     for c in range(C):
-        last = np.zeros(1, dtype=np.float32)
+        last = np.zeros(2, dtype=np.float32)
         L.or_discriminate(oracle.fptr(np.ascontiguousarray(sb.iq[c].numpy()).reshape(-1)), n, oracle.fptr(d[c]), oracle.fptr(last))
     b = SondeBatch(C, n, input_kind=INPUT_REAL)
     b.submit(_dev(torch.from_numpy(d)))
