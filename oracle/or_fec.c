@@ -173,6 +173,7 @@ static const uint8_t rs41_mask[64] = {
 #define RS41_TYPE_POS   56
 
 const uint8_t *or_demod_bitptr(const OrDemod *d);
+int or_framer_run_other(void *f, const uint8_t *bits, uint64_t wpos);
 
 struct OrFramer {
 	int type;
@@ -280,7 +281,7 @@ int or_framer_run(OrFramer *f, const OrDemod *d)
 	const uint64_t wpos = or_demod_nbits(d);
 	switch (f->type) {
 	case OR_RS41: return rs41_run(f, bits, wpos);
-	default: return 0;
+	default: return or_framer_run_other(f, bits, wpos);   /* or_framers.c; same struct layout */
 	}
 }
 

@@ -95,6 +95,9 @@ uint8_t  or_gf256_mul(uint8_t a, uint8_t b);
 int      or_rs255_decode(uint8_t *cw, int n);
 void     or_rs255_encode(uint8_t *cw, int n);   /* fills cw[0..23] from cw[24..n) */
 uint16_t or_crc16_ccitt(const uint8_t *p, size_t n);
+uint16_t or_m10_checksum(const uint8_t *p, size_t n);
+uint32_t or_bch_parity(uint64_t data34);                 /* BCH(63,51) shortened to (46,34) */
+uint64_t or_bch_decode(uint64_t blk46, int *st);         /* st: errors corrected (0..2) or -1 */
 
 typedef struct OrFramer OrFramer;
 OrFramer *or_framer_new(int type, uint32_t channel);

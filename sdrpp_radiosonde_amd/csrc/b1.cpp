@@ -88,9 +88,9 @@ static ParserStatus b1_decode(SondeB1Decoder *d, SondeData *dst, const float *sr
 	extern "C" ParserStatus x##_decode(T *d, SondeData *dst, const float *src, size_t len) { return b1_decode(d, dst, src, len); }
 
 SONDE_B1_DEF(RS41Decoder,   rs41,   SONDE_RS41,   true)
-SONDE_B1_DEF(DFM09Decoder,  dfm09,  SONDE_DFM09,  false)   // framer: DESIGN.md "next"
-SONDE_B1_DEF(IMS100Decoder, ims100, SONDE_IMS100, false)
-SONDE_B1_DEF(M10Decoder,    m10,    SONDE_M10,    false)
+SONDE_B1_DEF(DFM09Decoder,  dfm09,  SONDE_DFM09,  true)
+SONDE_B1_DEF(IMS100Decoder, ims100, SONDE_IMS100, true)
+SONDE_B1_DEF(M10Decoder,    m10,    SONDE_M10,    true)
 SONDE_B1_DEF(IMET4Decoder,  imet4,  SONDE_IMET4,  false)   // AFSK sondes: SURVEY 8f-4
 SONDE_B1_DEF(C50Decoder,    c50,    SONDE_C50,    false)
 SONDE_B1_DEF(MRZN1Decoder,  mrzn1,  SONDE_MRZN1,  false)

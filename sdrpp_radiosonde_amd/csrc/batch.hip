@@ -85,7 +85,7 @@ struct SondeBatch {
 	uint32_t *d_counts = nullptr;
 	float *d_taps = nullptr;
 	SdModem *d_modems = nullptr;
-	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_gfmulk = nullptr;
+	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_gfmulk = nullptr, *d_g64 = nullptr;
 	void *d_descs = nullptr;
 	uint32_t *d_chlist[SONDE_NTYPES] = {};
 	void *d_stage = nullptr;
@@ -109,7 +109,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	if (b->pending) (void)hipStreamSynchronize(b->last_stream);
 	(void)hipFree(b->d_states); (void)hipFree(b->d_fstates); (void)hipFree(b->d_hist); (void)hipFree(b->d_bitring);
 	(void)hipFree(b->d_frames); (void)hipFree(b->d_counts); (void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
-	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfmulk); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
+	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfmulk); (void)hipFree(b->d_g64); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	delete b;
@@ -144,7 +144,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	pmin -= pmin >> 8;
 	const uint64_t max_bits = ((uint64_t)cfg->max_samples << 16) / (uint64_t)pmin + 2;
 	b->ring_words = pow2ceil((uint32_t)((max_bits + 8 * SONDE_FRAME_MAX + 1024 + 31) / 32));
-	b->max_frames = (uint32_t)(max_bits / 1600) + 2;
+	b->max_frames = (uint32_t)(max_bits / 560) + 2;        // shortest frame: DFM, 560 chips
+	if ((size_t)b->ring_words * 4 > 65536) { delete b; return fail("sonde_batch_create: max_samples too large for the LDS-staged bit ring (64 KB)"); }
 
 	const size_t C = b->n_channels;
 #define ALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void **)&(p), (bytes)); if (e_ != hipSuccess) { sonde_batch_destroy(b); return fail("hipMalloc " #p, e_); } } while (0)
@@ -159,6 +160,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_gfexp, 512);
 	ALLOC(b->d_gflog, 256);
 	ALLOC(b->d_gfmulk, 24 * 256);
+	ALLOC(b->d_g64, 192);
 	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
@@ -193,6 +195,14 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		for (int j = 0; j < 24; j++)
 			for (int v = 0; v < 256; v++) mulk[256 * j + v] = v ? gexp[glog[v] + j] : 0;
 		CHK(hipMemcpy(b->d_gfmulk, mulk.data(), mulk.size(), hipMemcpyHostToDevice));
+	}
+	{	// GF(2^6)/x^6+x+1 tables for BCH(63,51): exp[128] then log[64]
+		uint8_t g64[192];
+		memset(g64, 0, sizeof(g64));
+		int x = 1;
+		for (int i = 0; i < 63; i++) { g64[i] = (uint8_t)x; g64[128 + x] = (uint8_t)i; x <<= 1; if (x & 0x40) x ^= 0x43; }
+		for (int i = 63; i < 128; i++) g64[i] = g64[i - 63];
+		CHK(hipMemcpy(b->d_g64, g64, sizeof(g64), hipMemcpyHostToDevice));
 	}
 	// initial channel state
 	std::vector<SdChanState> st(C);
@@ -238,6 +248,12 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
 			b->d_states, b->d_fstates, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfmulk, b->d_descs,
 			b->d_frames, b->d_counts, b->max_frames, b->d_chlist[SONDE_RS41]);
+		HIPCHK(hipGetLastError());
+	}
+	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10 }) {
+		if (b->chlist[t].empty()) continue;
+		sd_launch_framer_other(t, (uint32_t)b->chlist[t].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
+			b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->d_chlist[t]);
 		HIPCHK(hipGetLastError());
 	}
 	HIPCHK(hipEventRecord(ev[2], stream));

@@ -283,3 +283,246 @@ def make_rs41_batch(n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: 
     iq, cfo, tau, amp = gfsk_modulate(bits, n_samples, baud, seed=seed + first_channel, ebn0_db=ebn0_db,
                                       device=device, invert=invert, **mod_kw)
     return SynthBatch(iq=iq, frames=frames, bits=bits, cfo_hz=cfo, tau=tau, amp=amp)
+
+
+# ================================================================ Manchester / biphase sondes
+# Protocol facts: SURVEY.md Appendix B.3-B.5 ([RECALL]); the oracle (oracle/or_framers.c) and the HIP
+# framers hold the same tables, the *encoders* below are independent implementations.
+
+def manchester(bits: np.ndarray) -> np.ndarray:
+    """[F, n] bits -> [F, 2n] chips, 1 -> 10, 0 -> 01."""
+    b = np.asarray(bits, dtype=np.uint8)
+    return np.stack([b, 1 - b], axis=-1).reshape(b.shape[0], -1)
+
+
+def _bits_msb(vals: np.ndarray, nbits: int) -> np.ndarray:
+    """[F] ints -> [F, nbits] bits, most significant first."""
+    v = np.asarray(vals, dtype=np.int64)
+    return ((v[:, None] >> np.arange(nbits - 1, -1, -1)[None, :]) & 1).astype(np.uint8)
+
+
+# ---------------------------------------------------------------- DFM06/09/17
+DFM_SYNC16 = 0x45CF
+DFM_FRAME_CHIPS = 560
+
+
+def hamming84_encode(nib: np.ndarray) -> np.ndarray:
+    """nibble (c0..c3 = bits 3..0) -> 8-bit codeword c0..c7 (c0 = MSB), parity rows 0x78/0xB4/0xD2/0xE1."""
+    n = np.asarray(nib, dtype=np.int64) & 0xF
+    c0, c1, c2, c3 = (n >> 3) & 1, (n >> 2) & 1, (n >> 1) & 1, n & 1
+    c4, c5, c6, c7 = c1 ^ c2 ^ c3, c0 ^ c2 ^ c3, c0 ^ c1 ^ c3, c0 ^ c1 ^ c2
+    return ((c0 << 7) | (c1 << 6) | (c2 << 5) | (c3 << 4) | (c4 << 3) | (c5 << 2) | (c6 << 1) | c7).astype(np.uint8)
+
+
+def dfm_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray):
+    """Returns (codewords [F,33] uint8, air bits [F,280])."""
+    ch = np.asarray(channel_ids, dtype=np.int64)
+    fi = np.asarray(frame_idx, dtype=np.int64)
+    F = ch.shape[0]
+    nib = np.zeros((F, 33), dtype=np.int64)
+    # CONF: 7 nibbles: channel id nibble + 6 nibbles of (pseudo) sensor data
+    nib[:, 0] = fi % 7
+    conf = (seed * 2654435761 + ch * 40503 + fi * 9973) & 0xFFFFFF
+    for k in range(6):
+        nib[:, 1 + k] = (conf >> (4 * (5 - k))) & 0xF
+    # DAT1/DAT2: 6 bytes + id nibble; ids cycle 0,1 | 2,3 | 4,8
+    ids = np.array([[0, 1], [2, 3], [4, 8]])[fi % 3]
+    lat = np.round((47.0 + 1e-3 * ch) * 1e7).astype(np.int64)
+    lon = np.round((8.0 + 1e-5 * fi) * 1e7).astype(np.int64)
+    alt = np.round((1000.0 + 5.0 * fi) * 100).astype(np.int64)
+    for blk in range(2):
+        pid = ids[:, blk]
+        payload = np.zeros(F, dtype=np.int64)           # 48 bits
+        payload = np.where(pid == 0, (fi & 0xFFFF) << 24, payload)
+        payload = np.where(pid == 1, ((fi * 1000 + 123000) % 60000 & 0xFFFF) << 16, payload)   # UTC ms of minute
+        payload = np.where(pid == 2, ((lat & 0xFFFFFFFF) << 16) | 1200, payload)               # lat 1e-7, hor. speed cm/s
+        payload = np.where(pid == 3, ((lon & 0xFFFFFFFF) << 16) | 9000, payload)               # lon 1e-7, heading 0.01 deg
+        payload = np.where(pid == 4, ((alt & 0xFFFFFFFF) << 16) | 500, payload)                # alt cm, climb cm/s
+        payload = np.where(pid == 8, (2024 << 36) | (6 << 32) | (15 << 27) | (12 << 22) | ((fi % 60) << 16), payload)
+        for k in range(12):
+            nib[:, 7 + 13 * blk + k] = (payload >> (4 * (11 - k))) & 0xF
+        nib[:, 7 + 13 * blk + 12] = pid
+    cw = hamming84_encode(nib)
+    bits = np.zeros((F, 280), dtype=np.uint8)
+    bits[:, :16] = _bits_msb(np.full(F, DFM_SYNC16), 16)
+    off = 16
+    for (o, n) in ((0, 7), (7, 13), (20, 13)):
+        blk = cw[:, o: o + n]                                  # [F, n]
+        planes = ((blk[:, None, :] >> (7 - np.arange(8))[None, :, None]) & 1)   # [F, 8, n]: bit j of codeword i
+        bits[:, off: off + 8 * n] = planes.reshape(F, 8 * n)
+        off += 8 * n
+    return cw, bits
+
+
+# ---------------------------------------------------------------- M10
+M10_SYNC_CHIPS = np.array([int(c) for c in "10011001100110010100110010011001"], dtype=np.uint8)
+M10_FRAME_BYTES = 101
+
+
+def m10_checksum(frames: np.ndarray) -> np.ndarray:
+    """Meteomodem 16-bit checksum over frames[:, :99] (vectorised over frames)."""
+    cs = np.zeros(frames.shape[0], dtype=np.int64)
+    for i in range(99):
+        b = frames[:, i].astype(np.int64)
+        c1 = cs & 0xFF
+        b = ((b >> 1) | ((b & 1) << 7)) & 0xFF
+        b ^= (b >> 2) & 0xFF
+        t6 = (cs & 1) ^ ((cs >> 2) & 1) ^ ((cs >> 4) & 1)
+        t7 = ((cs >> 1) & 1) ^ ((cs >> 3) & 1) ^ ((cs >> 5) & 1)
+        t = (cs & 0x3F) | (t6 << 6) | (t7 << 7)
+        s = (cs >> 7) & 0xFF
+        s ^= (s >> 2) & 0xFF
+        cs = ((c1 << 8) | (b ^ t ^ s)) & 0xFFFF
+    return cs
+
+
+def _put_be(buf, off, val, nbytes):
+    v = np.asarray(val).astype(np.int64)
+    for b in range(nbytes):
+        buf[:, off + b] = (v >> (8 * (nbytes - 1 - b))) & 0xFF
+
+
+def m10_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray) -> np.ndarray:
+    ch = np.asarray(channel_ids, dtype=np.int64)
+    fi = np.asarray(frame_idx, dtype=np.int64)
+    F = ch.shape[0]
+    fr = np.zeros((F, M10_FRAME_BYTES), dtype=np.uint8)
+    g = np.random.Generator(np.random.Philox(key=(seed * 31 + 7) & 0xFFFFFFFFFFFFFFFF))
+    fr[:] = g.integers(0, 256, size=fr.shape, dtype=np.uint8)
+    fr[:, 0], fr[:, 1], fr[:, 2] = 0x64, 0x9F, 0x20
+    _put_be(fr, 0x04, np.round(12.0 * 200).astype(np.int64) & 0xFFFF + 0 * ch, 2)     # vE  (1/200 m/s)
+    _put_be(fr, 0x06, np.zeros(F, dtype=np.int64), 2)                                   # vN
+    _put_be(fr, 0x08, np.full(F, 5 * 200), 2)                                           # vU
+    _put_be(fr, 0x0A, (fi * 1000 + 123456000) % 604800000, 4)                           # GPS time of week, ms
+    _put_be(fr, 0x0E, np.round((47.0 + 1e-3 * ch) * (2 ** 32 / 360.0)).astype(np.int64) & 0xFFFFFFFF, 4)
+    _put_be(fr, 0x12, np.round((8.0 + 1e-5 * fi) * (2 ** 32 / 360.0)).astype(np.int64) & 0xFFFFFFFF, 4)
+    _put_be(fr, 0x16, np.round((1000.0 + 5.0 * fi) * 1000).astype(np.int64) & 0xFFFFFFFF, 4)   # mm
+    _put_be(fr, 0x20, np.full(F, 2200), 2)                                              # GPS week
+    cs = m10_checksum(fr)
+    fr[:, 99], fr[:, 100] = (cs >> 8) & 0xFF, cs & 0xFF
+    return fr
+
+
+# ---------------------------------------------------------------- iMS-100 / RS-11G
+IMS_SYNC24 = 0x049DCE
+IMS_NBLK, IMS_BLK_BITS, IMS_DATA_BYTES = 12, 46, 51
+BCH_G = 0x1539
+
+
+def bch_parity(data34: int) -> int:
+    r = data34 << 12
+    for i in range(45, 11, -1):
+        if r >> i & 1:
+            r ^= BCH_G << (i - 12)
+    return r & 0xFFF
+
+
+def ims_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray):
+    """Returns (data bytes [F,51], air bits [F, 576])."""
+    ch = np.asarray(channel_ids, dtype=np.int64)
+    fi = np.asarray(frame_idx, dtype=np.int64)
+    F = ch.shape[0]
+    data = np.zeros((F, IMS_DATA_BYTES), dtype=np.uint8)
+    g = np.random.Generator(np.random.Philox(key=(seed * 131 + 3) & 0xFFFFFFFFFFFFFFFF))
+    data[:] = g.integers(0, 256, size=data.shape, dtype=np.uint8)
+    _put_be(data, 0, fi & 0xFFFF, 2)                                                    # frame counter
+    _put_be(data, 2, np.round((47.0 + 1e-3 * ch) * 1e6).astype(np.int64) & 0xFFFFFFFF, 4)
+    _put_be(data, 6, np.round((8.0 + 1e-5 * fi) * 1e6).astype(np.int64) & 0xFFFFFFFF, 4)
+    _put_be(data, 10, np.round((1000.0 + 5.0 * fi) * 100).astype(np.int64) & 0xFFFFFFFF, 4)
+    dbits = np.unpackbits(data, axis=1)                                                 # [F, 408] MSB first
+    bits = np.zeros((F, 24 + IMS_NBLK * IMS_BLK_BITS), dtype=np.uint8)
+    bits[:, :24] = _bits_msb(np.full(F, IMS_SYNC24), 24)
+    for f in range(F):
+        for b in range(IMS_NBLK):
+            d = 0
+            for k in range(34):
+                d = (d << 1) | int(dbits[f, 34 * b + k])
+            blk = (d << 12) | bch_parity(d)
+            bits[f, 24 + 46 * b: 24 + 46 * (b + 1)] = [(blk >> (45 - k)) & 1 for k in range(46)]
+    return data, bits
+
+
+def biphase_s(bits: np.ndarray) -> np.ndarray:
+    """[n] bits -> [2n] chips: transition at every bit boundary, extra mid-bit transition for a 0
+    (so that a 1 reads as two equal chips).  Polarity-free by construction."""
+    out = np.zeros(2 * len(bits), dtype=np.uint8)
+    lvl = 0
+    for i, b in enumerate(bits):
+        lvl ^= 1
+        out[2 * i] = lvl
+        if not b:
+            lvl ^= 1
+        out[2 * i + 1] = lvl
+    return out
+
+
+# ---------------------------------------------------------------- chip streams + batches for any type
+SONDE_BAUD = {0: 4800.0, 1: 5000.0, 2: 4800.0, 3: 9600.0}     # on-air symbol (chip) rates
+
+
+def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int):
+    """Continuous on-air chip streams [C, nchips] plus, per channel, the list of
+    (chip offset of the sync, expected decoded frame bytes)."""
+    channels = np.asarray(channels, dtype=np.int64)
+    C = channels.shape[0]
+    rng = np.random.Generator(np.random.Philox(key=(seed * 7919 + 17 + sonde_type) & 0xFFFFFFFFFFFFFFFF))
+    if sonde_type == 1:      # DFM: continuous frames
+        flen = DFM_FRAME_CHIPS
+        gap = 0
+    elif sonde_type == 3:    # M10: bursts with idle gap
+        flen = 32 + 16 * M10_FRAME_BYTES
+        gap = 752
+    elif sonde_type == 2:    # iMS-100
+        flen = 2 * (24 + IMS_NBLK * IMS_BLK_BITS)
+        gap = 96
+    else:
+        raise ValueError("use rs41_bitstreams for RS41")
+    stride = flen + gap
+    nfr = nchips // stride + 2
+    lead = rng.integers(64, 64 + stride, size=C)
+    ch_rep = np.repeat(channels, nfr)
+    fi_rep = np.tile(np.arange(nfr), C)
+    if sonde_type == 1:
+        expect, bits = dfm_build_frames(seed, ch_rep, fi_rep)
+        chips = manchester(bits)
+    elif sonde_type == 3:
+        expect = m10_build_frames(seed, ch_rep, fi_rep)
+        chips = np.concatenate([np.tile(M10_SYNC_CHIPS, (C * nfr, 1)), manchester(np.unpackbits(expect, axis=1))], axis=1)
+    else:
+        expect, bits = ims_build_frames(seed, ch_rep, fi_rep)
+        chips = np.stack([biphase_s(b) for b in bits])
+    chips = chips.reshape(C, nfr, flen)
+    expect = expect.reshape(C, nfr, -1)
+    idle = (np.arange(nchips + 2 * stride) & 1).astype(np.uint8)
+    out = np.zeros((C, nchips + 2 * stride), dtype=np.uint8)
+    frames = []
+    for c in range(C):
+        pos = int(lead[c])
+        out[c, :pos] = idle[:pos]
+        lst = []
+        for f in range(nfr):
+            if pos >= nchips:
+                break
+            out[c, pos: pos + flen] = chips[c, f]
+            if pos + flen <= nchips:
+                lst.append((pos, expect[c, f].copy()))
+            pos += flen
+            out[c, pos: pos + gap] = idle[:gap]
+            pos += gap
+        frames.append(lst)
+    return out[:, :nchips], frames
+
+
+def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
+               device: str | torch.device = "cpu", first_channel: int = 0, invert: bool = False, **mod_kw) -> SynthBatch:
+    """Synthetic batch of any supported sonde type (0 RS41, 1 DFM09, 2 iMS-100, 3 M10)."""
+    if sonde_type == 0:
+        return make_rs41_batch(n_channels, n_samples, seed=seed, ebn0_db=ebn0_db, device=device,
+                               first_channel=first_channel, invert=invert, **mod_kw)
+    baud = SONDE_BAUD[sonde_type]
+    nchips = int(n_samples * baud / FS) + 16
+    channels = np.arange(first_channel, first_channel + n_channels)
+    chips, frames = chip_streams(sonde_type, seed, channels, nchips)
+    iq, cfo, tau, amp = gfsk_modulate(chips, n_samples, baud, seed=seed + first_channel + 1000 * sonde_type,
+                                      ebn0_db=ebn0_db, device=device, invert=invert, **mod_kw)
+    return SynthBatch(iq=iq, frames=frames, bits=chips, cfo_hz=cfo, tau=tau, amp=amp)

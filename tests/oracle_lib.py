@@ -89,12 +89,12 @@ def u8ptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_uint8))
 
 
-def batch_run(sonde_type: int, iq: np.ndarray, nthreads: int = 1, cap_per_channel: int = 16) -> np.ndarray:
+def batch_run(sonde_type: int, iq: np.ndarray, nthreads: int = 1, cap_per_channel: int = 0) -> np.ndarray:
     """iq: [C, n, 2] float32.  Returns structured array of frames (FRAME_DTYPE), ordered by channel then time."""
     L = lib()
     iq = np.ascontiguousarray(iq, dtype=np.float32)
     nch, n = iq.shape[0], iq.shape[1]
-    cap = nch * cap_per_channel
+    cap = nch * (cap_per_channel or (n // 4096 + 8))      # shortest frame: DFM, 560 chips = 5376 samples
     out = np.zeros(cap, dtype=FRAME_DTYPE)
     total = L.or_batch_run(sonde_type, fptr(iq.reshape(-1)), nch, n, nthreads, out.ctypes.data, cap)
     assert total <= cap

@@ -184,3 +184,67 @@ def test_timing_loop_locks(oracle):
         assert np.sum(rx[1500: 5000] != tx[1500 + best: 5000 + best]) == 0
         st = ch.state()
         assert abs(st["period"] - 655360) < 200        # 4800 Bd at 48 kS/s, Q16
+
+
+# ---------------------------------------------------------------- DFM / M10 / iMS-100 building blocks
+def test_hamming84_all_codewords_all_single_flips(oracle):
+    """Hamming(8,4) all 16 codewords x all single-bit flips, via whole DFM frames."""
+    cws = synth.hamming84_encode(np.arange(16))
+    H = [0x78, 0xB4, 0xD2, 0xE1]
+    for cw in cws:
+        assert all(bin(int(cw) & h).count("1") % 2 == 0 for h in H)
+        for i in range(8):
+            bad = int(cw) ^ (0x80 >> i)
+            syn = [bin(bad & h).count("1") % 2 for h in H]
+            col = [(h >> (7 - i)) & 1 for h in H]
+            assert syn == col                      # the syndrome of a single flip is that column of H
+    assert len(set(int(c) for c in cws)) == 16
+
+
+def test_bch_63_51_all_double_errors(oracle):
+    """BCH(63,51) (shortened 46,34): every <=2-bit error pattern on a fixed codeword."""
+    import ctypes as C
+    L = oracle.lib()
+    L.or_bch_parity.restype = C.c_uint32
+    L.or_bch_parity.argtypes = [C.c_uint64]
+    L.or_bch_decode.restype = C.c_uint64
+    L.or_bch_decode.argtypes = [C.c_uint64, C.POINTER(C.c_int)]
+    d = 0x2A5F0C3D7 & ((1 << 34) - 1)
+    assert L.or_bch_parity(d) == synth.bch_parity(d)          # independent python encoder agrees
+    cw = (d << 12) | synth.bch_parity(d)
+    st = C.c_int()
+    assert L.or_bch_decode(cw, C.byref(st)) == cw and st.value == 0
+    for i in range(46):
+        assert L.or_bch_decode(cw ^ (1 << i), C.byref(st)) == cw and st.value == 1
+        for j in range(i + 1, 46):
+            assert L.or_bch_decode(cw ^ (1 << i) ^ (1 << j), C.byref(st)) == cw and st.value == 2
+    # three errors are never "corrected" into the transmitted word
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        i, j, k = rng.choice(46, size=3, replace=False)
+        out = L.or_bch_decode(cw ^ (1 << int(i)) ^ (1 << int(j)) ^ (1 << int(k)), C.byref(st))
+        assert st.value == -1 or out != cw
+
+
+def test_m10_checksum_matches_generator(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    L.or_m10_checksum.restype = C.c_uint16
+    L.or_m10_checksum.argtypes = [C.POINTER(C.c_uint8), C.c_size_t]
+    fr = synth.m10_build_frames(9, np.arange(4), np.arange(4))
+    for f in fr:
+        f = np.ascontiguousarray(f)
+        assert L.or_m10_checksum(oracle.u8ptr(f), 99) == (int(f[99]) << 8 | int(f[100]))
+
+
+@pytest.mark.parametrize("stype,ebn0", [(1, 30.0), (1, 15.0), (3, 30.0), (3, 15.0), (2, 30.0), (2, 15.0)])
+def test_oracle_decodes_other_sondes(oracle, stype, ebn0):
+    C, n = 6, 2048 * 40
+    sb = synth.make_batch(stype, C, n, seed=5, ebn0_db=ebn0)
+    fr = oracle.batch_run(stype, sb.iq.numpy(), nthreads=4)
+    sent = sum(len(f) for f in sb.frames)
+    exact = sum(any(np.array_equal(tx, f["data"][: f["len"]]) for _, tx in sb.frames[f["channel"]]) for f in fr)
+    assert sent >= C
+    assert exact >= (sent - C if ebn0 > 20 else 0.5 * sent)
+    if ebn0 < 20 and stype != 3:
+        assert (fr["nerr"][:, 0] > 0).any()       # Hamming / BCH corrections happen
