@@ -144,6 +144,10 @@ int      sonde_get_taps(int type, float *out /* 32*32 floats, [phase][tap] */);
  * Returns number of fragments written (<= cap). */
 int  sonde_parse_frame(const SondeFrame *f, SondeData *out, int cap);
 
+/* post-FEC derived quantities, as /root/reference/src/decode/decoder.hpp:132-174 computes them */
+float sonde_dewpt(float temp, float rh);
+float sonde_altitude_to_pressure(float alt);
+
 const char *sonde_last_error(void);
 const char *sonde_version(void);
 

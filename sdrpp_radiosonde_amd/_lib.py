@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
     "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_kernel_ms", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_get_taps", "sonde_parse_frame",
-    "sonde_last_error", "sonde_version",
+    "sonde_last_error", "sonde_version", "sonde_dewpt", "sonde_altitude_to_pressure",
 ] + [f"{x}_{fn}" for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1")
      for fn in ("decoder_init", "decoder_deinit", "decode")]
 
@@ -85,6 +85,10 @@ def load() -> C.CDLL:
                                          C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.sonde_get_taps.argtypes = [C.c_int, vp]
     L.sonde_parse_frame.argtypes = [vp, C.POINTER(SondeData), C.c_int]
+    L.sonde_dewpt.restype = C.c_float
+    L.sonde_dewpt.argtypes = [C.c_float, C.c_float]
+    L.sonde_altitude_to_pressure.restype = C.c_float
+    L.sonde_altitude_to_pressure.argtypes = [C.c_float]
     for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1"):
         getattr(L, f"{x}_decoder_init").argtypes = [C.c_int]
         getattr(L, f"{x}_decoder_init").restype = vp

@@ -104,11 +104,104 @@ void SondeParser::feed_rs41(const SondeFrame &f, std::vector<SondeData> &out)
 	}
 }
 
+// days since 1970-01-01 of a proleptic Gregorian date
+static long long days_from_civil(int y, int m, int d)
+{
+	y -= m <= 2;
+	const long long era = (y >= 0 ? y : y - 399) / 400;
+	const unsigned yoe = (unsigned)(y - era * 400);
+	const unsigned doy = (153u * (unsigned)(m + (m > 2 ? -3 : 9)) + 2u) / 5u + (unsigned)d - 1u;
+	const unsigned doe = yoe * 365u + yoe / 4u - yoe / 100u + doy;
+	return era * 146097LL + (long long)doe - 719468LL;
+}
+
+// DFM06/09/17: frame = 33 corrected Hamming codewords (data nibble = high nibble): 7 CONF, 13 DAT1, 13 DAT2.
+// Each DAT block = 48 payload bits + sub-packet id nibble (ids per public DFM notes):
+//   0 frame counter, 1 UTC ms of minute, 2 lat (1e-7 deg) + ground speed (cm/s), 3 lon + heading (0.01 deg),
+//   4 altitude (cm) + climb (cm/s), 8 date/time.
+void SondeParser::feed_dfm(const SondeFrame &f, std::vector<SondeData> &out)
+{
+	if (f.len != 33 || f.nerr[1] != 0) return;       // a codeword with a detected double error poisons the frame
+	for (int blk = 0; blk < 2; blk++) {
+		const uint8_t *cw = f.data + 7 + 13 * blk;
+		unsigned long long pay = 0;
+		for (int k = 0; k < 12; k++) pay = (pay << 4) | (unsigned long long)(cw[k] >> 4);
+		const int id = cw[12] >> 4;
+		SondeData sd;
+		memset(&sd, 0, sizeof(sd));
+		const int32_t v32 = (int32_t)(uint32_t)(pay >> 16);
+		const uint32_t v16 = (uint32_t)(pay & 0xFFFF);
+		switch (id) {
+		case 0:
+			sd.fields = DATA_SEQ;
+			sd.seq = (int)((pay >> 24) & 0xFFFF);
+			break;
+		case 1:
+			if (m_dfm_date >= 0) {
+				sd.fields = DATA_TIME;
+				sd.time = (time_t)(m_dfm_date + (long long)((pay >> 16) & 0xFFFF) / 1000);
+			}
+			break;
+		case 2:
+			m_dfm_lat = v32 * 1e-7; m_dfm_spd = v16 * 1e-2; m_dfm_have |= 1;
+			break;
+		case 3:
+			m_dfm_lon = v32 * 1e-7; m_dfm_hdg = v16 * 1e-2; m_dfm_have |= 2;
+			break;
+		case 4:
+			if (m_dfm_have == 3) {
+				sd.fields = DATA_POS | DATA_SPEED;
+				sd.lat = (float)m_dfm_lat; sd.lon = (float)m_dfm_lon; sd.alt = (float)(v32 * 1e-2);
+				sd.speed = (float)m_dfm_spd; sd.heading = (float)m_dfm_hdg;
+				sd.climb = (float)((int16_t)v16 * 1e-2);
+			}
+			break;
+		case 8: {
+			const int year = (int)((pay >> 36) & 0xFFF), mon = (int)((pay >> 32) & 0xF), day = (int)((pay >> 27) & 0x1F);
+			const int hour = (int)((pay >> 22) & 0x1F), min = (int)((pay >> 16) & 0x3F);
+			if (mon >= 1 && mon <= 12 && day >= 1) m_dfm_date = days_from_civil(year, mon, day) * 86400LL + hour * 3600LL + min * 60LL;
+			break;
+		}
+		default:
+			break;
+		}
+		if (sd.fields) out.push_back(sd);
+	}
+}
+
+// M10: 101-byte frame, big-endian fields at fixed offsets (public M10 notes)
+void SondeParser::feed_m10(const SondeFrame &f, std::vector<SondeData> &out)
+{
+	if (f.len != 101 || f.nerr[0] != 0) return;      // checksum failed
+	const uint8_t *d = f.data;
+	if (d[1] != 0x9F) return;                        // 0x9F = M10 (M20 differs)
+	auto be16 = [&](int o) { return (int16_t)((d[o] << 8) | d[o + 1]); };
+	auto be32 = [&](int o) { return (int32_t)(((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]); };
+	SondeData sd;
+	memset(&sd, 0, sizeof(sd));
+	const double ve = be16(0x04) / 200.0, vn = be16(0x06) / 200.0, vu = be16(0x08) / 200.0;
+	const uint32_t tow_ms = (uint32_t)be32(0x0A);
+	const unsigned week = (unsigned)(uint16_t)be16(0x20);
+	sd.fields = DATA_POS | DATA_SPEED | DATA_TIME;
+	sd.lat = (float)(be32(0x0E) * (360.0 / 4294967296.0));
+	sd.lon = (float)(be32(0x12) * (360.0 / 4294967296.0));
+	sd.alt = (float)(be32(0x16) / 1000.0);
+	sd.speed = (float)sqrt(ve * ve + vn * vn);
+	double hdg = atan2(ve, vn) * 180.0 / M_PI;
+	if (hdg < 0.0) hdg += 360.0;
+	sd.heading = (float)hdg;
+	sd.climb = (float)vu;
+	sd.time = (time_t)(315964800LL + (long long)week * 604800LL + (long long)(tow_ms / 1000) - 18LL);
+	out.push_back(sd);
+}
+
 void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
 {
 	switch (f.type) {
 	case SONDE_RS41: feed_rs41(f, out); break;
-	default: break;
+	case SONDE_DFM09: feed_dfm(f, out); break;
+	case SONDE_M10: feed_m10(f, out); break;
+	default: break;   // iMS-100: frames are delivered, field layout not implemented
 	}
 }
 
@@ -121,4 +214,33 @@ extern "C" int sonde_parse_frame(const SondeFrame *f, SondeData *out, int cap)
 	int n = 0;
 	for (; n < (int)v.size() && n < cap; n++) out[n] = v[n];
 	return n;
+}
+
+// ---- post-FEC derived quantities the reference's Decoder computes while merging fragments.
+// Restated from /root/reference/src/decode/decoder.hpp:132-137 (Magnus dew point) and :138-174 (ISA
+// barometric formula; note the double-precision 1e-2 factor and the table's 77 km last layer).
+extern "C" float sonde_dewpt(float temp, float rh)
+{
+	const float g = (logf(rh / 100.0f) + (17.27f * temp / (237.3f + temp))) / 17.27f;
+	return 237.3f * g / (1 - g);
+}
+
+extern "C" float sonde_altitude_to_pressure(float alt)
+{
+	struct Layer { float hb, Lb, Pb, Tb; };
+	static const Layer isa[7] = {
+		{ 0.0,     -0.0065, 101325.0, 288.15 }, { 11000.0, 0.0,    22632.1, 216.65 }, { 20000.0, 0.001, 5474.89, 216.65 },
+		{ 32000.0,  0.0028, 868.02,   228.65 }, { 47000.0, 0.0,    110.91,  270.65 }, { 51000.0, -0.0028, 66.94, 270.65 },
+		{ 77000.0, -0.002,  3.96,     214.65 },
+	};
+	const float g0 = 9.80665, M = 0.0289644, R_star = 8.3144598;
+	int b = 6;
+	for (int i = 0; i < 6; i++) if (alt < isa[i + 1].hb) { b = i; break; }
+	const Layer &l = isa[b];
+	if (l.Lb != 0) {
+		const float base = (l.Tb + l.Lb * (alt - l.hb)) / l.Tb;
+		const float expo = -(g0 * M) / (R_star * l.Lb);
+		return (float)(1e-2 * l.Pb * powf(base, expo));
+	}
+	return (float)(1e-2 * l.Pb * expf(-g0 * M * (alt - l.hb) / (R_star * l.Tb)));
 }

@@ -12,9 +12,15 @@ public:
 	void feed(const SondeFrame &f, std::vector<SondeData> &out);
 private:
 	void feed_rs41(const SondeFrame &f, std::vector<SondeData> &out);
+	void feed_dfm(const SondeFrame &f, std::vector<SondeData> &out);
+	void feed_m10(const SondeFrame &f, std::vector<SondeData> &out);
 	int m_type;
 	uint64_t m_calib_mask = 0;         // RS41: which of the 51 calibration fragments have been seen
 	uint8_t m_calib[51 * 16] = {};
+	// DFM: position/time arrive as separate sub-packets spread over three frames
+	double m_dfm_lat = 0, m_dfm_lon = 0, m_dfm_spd = 0, m_dfm_hdg = 0;
+	long long m_dfm_date = -1;        // seconds since epoch of the date+hh:mm part, -1 unknown
+	int m_dfm_have = 0;               // bit0 lat, bit1 lon
 };
 
 uint16_t sonde_crc16_ccitt(const uint8_t *p, size_t n);

@@ -1,0 +1,87 @@
+"""-m gpu: the B1 boundary -- X_decoder_init / X_decode / X_decoder_deinit exactly as
+/root/reference/src/decode/decoder.hpp:22,39,61 drives them: real 48 kS/s discriminator samples in
+arbitrary buffer sizes, the same buffer re-offered until PROCEED, one SondeData fragment per PARSED."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sdrpp_radiosonde_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _discriminate(oracle, iq):
+    L = oracle.lib()
+    n = iq.shape[0]
+    d = np.zeros(n, dtype=np.float32)
+    last = np.zeros(2, dtype=np.float32)
+    L.or_discriminate(oracle.fptr(np.ascontiguousarray(iq).reshape(-1)), n, oracle.fptr(d), oracle.fptr(last))
+    return d
+
+
+def _run_b1(name, d, bufsize):
+    L = _lib.load()
+    dec = getattr(L, f"{name}_decoder_init")(48000)
+    assert dec, _lib.last_error()
+    frags, sd = [], _lib.SondeData()
+    for off in range(0, len(d), bufsize):
+        buf = np.ascontiguousarray(d[off: off + bufsize])
+        calls = 0
+        while getattr(L, f"{name}_decode")(dec, C.byref(sd), buf.ctypes.data_as(C.c_void_p), len(buf)) != _lib.PROCEED:
+            assert sd.fields != 0                      # decoder.hpp:112 would drop it
+            frags.append({k: getattr(sd, k) for k, _ in _lib.SondeData._fields_})
+            calls += 1
+            assert calls < 1000
+    getattr(L, f"{name}_decoder_deinit")(dec)
+    return frags
+
+
+@pytest.mark.parametrize("bufsize", [4800, 1000, 50000])
+def test_rs41_b1_stream(oracle, bufsize):
+    n = 2048 * 80
+    sb = synth.make_rs41_batch(1, n, seed=12, ebn0_db=24.0)
+    d = _discriminate(oracle, sb.iq.numpy()[0])
+    frags = _run_b1("rs41", d, bufsize)
+    # reference: the oracle's frames (bit-exact to the GPU's, tests/test_gpu_parity.py) through the parser
+    ch = oracle.Channel(0, 0)
+    ch.feed(d[: (len(d) // 2048) * 2048], is_iq=False)
+    L = _lib.load()
+    expect = []
+    out = (_lib.SondeData * 8)()
+    for f in ch.frames():
+        fr = _lib.SondeFrame.from_buffer_copy(f.tobytes())
+        for i in range(L.sonde_parse_frame(C.byref(fr), out, 8)):
+            expect.append({k: getattr(out[i], k) for k, _ in _lib.SondeData._fields_})
+    assert len(expect) >= 9 and len(frags) == len(expect)
+    for a, b in zip(frags, expect):
+        assert a == b
+    seqs = [f["seq"] for f in frags if f["fields"] & _lib.DATA_SEQ]
+    assert seqs == list(range(seqs[0], seqs[0] + len(seqs))) and frags[0]["serial"] == b"S0000000"
+    pos = [f for f in frags if f["fields"] & _lib.DATA_POS]
+    assert all(abs(p["lat"] - 47.0) < 0.01 and abs(p["lon"] - 8.0) < 0.01 and abs(p["speed"] - 12.0) < 0.05 for p in pos)
+
+
+def test_dfm_and_m10_b1_fields(oracle):
+    for name, stype in (("dfm09", 1), ("m10", 3)):
+        n = 2048 * 60
+        sb = synth.make_batch(stype, 1, n, seed=31, ebn0_db=26.0)
+        frags = _run_b1(name, _discriminate(oracle, sb.iq.numpy()[0]), 4096)
+        pos = [f for f in frags if f["fields"] & _lib.DATA_POS]
+        assert len(pos) >= 3, name
+        for p in pos:
+            assert abs(p["lat"] - 47.0) < 1e-3 and abs(p["lon"] - 8.0) < 1e-2 and 990.0 < p["alt"] < 1200.0, (name, p)
+            assert abs(p["climb"] - 5.0) < 0.05 and abs(p["speed"] - 12.0) < 0.05 and abs(p["heading"] - 90.0) < 0.5, (name, p)
+        times = [f["time"] for f in frags if f["fields"] & _lib.DATA_TIME]
+        assert len(times) >= 2 and all(t > 1_400_000_000 for t in times), name
+
+
+def test_unimplemented_sondes_always_proceed():
+    L = _lib.load()
+    sd = _lib.SondeData()
+    buf = np.zeros(4096, dtype=np.float32)
+    for name in ("imet4", "c50", "mrzn1"):
+        dec = getattr(L, f"{name}_decoder_init")(48000)
+        assert dec
+        assert getattr(L, f"{name}_decode")(dec, C.byref(sd), buf.ctypes.data_as(C.c_void_p), 4096) == _lib.PROCEED
+        getattr(L, f"{name}_decoder_deinit")(dec)
