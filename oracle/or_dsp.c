@@ -145,7 +145,7 @@ struct OrDemod {
 	float iq_last[2];
 	int64_t t_next;      /* Q16 absolute on-time instant of the next symbol */
 	int32_t period;      /* Q16 samples per symbol */
-	float yprev, bias, amp;
+	float bias, amp;
 	int32_t nstat;
 	uint8_t *bits;
 	uint64_t nbits, cap;
@@ -209,12 +209,16 @@ static void run_rounds(OrDemod *d)
 			m[k] = interp(d, t - (d->period >> 1));
 		}
 		for (int k = 0; k < K; k++) {
-			const float prev = k ? y[k - 1] : d->yprev;
-			const float a = prev - y[k];
-			const float b = m[k] - d->bias;
-			float e = a * b;
-			e = clampf(e * 1024.0f, -1.0e6f, 1.0e6f);
-			E += (int32_t)lrintf(e);
+			/* Gardner term of symbol k uses the previous symbol of the same round; the first symbol of
+			 * every 64-symbol group contributes nothing (on the GPU a group is one wavefront, and this
+			 * keeps the detector free of cross-wave traffic: 1.6 % fewer terms in a 200-term average) */
+			if (k & 63) {
+				const float a = y[k - 1] - y[k];
+				const float b = m[k] - d->bias;
+				float e = a * b;
+				e = clampf(e * 1024.0f, -1.0e6f, 1.0e6f);
+				E += (int32_t)lrintf(e);
+			}
 			const int bit = y[k] > d->bias;
 			const int32_t Y = (int32_t)lrintf(clampf(y[k], -8.0f, 8.0f) * 4096.0f);
 			if (bit) { S1 += Y; C1++; } else { S0 += Y; }
@@ -249,7 +253,6 @@ static void run_rounds(OrDemod *d)
 		const int32_t pmax = d->m->period0 + (d->m->period0 >> 8);
 		if (d->period < pmin) d->period = pmin;
 		if (d->period > pmax) d->period = pmax;
-		d->yprev = y[K - 1];
 	}
 }
 
@@ -283,7 +286,7 @@ void or_demod_state(const OrDemod *d, int64_t *t_next, int32_t *period, float *b
 	if (period) *period = d->period;
 	if (bias) *bias = d->bias;
 	if (amp) *amp = d->amp;
-	if (yprev) *yprev = d->yprev;
+	if (yprev) *yprev = 0.0f;
 }
 
 /* internal accessor for the framer */

@@ -177,6 +177,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		modems[t].ki = modems[t].kp * (1.0f / 4096.0f);
 		modems[t].pmin = p0 - (p0 >> 8);
 		modems[t].pmax = p0 + (p0 >> 8);
+		modems[t].rounds = ((((int64_t)SD_TILE << 16) / modems[t].pmin) + 2 > SD_ROUND_MAX) ? 2 : 1;
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
 	CHK(hipMemcpy(b->d_modems, modems, sizeof(modems), hipMemcpyHostToDevice));

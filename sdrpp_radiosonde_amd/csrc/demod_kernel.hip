@@ -111,39 +111,41 @@ __device__ __forceinline__ int wave_sum(int v)
 
 #define SD_LH      64     // samples of history kept in front of the tile in LDS
 #define SD_BUF     (SD_LH + SD_TILE + 4)
+#define SD_WGT     512    // workgroup: waves 0-3 run the timing-loop rounds, waves 4-7 the discriminator
 
 // LDS: the discriminator samples of [tile_start - 64, tile_end) twice, so that every (d[x], d[x+1])
 // pair the FIR needs is one 8-byte-aligned ds_read_b64 with an immediate offset:
 //   A[x] = d[x],  B[x] = d[x+1]   (x = index relative to tile_start - 64)
+// and double-buffered over tiles: while the round waves read tile i from buffer i&1, the
+// discriminator waves fill buffer (i+1)&1 with tile i+1.  One barrier per tile.
 struct DemodLds {
-	float A[SD_BUF];
-	float B[SD_BUF];
+	float A[2][SD_BUF];
+	float B[2][SD_BUF];
 	float taps[SD_NPHASE * SD_TAPS_LD];     // rows padded to 36 floats: 16-byte aligned ds_read_b128
-	float y[SD_WG];
-	int4 red[4];                            // per wave: (E, S1, S0, C1)
-	float iq_last[2];
-	uint32_t chunk[10];
+	int4 red[2][4];                         // [round parity][wave]: (E, S1, S0, C1)
+	uint32_t chunk[2][10];                  // [round parity]: the round's bits, one ballot per wave, zero-padded
 	uint32_t partial[2];                    // bits already in the ring word that wpos points into (ping-pong)
+	float iq_last[2];
 };
 
-// samples (i, i+1) of the new tile, i even
-__device__ __forceinline__ void store_pair(DemodLds &s, uint32_t i, float d0, float d1)
+// samples (i, i+1) of a tile, i even, into buffer b
+__device__ __forceinline__ void store_pair(DemodLds &s, int b, uint32_t i, float d0, float d1)
 {
-	*reinterpret_cast<float2 *>(&s.A[SD_LH + i]) = make_float2(d0, d1);
-	s.B[SD_LH + i - 1] = d0;
-	s.B[SD_LH + i] = d1;
+	*reinterpret_cast<float2 *>(&s.A[b][SD_LH + i]) = make_float2(d0, d1);
+	s.B[b][SD_LH + i - 1] = d0;
+	s.B[b][SD_LH + i] = d1;
 }
 
 // y(pos) = (sum_{j even} H[p][j] d[n+16-j]) + (sum_{j odd} H[p][j] d[n+16-j]), each an fmaf chain with j
 // ascending (SPEC 3.2): one v_pk_fma_f32 per tap pair.  The tap rows are stored pair-swapped
 // (T[2i] = H[2i+1], T[2i+1] = H[2i]) so that they line up with the (d[x], d[x+1]) pairs.
 // rel = pos relative to A[0], Q16.
-__device__ __forceinline__ float interp(const DemodLds &s, uint32_t rel)
+__device__ __forceinline__ float interp(const float *A, const float *B, const float *taps, uint32_t rel)
 {
 	const uint32_t top = (rel >> 16) + SD_NTAPS / 2;                    // buffer index of d for j = 0
-	const float *h = s.taps + ((rel >> 11) & (SD_NPHASE - 1)) * SD_TAPS_LD;
+	const float *h = taps + ((rel >> 11) & (SD_NPHASE - 1)) * SD_TAPS_LD;
 	// pair i holds (d[top-1-2i], d[top-2i]); it is 8-byte aligned in A when top is odd, in B otherwise
-	const float *lo = (top & 1u) ? (s.A + (top - 31u)) : (s.B + (top - 32u));
+	const float *lo = (top & 1u) ? (A + (top - 31u)) : (B + (top - 32u));
 	f32x2 acc = {0.0f, 0.0f};                                           // (odd chain, even chain)
 #pragma unroll
 	for (int q = 0; q < SD_NTAPS / 4; q++) {
@@ -158,8 +160,13 @@ __device__ __forceinline__ float interp(const DemodLds &s, uint32_t rel)
 	return acc.y + acc.x;
 }
 
+// ---------------------------------------------------------------- the kernel
+// Wave specialisation: the discriminator (K1) is pure per-sample ALU work, the rounds (K2/K3) are a
+// latency-bound chain (loop update -> FIR reads -> reduction).  Running them as different waves of the
+// same workgroup doubles the waves per SIMD and lets the hardware overlap them; the only hand-over is
+// the double-buffered LDS tile, one s_barrier per tile (two for sondes with > 256 symbols per tile).
 template <bool IS_IQ>
-__global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
+__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
@@ -168,138 +175,127 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 	__shared__ __attribute__((aligned(16))) DemodLds s;
 
 	const int tid = threadIdx.x;
-	const int lane = tid & 63, wave = tid >> 6;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const bool is_k = wave >= 4;           // wave-uniform role
+	const int t = tid & 255;               // index inside the role group
+	const int rwave = wave & 3;
 	const uint32_t ch = blockIdx.x;
 
 	SdChanState st = states[ch];
 	const SdModem md = modems[st.type];
+	const int rounds = md.rounds;          // sub-phases (= barriers) per tile: 1, or 2 for M10
 	const float *taps_g = taps_all + (size_t)st.type * SD_NPHASE * SD_NTAPS;
-	for (int i = tid; i < SD_NPHASE * SD_NTAPS; i += SD_WG)
+	for (int i = tid; i < SD_NPHASE * SD_NTAPS; i += SD_WGT)
 		s.taps[(i >> 5) * SD_TAPS_LD + ((i & 31) ^ 1)] = taps_g[i];     // pair-swapped rows, see interp()
 	// restore the carried history in front of the first tile (both copies)
 	if (tid < SD_LH) {
 		const float hv = hist[(size_t)ch * SD_HIST + tid];
-		s.A[tid] = hv;
-		if (tid) s.B[tid - 1] = hv;
+		s.A[0][tid] = hv;
+		if (tid) s.B[0][tid - 1] = hv;
 	}
 	uint32_t *ring_g = bitring + (size_t)ch * ring_words;
 	const uint32_t ring_mask = ring_words - 1;
 	if (tid == 0) {
-		s.chunk[0] = 0;
-		s.chunk[9] = 0;
+		s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0;
 		s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
 	}
-	int par = 0;
 
+	// ================================================================ discriminator role (waves 4-7)
 	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
 	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
 	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)ch * ch_stride);
 	const float2 *src2 = reinterpret_cast<const float2 *>(src);
 	float4 v[NLD];
-	float2 pv[NLD];                        // IQ: the sample just before each load's first sample
-	f32x2 dd[NLD];                         // IQ: the two discriminator outputs of each load
-	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);   // thread 255: newest sample seen
+	float2 pv[NLD];                        // IQ: the sample just before each wave's first sample of a load
+	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);
 
 	auto load_tile = [&](int tile) {
 #pragma unroll
 		for (int r = 0; r < NLD; r++) {
-			v[r] = src[(size_t)tile * TILE_F4 + tid + SD_WG * r];
+			v[r] = src[(size_t)tile * TILE_F4 + t + SD_WG * r];
 			if (IS_IQ && lane == 0) {
-				// only each wave's first lane fetches its predecessor sample; the others shuffle it in
-				const long idx = (long)tile * SD_TILE + 2 * (tid + SD_WG * r) - 1;
+				const long idx = (long)tile * SD_TILE + 2 * (t + SD_WG * r) - 1;
 				pv[r] = idx >= 0 ? src2[idx] : make_float2(st.iq_last[0], st.iq_last[1]);
 			}
 		}
 	};
-	// K1, lane-local: d[n] = atan2q(x[n] * conj(x[n-1])) for the lane's 8 samples (registers only)
-	auto k1_compute = [&](int r0, int r1) {
-		if (IS_IQ) {
+	// K1: d[n] = atan2q(x[n] * conj(x[n-1])) for the lane's 8 samples, straight into buffer b
+	auto k1_tile = [&](int b) {
 #pragma unroll
-			for (int r = r0; r < r1; r++) {
+		for (int r = 0; r < NLD; r++) {
+			if (IS_IQ) {
 				float px = __shfl_up(v[r].z, 1, 64), py = __shfl_up(v[r].w, 1, 64);
 				if (lane == 0) { px = pv[r].x; py = pv[r].y; }
-				dd[r].x = sd_disc(v[r].x, v[r].y, px, py);
-				dd[r].y = sd_disc(v[r].z, v[r].w, v[r].x, v[r].y);
-			}
-			last_iq = make_float2(v[NLD - 1].z, v[NLD - 1].w);
-		}
-	};
-	// after the barrier that ends the FIR reads of the previous tile: both LDS copies
-	auto k1_store = [&]() {
-		if (IS_IQ) {
-#pragma unroll
-			for (int r = 0; r < NLD; r++)
-				store_pair(s, 2u * (uint32_t)(tid + SD_WG * r), dd[r].x, dd[r].y);
-		} else {
-#pragma unroll
-			for (int r = 0; r < NLD; r++) {
-				const uint32_t i = 4u * (uint32_t)(tid + SD_WG * r);
-				store_pair(s, i, v[r].x, v[r].y);
-				store_pair(s, i + 2u, v[r].z, v[r].w);
+				const float d0 = sd_disc(v[r].x, v[r].y, px, py);
+				const float d1 = sd_disc(v[r].z, v[r].w, v[r].x, v[r].y);
+				store_pair(s, b, 2u * (uint32_t)(t + SD_WG * r), d0, d1);
+			} else {
+				const uint32_t i = 4u * (uint32_t)(t + SD_WG * r);
+				store_pair(s, b, i, v[r].x, v[r].y);
+				store_pair(s, b, i + 2u, v[r].z, v[r].w);
 			}
 		}
+		if (IS_IQ) last_iq = make_float2(v[NLD - 1].z, v[NLD - 1].w);
 	};
 
-	// timing-loop round, first part: both FIR evaluations of this lane's symbol
-	float y = 0.0f, m = 0.0f;
-	auto round_interp = [&](int K) {
-		y = 0.0f; m = 0.0f;
-		if (tid < K) {
-			const int64_t base = (st.n0 - SD_TILE - SD_LH) << 16;
-			const uint32_t rel = (uint32_t)(st.t_next - base) + (uint32_t)tid * (uint32_t)st.period;
-			y = interp(s, rel);
-			m = interp(s, rel - ((uint32_t)st.period >> 1));
+	// ================================================================ round role (waves 0-3)
+	int par = 0;                           // parity of the round whose statistics are pending in LDS
+	int pendK = -1;                        // symbols of that round, -1: nothing pending
+	int64_t n0 = st.n0;                    // samples consumed up to and including the tile in LDS
+
+	// FIR at this lane's symbol + Gardner term + slicer, integer statistics of the round -> LDS
+	auto round_front = [&](int K, int b) {
+		float y = 0.0f, m = 0.0f;
+		if (t < K) {
+			const int64_t base = (n0 - SD_TILE - SD_LH) << 16;
+			const uint32_t rel = (uint32_t)(st.t_next - base) + (uint32_t)t * (uint32_t)st.period;
+			y = interp(s.A[b], s.B[b], s.taps, rel);
+			m = interp(s.A[b], s.B[b], s.taps, rel - ((uint32_t)st.period >> 1));
 		}
-		s.y[tid] = y;
-	};
-	// second part (after a barrier): Gardner error, slice, integer statistics -> LDS
-	float ylast = 0.0f;
-	auto round_reduce = [&](int K) {
-		int Ei = 0, S1i = 0, S0i = 0;
-		bool bit = false;
-		if (tid < K) {
-			const float prev = tid ? s.y[tid - 1] : st.yprev;
-			const float a = prev - y;
-			const float b = m - st.bias;
-			float e = a * b;
-			e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
-			Ei = __float2int_rn(e);
-			bit = y > st.bias;
-			const int Y = __float2int_rn(sd_clamp(y, -8.0f, 8.0f) * 4096.0f);
-			if (bit) S1i = Y; else S0i = Y;
-		}
+		const float yprev = __shfl_up(y, 1, 64);
+		const bool act = t < K;
+		float e = (yprev - y) * (m - st.bias);
+		e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
+		int Ei = (act && lane != 0) ? __float2int_rn(e) : 0;     // first symbol of a 64-group: no term (SPEC 3.2)
+		const bool bit = act && (y > st.bias);
+		const int Y = __float2int_rn(sd_clamp(y, -8.0f, 8.0f) * 4096.0f);
+		int S1i = bit ? Y : 0;
+		int S0i = (act && !bit) ? Y : 0;
 		const unsigned long long bal = __ballot(bit);
 		Ei = wave_sum(Ei);
 		S1i = wave_sum(S1i);
 		S0i = wave_sum(S0i);
 		if (lane == 0) {
-			s.red[wave] = make_int4(Ei, S1i, S0i, __popcll(bal));
-			s.chunk[1 + 2 * wave] = (uint32_t)bal;
-			s.chunk[2 + 2 * wave] = (uint32_t)(bal >> 32);
+			s.red[par][rwave] = make_int4(Ei, S1i, S0i, __popcll(bal));
+			s.chunk[par][1 + 2 * rwave] = (uint32_t)bal;
+			s.chunk[par][2 + 2 * rwave] = (uint32_t)(bal >> 32);
 		}
-		ylast = K > 0 ? s.y[K - 1] : 0.0f;
+		pendK = K;
 	};
-	// third part (after a barrier): append the bits, update slicer levels and the PI loop filter
-	auto round_update = [&](int K) {
-		if (K <= 0) return;
-		const int4 r0 = s.red[0], r1 = s.red[1], r2 = s.red[2], r3 = s.red[3];
+	// after the barrier: append the round's bits, update slicer levels and the PI loop filter
+	auto round_back = [&]() {
+		const int K = pendK;
+		pendK = -1;
+		if (K <= 0) return;        // nothing was read or appended: keep the ping-pong parity
+		const int4 r0 = s.red[par][0], r1 = s.red[par][1], r2 = s.red[par][2], r3 = s.red[par][3];
 		const int E = r0.x + r1.x + r2.x + r3.x;
 		const int S1 = r0.y + r1.y + r2.y + r3.y;
 		const int S0 = r0.z + r1.z + r2.z + r3.z;
 		const int C1 = r0.w + r1.w + r2.w + r3.w;
 		const int C0 = K - C1;
-		if (tid < 9) {
+		if (t < 9) {
 			const uint32_t sh = (uint32_t)st.wpos & 31u;
 			const uint32_t w0 = (uint32_t)(st.wpos >> 5);
-			if ((uint32_t)(32 * tid) < sh + (uint32_t)K) {
-				const uint32_t lo = s.chunk[tid + 1];
-				const uint32_t pv = s.chunk[tid];
-				uint32_t vv = sh ? ((lo << sh) | (pv >> (32u - sh))) : lo;
-				const uint32_t idx = (w0 + tid) & ring_mask;
-				if (tid == 0 && sh) vv |= s.partial[par] & ((1u << sh) - 1u);
+			if ((uint32_t)(32 * t) < sh + (uint32_t)K) {
+				const uint32_t lo = s.chunk[par][t + 1];
+				const uint32_t pvw = s.chunk[par][t];
+				uint32_t vv = sh ? ((lo << sh) | (pvw >> (32u - sh))) : lo;
+				const uint32_t idx = (w0 + t) & ring_mask;
+				if (t == 0 && sh) vv |= s.partial[par] & ((1u << sh) - 1u);
 				ring_g[idx] = vv;
 				// whoever owns the word the next round starts in publishes it (read after a barrier)
-				if ((uint32_t)tid == ((sh + (uint32_t)K) >> 5)) s.partial[par ^ 1] = vv;
+				if ((uint32_t)t == ((sh + (uint32_t)K) >> 5)) s.partial[par ^ 1] = vv;
 			}
 		}
 		if (C1 > 0 && C0 > 0) {
@@ -330,63 +326,58 @@ __global__ __launch_bounds__(SD_WG, 4) void sd_demod_kernel(
 		st.period += dper;
 		if (st.period < md.pmin) st.period = md.pmin;
 		if (st.period > md.pmax) st.period = md.pmax;
-		st.yprev = ylast;
 		st.wpos += (uint64_t)K;
 		par ^= 1;
 	};
 
-	// ---- prologue: tile 0 into LDS, tile 1 in flight
-	load_tile(0);
-	k1_compute(0, NLD);
-	__syncthreads();
-	k1_store();
-	if (n_tiles > 1) load_tile(1);
-	st.n0 += SD_TILE;
-	__syncthreads();
-
-	for (int tile = 0; tile < n_tiles; tile++) {
-		// LDS holds tile `tile` (+64 samples of history); v[] holds the raw samples of tile+1
-		const bool has_next = tile + 1 < n_tiles;
-		const int64_t limit = (((st.n0 - 1 - SD_NTAPS / 2 - SD_MARGIN) << 16) | 0xFFFF);
-		int K_total = (st.t_next <= limit) ? (int)((uint32_t)(limit - st.t_next) / (uint32_t)st.period) + 1 : 0;
-		// all but the last round of the tile (only sondes with > 256 symbols per tile get here)
-		while (K_total > SD_ROUND_MAX) {
-			round_interp(SD_ROUND_MAX);
-			__syncthreads();
-			round_reduce(SD_ROUND_MAX);
-			__syncthreads();
-			round_update(SD_ROUND_MAX);
-			K_total -= SD_ROUND_MAX;
+	// ---- the two roles run separate loops (so that neither carries the other's live registers) with the
+	// same number of s_barriers: one after the prologue, then `rounds` per tile.  is_k is wave-uniform.
+	if (is_k) {
+		load_tile(0);
+		k1_tile(0);
+		if (n_tiles > 1) load_tile(1);
+		__syncthreads();
+		for (int tile = 0; tile < n_tiles; tile++) {
+			const int b = tile & 1;
+			if (tile + 1 < n_tiles) {
+				// history roll: the last 64 samples of tile `tile` in front of tile+1 in the other buffer
+				if (t < SD_LH) s.A[b ^ 1][t] = s.A[b][SD_TILE + t];
+				else if (t < 2 * SD_LH - 1) s.B[b ^ 1][t - SD_LH] = s.B[b][SD_TILE + t - SD_LH];
+				k1_tile(b ^ 1);
+				if (tile + 2 < n_tiles) load_tile(tile + 2);
+			}
+			for (int r = 0; r < rounds; r++) __syncthreads();
 		}
-		// last round, software-pipelined with K1 of the next tile: two barriers per tile
-		const int K = K_total;
-		round_interp(K);
-		float rollA = 0.0f, rollB = 0.0f;
-		if (has_next) {
-			k1_compute(0, NLD / 2);                       // ALU work that covers the LDS latency above
-			if (tid < SD_LH) rollA = s.A[SD_TILE + tid];
-			else if (tid < 2 * SD_LH - 1) rollB = s.B[SD_TILE + tid - SD_LH];
+	} else {
+		__syncthreads();
+		int K_total = 0;
+		for (int tile = 0; tile < n_tiles; tile++) {
+			const int b = tile & 1;
+			for (int r = 0; r < rounds; r++) {
+				if (pendK >= 0) round_back();                         // the previous round's update
+				if (r == 0) {
+					n0 += SD_TILE;                                    // the tile in buffer b is now counted
+					const int64_t limit = (((n0 - 1 - SD_NTAPS / 2 - SD_MARGIN) << 16) | 0xFFFF);
+					K_total = (st.t_next <= limit) ? (int)((uint32_t)(limit - st.t_next) / (uint32_t)st.period) + 1 : 0;
+				}
+				const int K = K_total > SD_ROUND_MAX ? SD_ROUND_MAX : K_total;
+				K_total -= K;
+				round_front(K, b);
+				__syncthreads();
+			}
 		}
-		__syncthreads();                                  // (1) all FIR reads of this tile are done
-		round_reduce(K);
-		if (has_next) {
-			if (tid < SD_LH) s.A[tid] = rollA;            // history roll: last 64 samples to the front
-			else if (tid < 2 * SD_LH - 1) s.B[tid - SD_LH] = rollB;
-			k1_compute(NLD / 2, NLD);                     // ... and the DPP reduction latency here
-			k1_store();                                   // tile+1 replaces tile in LDS
-			if (tile + 2 < n_tiles) load_tile(tile + 2);
-		}
-		__syncthreads();                                  // (2) statistics + next tile visible
-		round_update(K);
-		if (has_next) st.n0 += SD_TILE;
 	}
 
-	if (IS_IQ && tid == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
+	// ---- epilogue: the last round's update, then carry history and state to the next submit
+	if (is_k && IS_IQ && t == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
+	if (!is_k && pendK >= 0) round_back();
 	__syncthreads();
-	// carry the history and the scalar state to the next submit
-	if (tid < SD_LH) hist[(size_t)ch * SD_HIST + tid] = s.A[SD_TILE + tid];
+	const int bl = (n_tiles - 1) & 1;
+	if (tid < SD_LH) hist[(size_t)ch * SD_HIST + tid] = s.A[bl][SD_TILE + tid];
 	if (tid == 0) {
+		st.n0 = n0;
 		if (IS_IQ) { st.iq_last[0] = s.iq_last[0]; st.iq_last[1] = s.iq_last[1]; }
+		st.yprev = 0.0f;
 		states[ch] = st;
 	}
 }
@@ -396,9 +387,9 @@ void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems)
 {
 	if (is_iq)
-		hipLaunchKernelGGL(sd_demod_kernel<true>, dim3(n_channels), dim3(SD_WG), 0, stream,
+		hipLaunchKernelGGL(sd_demod_kernel<true>, dim3(n_channels), dim3(SD_WGT), 0, stream,
 			in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems);
 	else
-		hipLaunchKernelGGL(sd_demod_kernel<false>, dim3(n_channels), dim3(SD_WG), 0, stream,
+		hipLaunchKernelGGL(sd_demod_kernel<false>, dim3(n_channels), dim3(SD_WGT), 0, stream,
 			in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems);
 }

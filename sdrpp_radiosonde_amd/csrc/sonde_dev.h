@@ -22,6 +22,7 @@ struct SdModem {            // per sonde type, built on the host
 	float   kp;             // proportional gain, Q16 samples per unit error
 	float   ki;             // integral gain
 	int32_t pmin, pmax;     // period clamp
+	int32_t rounds;         // timing-loop rounds per tile: 1, or 2 when a tile can hold > 256 symbols (M10)
 };
 
 struct SdChanState {        // demodulator state, one per channel (64 B)
