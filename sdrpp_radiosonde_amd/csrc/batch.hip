@@ -74,6 +74,7 @@ struct SondeBatch {
 	uint32_t n_channels = 0, max_samples = 0;
 	int input_kind = 0, device = 0;
 	uint32_t ring_words = 0, max_frames = 0;
+	uint32_t type_frames[SONDE_NTYPES] = {};   // upper bound of complete frames per submit, per sonde type (B2 grid)
 	std::vector<uint8_t> types;
 	std::vector<uint32_t> chlist[SONDE_NTYPES];
 
@@ -97,6 +98,7 @@ struct SondeBatch {
 	hipStream_t last_stream = nullptr;
 	bool pending = false, have_counts = false;
 	std::vector<uint32_t> h_counts;
+	std::vector<SondeFrame> h_slots;
 	long n_frames = 0;
 };
 
@@ -144,7 +146,17 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	pmin -= pmin >> 8;
 	const uint64_t max_bits = ((uint64_t)cfg->max_samples << 16) / (uint64_t)pmin + 2;
 	b->ring_words = pow2ceil((uint32_t)((max_bits + 8 * SONDE_FRAME_MAX + 1024 + 31) / 32));
-	b->max_frames = (uint32_t)(max_bits / 560) + 2;        // shortest frame: DFM, 560 chips
+	b->max_frames = 2;
+	{	// frames per submit per type: submit bits (at that type's fastest period) / shortest frame of the type, + carry-over
+		static const uint32_t min_frame_bits[SONDE_NTYPES] = { 320 * 8, 560, 1152, 1648, 1u << 30, 1u << 30, 1u << 30 };
+		for (int t = 0; t < SONDE_NTYPES; t++) {
+			if (b->chlist[t].empty()) continue;
+			const int32_t p = modem_period0(t) - (modem_period0(t) >> 8);
+			const uint64_t bits_t = ((uint64_t)cfg->max_samples << 16) / (uint64_t)p + 2;
+			b->type_frames[t] = (uint32_t)(bits_t / min_frame_bits[t]) + 2;
+			b->max_frames = std::max(b->max_frames, b->type_frames[t]);
+		}
+	}
 	if ((size_t)b->ring_words * 4 > 65536) { delete b; return fail("sonde_batch_create: max_samples too large for the LDS-staged bit ring (64 KB)"); }
 
 	const size_t C = b->n_channels;
@@ -248,13 +260,13 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	if (!b->chlist[SONDE_RS41].empty()) {
 		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
 			b->d_states, b->d_fstates, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfmulk, b->d_descs,
-			b->d_frames, b->d_counts, b->max_frames, b->d_chlist[SONDE_RS41]);
+			b->d_frames, b->d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);
 		HIPCHK(hipGetLastError());
 	}
 	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10 }) {
 		if (b->chlist[t].empty()) continue;
 		sd_launch_framer_other(t, (uint32_t)b->chlist[t].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-			b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->d_chlist[t]);
+			b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t]);
 		HIPCHK(hipGetLastError());
 	}
 	HIPCHK(hipEventRecord(ev[2], stream));
@@ -309,8 +321,22 @@ extern "C" long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap)
 	const long n = sonde_batch_sync(b);
 	if (n < 0) return n;
 	if (n == 0 || !out || cap == 0) return 0;
-	// frames sit in per-channel slot groups: gather the used slots (already ordered by channel, then time)
+	// frames sit in per-channel slot groups (ordered by channel, then time): one bulk copy of the slot
+	// array when it is small, else one copy per channel that has frames
 	size_t k = 0;
+	const size_t all = (size_t)b->n_channels * b->max_frames;
+	if (all * sizeof(SondeFrame) <= (64u << 20)) {
+		b->h_slots.resize(all);
+		hipError_t e = hipMemcpy(b->h_slots.data(), b->d_frames, all * sizeof(SondeFrame), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return fail("hipMemcpy frames", e);
+		for (uint32_t c = 0; c < b->n_channels && k < cap; c++) {
+			const uint32_t cnt = std::min(b->h_counts[c], b->max_frames);
+			const size_t take = std::min((size_t)cnt, cap - k);
+			if (take) memcpy(out + k, b->h_slots.data() + (size_t)c * b->max_frames, take * sizeof(SondeFrame));
+			k += take;
+		}
+		return (long)k;
+	}
 	for (uint32_t c = 0; c < b->n_channels && k < cap; c++) {
 		const uint32_t cnt = std::min(b->h_counts[c], b->max_frames);
 		if (!cnt) continue;

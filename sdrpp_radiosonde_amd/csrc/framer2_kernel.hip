@@ -305,11 +305,11 @@ __global__ __launch_bounds__(64) void sd_dec_ims_kernel(
 // ---------------------------------------------------------------- host launcher
 void sd_launch_framer_other(int type, uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
-	const uint8_t *g64, void *descs_, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist)
+	const uint8_t *g64, void *descs_, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist)
 {
 	SdFrameDesc *descs = (SdFrameDesc *)descs_;
 	const size_t lds = ring_words * sizeof(uint32_t);
-	const dim3 g2(max_frames, n_list);
+	const dim3 g2(grid_frames, n_list);
 	switch (type) {
 	case SONDE_DFM09:
 		hipLaunchKernelGGL(sd_sync_fixed_kernel<SONDE_DFM09>, dim3(n_list), dim3(64), lds, stream, states, fstates, bitring, ring_words, descs, counts, max_frames, chlist);

@@ -33,10 +33,16 @@ __constant__ uint8_t c_rs41_mask[64] = {
 	0xD0, 0xBC, 0xB4, 0xB6, 0x06, 0xAA, 0xF4, 0x23, 0x78, 0x6E, 0x3B, 0xAE, 0xBF, 0x7B, 0x4C, 0xC1,
 };
 
-struct FramerLds {
+// wave-scope ordering of LDS traffic: DS operations of one wave execute in order, so lanes of the same
+// wave see each other's LDS writes once the compiler is kept from reordering across this point
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+struct FramerTabs {                // shared by the waves of a workgroup
 	uint8_t mulk[RS_R * 256];      // mulk[j][v] = v * alpha^j : one dependent lookup per Horner step
 	uint8_t exp[512];
 	uint8_t log[256];
+};
+struct FramerLds {                 // one per wave (= per frame)
 	uint8_t frame[SONDE_FRAME_MAX];
 	uint8_t cw[2][256];
 	uint8_t S[2][RS_R];
@@ -50,11 +56,11 @@ struct FramerLds {
 	int     status[2];     // 0 clean, >0 errors to fix, -1 fail
 };
 
-__device__ __forceinline__ uint8_t gmul(const FramerLds &s, uint8_t a, uint8_t b)
+__device__ __forceinline__ uint8_t gmul(const FramerTabs &s, uint8_t a, uint8_t b)
 {
 	return (a && b) ? s.exp[s.log[a] + s.log[b]] : 0;
 }
-__device__ __forceinline__ uint8_t gdiv(const FramerLds &s, uint8_t a, uint8_t b)
+__device__ __forceinline__ uint8_t gdiv(const FramerTabs &s, uint8_t a, uint8_t b)
 {
 	return a ? s.exp[s.log[a] + 255 - s.log[b]] : 0;
 }
@@ -75,15 +81,27 @@ __device__ __forceinline__ uint8_t byte_at(const uint32_t *ring, uint32_t mask, 
 }
 
 // Decode both codewords held in s.cw[c][0..n).  Wave-synchronous; 64 lanes.
-__device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
+__device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int lane)
 {
 	// ---- syndromes: lane = 24*c + j, Horner from the highest position down
 	uint8_t syn = 0;
 	if (lane < 2 * RS_R) {
 		const int c = lane / RS_R, j = lane % RS_R;
-		const uint8_t *mj = s.mulk + 256 * j;
-		for (int i = n - 1; i >= 0; i--)
-			syn = (uint8_t)(mj[syn] ^ s.cw[c][i]);
+		// Horner in four independent quarter-chains (4x shorter dependent LDS-lookup chain), then
+		// S = ((S3*A + S2)*A + S1)*A + S0 with A = alpha^(j*q): same field element as one long chain
+		const uint8_t *mj = tb.mulk + 256 * j;
+		const int q = (n + 3) >> 2;                 // quarter length; the top quarter may be shorter
+		uint8_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+		for (int i = q - 1; i >= 0; i--) {
+			p0 = (uint8_t)(mj[p0] ^ s.cw[c][i]);
+			p1 = (uint8_t)(mj[p1] ^ s.cw[c][q + i]);
+			p2 = (uint8_t)(mj[p2] ^ s.cw[c][2 * q + i]);
+			p3 = (uint8_t)(mj[p3] ^ (3 * q + i < n ? s.cw[c][3 * q + i] : 0));
+		}
+		const uint8_t A = tb.exp[(j * q) % 255];
+		syn = (uint8_t)(gmul(tb, p3, A) ^ p2);
+		syn = (uint8_t)(gmul(tb, syn, A) ^ p1);
+		syn = (uint8_t)(gmul(tb, syn, A) ^ p0);
 		s.S[c][j] = syn;
 	}
 	const unsigned long long nzm = __ballot(syn != 0);
@@ -92,7 +110,7 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 		s.status[lane] = nz ? 1 : 0;
 		s.L[lane] = 0;
 	}
-		__syncthreads();
+		WAVE_SYNC();
 
 	// ---- Berlekamp-Massey, one coefficient per lane: half-wave h handles codeword h, lane idx = lane&31
 	// holds lam[idx] and Bp[idx] where Bp = x^m * B.  Same recurrence as the sequential form
@@ -106,7 +124,7 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 		uint8_t bb = 1;
 		for (int r = 0; r < RS_R; r++) {
 			const uint8_t sv = (live && idx <= r && idx <= L && idx < RS_R + 1) ? s.S[h][r - idx] : 0;
-			int t = gmul(s, lam, sv);
+			int t = gmul(tb, lam, sv);
 			// xor-reduce over the 32 lanes of this half (two DPP rows)
 			t ^= __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true);
 			t ^= __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xF, 0xF, true);
@@ -118,8 +136,8 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 			const uint8_t lam_old = lam;
 			bool change = false;
 			if (delta) {
-				const uint8_t f = gdiv(s, delta, bb);
-				lam = (uint8_t)(lam ^ gmul(s, f, Bp));
+				const uint8_t f = gdiv(tb, delta, bb);
+				lam = (uint8_t)(lam ^ gmul(tb, f, Bp));
 				change = 2 * L <= r;
 			}
 			const int shifted_src = change ? (int)lam_old : (int)Bp;
@@ -137,7 +155,7 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 			if (L > RS_T || deg != L) s.status[h] = -1;
 		}
 	}
-	__syncthreads();
+	WAVE_SYNC();
 
 	for (int c = 0; c < 2; c++) {
 		if (s.status[c] <= 0) continue;          // wave-uniform
@@ -152,7 +170,7 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 			if (i < 255) {
 				uint8_t v = 0;
 				for (int k = 0; k <= L; k++)
-					if (lam[k]) v ^= s.exp[(s.log[lam[k]] + (255 - i) * k) % 255];
+					if (lam[k]) v ^= tb.exp[(tb.log[lam[k]] + (255 - i) * k) % 255];
 				root = (v == 0);
 			}
 			const unsigned long long rm = __ballot(root);
@@ -165,16 +183,16 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 		}
 		if (__ballot(fail) != 0ull || npos != L) {
 			if (lane == 0) s.status[c] = -1;
-						__syncthreads();
+						WAVE_SYNC();
 			continue;
 		}
 		// ---- omega = S*lam mod x^24
 		if (lane < RS_R) {
 			uint8_t v = 0;
-			for (int k = 0; k <= lane && k <= L; k++) v ^= gmul(s, lam[k], s.S[c][lane - k]);
+			for (int k = 0; k <= lane && k <= L; k++) v ^= gmul(tb, lam[k], s.S[c][lane - k]);
 			s.om[c][lane] = v;
 		}
-				__syncthreads();
+				WAVE_SYNC();
 		// ---- Forney: e = X * omega(X^-1) / lam'(X^-1)
 		bool bad = false;
 		uint8_t ev = 0;
@@ -184,11 +202,11 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 			const int xi = (255 - p) % 255;
 			uint8_t num = 0, den = 0;
 			for (int k = 0; k < RS_R; k++)
-				if (s.om[c][k]) num ^= s.exp[(s.log[s.om[c][k]] + xi * k) % 255];
+				if (s.om[c][k]) num ^= tb.exp[(tb.log[s.om[c][k]] + xi * k) % 255];
 			for (int k = 1; k <= L; k += 2)
-				if (lam[k]) den ^= s.exp[(s.log[lam[k]] + xi * (k - 1)) % 255];
+				if (lam[k]) den ^= tb.exp[(tb.log[lam[k]] + xi * (k - 1)) % 255];
 			if (!den) bad = true;
-			else ev = gmul(s, s.exp[p], gdiv(s, num, den));
+			else ev = gmul(tb, tb.exp[p], gdiv(tb, num, den));
 		}
 		if (__ballot(bad) != 0ull) {
 			if (lane == 0) s.status[c] = -1;
@@ -196,7 +214,7 @@ __device__ void rs255_decode_pair(FramerLds &s, int n, int lane)
 			if (lane < npos) s.cw[c][p] ^= ev;
 			if (lane == 0) s.status[c] = npos;
 		}
-				__syncthreads();
+				WAVE_SYNC();
 	}
 }
 
@@ -293,33 +311,44 @@ __global__ __launch_bounds__(64) void sd_sync_rs41_kernel(
 }
 
 // ---------------------------------------------------------------- B2: per-frame de-whitening + RS
-__global__ __launch_bounds__(64) void sd_rsdec_rs41_kernel(
+// 256 threads = 4 waves = 4 frames per workgroup: the 7 KB of GF tables are staged once per
+// workgroup, each wave then works alone on its own frame (wave-scope synchronisation only), so that
+// all frames of a step are resident at once and their latency-bound GF(2^8) chains overlap.
+#define B2_WAVES 4
+__global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 	const uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const uint8_t *__restrict__ gf_exp, const uint8_t *__restrict__ gf_log, const uint8_t *__restrict__ gf_mulk,
 	const SdFrameDesc *__restrict__ descs, const uint32_t *__restrict__ counts, uint32_t max_frames,
 	SondeFrame *__restrict__ frames, const uint32_t *__restrict__ chlist)
 {
+	__shared__ __attribute__((aligned(16))) FramerTabs tabs;
+	__shared__ __attribute__((aligned(16))) FramerLds wl[B2_WAVES];
 	const uint32_t ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
-	const uint32_t k = blockIdx.x;
-	if (k >= counts[ch] || k >= max_frames) return;
-	__shared__ __attribute__((aligned(16))) FramerLds s;
-	const int lane = threadIdx.x;
+	const uint32_t nfr = min(counts[ch], max_frames);
+	if (B2_WAVES * blockIdx.x >= nfr) return;                  // whole workgroup has nothing to do
+	{
+		const int tid = threadIdx.x;
+		const uint4 *src = reinterpret_cast<const uint4 *>(gf_mulk);
+		uint4 *dst = reinterpret_cast<uint4 *>(tabs.mulk);
+		for (int i = tid; i < RS_R * 256 / 16; i += 64 * B2_WAVES) dst[i] = src[i];
+		if (tid < 512 / 4) reinterpret_cast<uint32_t *>(tabs.exp)[tid] = reinterpret_cast<const uint32_t *>(gf_exp)[tid];
+		else if (tid < 512 / 4 + 256 / 4) reinterpret_cast<uint32_t *>(tabs.log)[tid - 128] = reinterpret_cast<const uint32_t *>(gf_log)[tid - 128];
+	}
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int w = threadIdx.x >> 6;
+	const uint32_t k = B2_WAVES * blockIdx.x + (uint32_t)w;
+	if (k >= nfr) return;
+	FramerLds &s = wl[w];
 	const uint32_t *ring = bitring + (size_t)ch * ring_words;
 	const uint32_t mask = ring_words - 1;
 	const SdFrameDesc d = descs[(size_t)ch * max_frames + k];
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(gf_mulk);
-		uint4 *dst = reinterpret_cast<uint4 *>(s.mulk);
-		for (int i = lane; i < RS_R * 256 / 16; i += 64) dst[i] = src[i];
-		for (int i = lane; i < 512 / 4; i += 64) reinterpret_cast<uint32_t *>(s.exp)[i] = reinterpret_cast<const uint32_t *>(gf_exp)[i];
-		if (lane < 256 / 4) reinterpret_cast<uint32_t *>(s.log)[lane] = reinterpret_cast<const uint32_t *>(gf_log)[lane];
-	}
 	const int flen = d.flen;
 	const uint8_t xinv = d.inv ? 0xFF : 0x00;
 	// K5: extract + de-whiten
 	for (int i = lane; i < flen; i += 64)
 		s.frame[i] = (uint8_t)(byte_at(ring, mask, d.fstart + 8 * (uint64_t)i) ^ xinv ^ c_rs41_mask[i & 63]);
-	__syncthreads();
+	WAVE_SYNC();
 	// K6: de-interleave into two shortened codewords
 	const int msglen = (flen - 56) / 2;
 	const int n = RS_R + msglen;
@@ -330,8 +359,8 @@ __global__ __launch_bounds__(64) void sd_rsdec_rs41_kernel(
 		else if (kk < n) v = s.frame[56 + 2 * (kk - RS_R) + c];
 		s.cw[c][kk] = v;
 	}
-	__syncthreads();
-	rs255_decode_pair(s, n, lane);
+	WAVE_SYNC();
+	rs255_decode_pair(tabs, s, n, lane);
 	for (int c = 0; c < 2; c++) {
 		if (s.status[c] > 0) {
 			for (int kk = lane; kk < n; kk += 64) {
@@ -340,7 +369,7 @@ __global__ __launch_bounds__(64) void sd_rsdec_rs41_kernel(
 			}
 		}
 	}
-	__syncthreads();
+	WAVE_SYNC();
 	SondeFrame *fr = frames + (size_t)ch * max_frames + k;
 	if (lane == 0) {
 		fr->channel = ch;
@@ -353,19 +382,19 @@ __global__ __launch_bounds__(64) void sd_rsdec_rs41_kernel(
 	}
 	for (int i = lane; i < SONDE_FRAME_MAX / 4; i += 64) {
 		const int b = 4 * i;
-		uint32_t w = 0;
-		for (int q = 0; q < 4; q++) w |= (uint32_t)(b + q < flen ? s.frame[b + q] : 0) << (8 * q);
-		reinterpret_cast<uint32_t *>(fr->data)[i] = w;
+		uint32_t wd = 0;
+		for (int q = 0; q < 4; q++) wd |= (uint32_t)(b + q < flen ? s.frame[b + q] : 0) << (8 * q);
+		reinterpret_cast<uint32_t *>(fr->data)[i] = wd;
 	}
 }
 
 void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
 	const uint8_t *gf_exp, const uint8_t *gf_log, const uint8_t *gf_mulk, void *descs,
-	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist)
+	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist)
 {
 	hipLaunchKernelGGL(sd_sync_rs41_kernel, dim3(n_list), dim3(64), ring_words * sizeof(uint32_t), stream,
 		states, fstates, bitring, ring_words, (SdFrameDesc *)descs, counts, max_frames, chlist);
-	hipLaunchKernelGGL(sd_rsdec_rs41_kernel, dim3(max_frames, n_list), dim3(64), 0, stream,
+	hipLaunchKernelGGL(sd_rsdec_rs41_kernel, dim3((grid_frames + B2_WAVES - 1) / B2_WAVES, n_list), dim3(64 * B2_WAVES), 0, stream,
 		bitring, ring_words, gf_exp, gf_log, gf_mulk, (const SdFrameDesc *)descs, counts, max_frames, frames, chlist);
 }

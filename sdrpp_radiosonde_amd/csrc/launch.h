@@ -12,8 +12,8 @@ void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
 void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
 	const uint8_t *gf_exp, const uint8_t *gf_log, const uint8_t *gf_mulk, void *descs,
-	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist);
+	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist);
 
 void sd_launch_framer_other(int type, uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
-	const uint8_t *g64, void *descs, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist);
+	const uint8_t *g64, void *descs, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist);
