@@ -148,6 +148,18 @@ int  sonde_parse_frame(const SondeFrame *f, SondeData *out, int cap);
 float sonde_dewpt(float temp, float rh);
 float sonde_altitude_to_pressure(float alt);
 
+/* sinks (C faces of include/sonde_sinks.hpp): GPX 1.1 track + PTU CSV, byte-identical to the files
+ * /root/reference/src/gpx.cpp and /root/reference/src/ptu.cpp write */
+void *sonde_gpx_open(const char *path);
+void  sonde_gpx_close(void *g);
+void  sonde_gpx_start_track(void *g, const char *name);
+void  sonde_gpx_stop_track(void *g);
+void  sonde_gpx_add_point(void *g, long t, float lat, float lon, float alt, float spd, float hdg);
+void *sonde_ptu_open(const char *path);
+void  sonde_ptu_close(void *p);
+void  sonde_ptu_add_point(void *p, long t, float temp, float rh, float dewpt, float pressure, float lat, float lon,
+                          float alt, float spd, float hdg, float climb, const char *aux);
+
 const char *sonde_last_error(void);
 const char *sonde_version(void);
 

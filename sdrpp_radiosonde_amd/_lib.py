@@ -50,6 +50,8 @@ ABI_SYMBOLS = [
     "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_kernel_ms", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_get_taps", "sonde_parse_frame",
     "sonde_last_error", "sonde_version", "sonde_dewpt", "sonde_altitude_to_pressure",
+    "sonde_gpx_open", "sonde_gpx_close", "sonde_gpx_start_track", "sonde_gpx_stop_track", "sonde_gpx_add_point",
+    "sonde_ptu_open", "sonde_ptu_close", "sonde_ptu_add_point",
 ] + [f"{x}_{fn}" for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1")
      for fn in ("decoder_init", "decoder_deinit", "decode")]
 
@@ -89,6 +91,17 @@ def load() -> C.CDLL:
     L.sonde_dewpt.argtypes = [C.c_float, C.c_float]
     L.sonde_altitude_to_pressure.restype = C.c_float
     L.sonde_altitude_to_pressure.argtypes = [C.c_float]
+    f = C.c_float
+    L.sonde_gpx_open.restype = vp
+    L.sonde_gpx_open.argtypes = [C.c_char_p]
+    L.sonde_gpx_close.argtypes = [vp]
+    L.sonde_gpx_start_track.argtypes = [vp, C.c_char_p]
+    L.sonde_gpx_stop_track.argtypes = [vp]
+    L.sonde_gpx_add_point.argtypes = [vp, C.c_long, f, f, f, f, f]
+    L.sonde_ptu_open.restype = vp
+    L.sonde_ptu_open.argtypes = [C.c_char_p]
+    L.sonde_ptu_close.argtypes = [vp]
+    L.sonde_ptu_add_point.argtypes = [vp, C.c_long, f, f, f, f, f, f, f, f, f, f, C.c_char_p]
     for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1"):
         getattr(L, f"{x}_decoder_init").argtypes = [C.c_int]
         getattr(L, f"{x}_decoder_init").restype = vp
