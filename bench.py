@@ -112,6 +112,15 @@ def main():
     # + bits written (n/sps/8 bytes per channel) -- DESIGN.md section 6
     alg_bytes = C * n * 8 + C * (n * 4800 // 48000) // 8
     achieved = alg_bytes / (demod_ms * 1e-3) / 1e9
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes from the
+    # committed rocprofv3 --pmc passes of this same command (profiles/r1_traffic.json) when the workload matches
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        if tj["channels_per_gpu"] == C and tj["samples_per_channel"] == n:
+            traffic = tj["fetch_bytes"] + tj["write_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     out = {
         "metric": "IQ Msamples/s through demod+FEC @ 48 kS/s/ch",
@@ -134,7 +143,8 @@ def main():
         "realtime_channels": round(msps * 1e6 / 48000.0, 1),
         "kernel_ms": {"demod": round(demod_ms, 4), "framer_fec": round(framer_ms, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes": alg_bytes, "kernel": "sd_demod_kernel<true>"},
     }
     if scatter_ms is not None:
         out["scatter_ms"] = round(scatter_ms, 3)
