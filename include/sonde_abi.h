@@ -144,6 +144,21 @@ int      sonde_get_taps(int type, float *out /* 32*32 floats, [phase][tap] */);
  * Returns number of fragments written (<= cap). */
 int  sonde_parse_frame(const SondeFrame *f, SondeData *out, int cap);
 
+/* ------------------------------------------------------------------ wideband front-end (BASELINE config 4)
+ * 10 MS/s complex IQ -> 512-bin polyphase channelizer (19531.25 Hz spacing, 40 kS/s per bin) -> per-bin FM
+ * discriminator -> 6/5 rational resampler -> 48 kS/s -> the decoder of the bin's sonde type: the reference's
+ * VFO -> dsp::demod::FM -> RationalResampler -> Decoder chain (/root/reference/src/main.cpp:55-68) for every
+ * bin at once.  One submit takes blocks_per_submit * 1 280 000 wideband samples (device pointer, complex64). */
+typedef struct SondeChannelizer SondeChannelizer;
+int         sonde_chan_create(const uint8_t *types /* 512 entries or NULL = RS41 */, uint32_t blocks_per_submit /* 1..2 */,
+                              int device, SondeChannelizer **out);
+void        sonde_chan_destroy(SondeChannelizer *c);
+uint32_t    sonde_chan_samples_per_submit(const SondeChannelizer *c);
+int         sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t n_samples, void *stream);
+SondeBatch *sonde_chan_batch(SondeChannelizer *c);     /* frames of the 512 bins: sonde_batch_sync / _frames on this */
+int         sonde_chan_read(SondeChannelizer *c, float *bins, float *out48);      /* parity-test introspection */
+int         sonde_chan_tables(float *h, float *tw, float *g);
+
 /* post-FEC derived quantities, as /root/reference/src/decode/decoder.hpp:132-174 computes them */
 float sonde_dewpt(float temp, float rh);
 float sonde_altitude_to_pressure(float alt);

@@ -1,0 +1,160 @@
+/*
+ * or_chan.c -- oracle for the wideband front-end (BASELINE config 4):
+ *   10 MS/s complex IQ -> 512-bin oversampled polyphase filter bank (decimation 250 -> 40 kS/s per bin)
+ *   -> per-bin FM discriminator at 40 kS/s -> real rational resampler 6/5 -> 48 kS/s
+ * which is the reference's own ordering  VFO channeliser -> dsp::demod::FM -> RationalResampler -> decoder
+ * (/root/reference/src/main.cpp:55-60).  Those SDR++ blocks are absent from the reference tree, so the
+ * arithmetic is this repo's SPEC.  TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+ *
+ * Bit-exactness contract as elsewhere: -ffp-contract=off, explicit fmaf, fixed summation orders.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "sonde_oracle.h"
+
+#define CH_PI 3.14159265358979323846
+
+/* prototype low-pass of the filter bank: Blackman-windowed sinc, cutoff 8 kHz at 10 MS/s, unit DC gain */
+void or_chan_proto(float *h /* OR_CH_L */)
+{
+	const double fc = 8000.0 / OR_CH_FS;
+	double sum = 0.0;
+	static double tmp[OR_CH_L];
+	for (int i = 0; i < OR_CH_L; i++) {
+		const double t = (double)i - 0.5 * (double)(OR_CH_L - 1);
+		const double x = (double)i / (double)(OR_CH_L - 1);
+		const double w = 0.42 - 0.5 * cos(2.0 * CH_PI * x) + 0.08 * cos(4.0 * CH_PI * x);
+		const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * CH_PI * fc * t) / (CH_PI * t);
+		tmp[i] = s * w;
+		sum += tmp[i];
+	}
+	for (int i = 0; i < OR_CH_L; i++) h[i] = (float)(tmp[i] / sum);
+}
+
+/* twiddles w[k] = exp(-2 pi i k / 512), k < 256 */
+void or_chan_twiddles(float *tw /* 2*256, (re, im) */)
+{
+	for (int k = 0; k < OR_CH_M / 2; k++) {
+		tw[2 * k] = (float)cos(2.0 * CH_PI * (double)k / (double)OR_CH_M);
+		tw[2 * k + 1] = (float)(-sin(2.0 * CH_PI * (double)k / (double)OR_CH_M));
+	}
+}
+
+/* 6/5 resampler prototype: Blackman-windowed sinc at 240 kHz, cutoff 18 kHz, 16 taps per phase;
+ * g[p][t] = 6 * proto[6 t + p] (unit DC gain per phase after normalisation) */
+void or_chan_resamp_taps(float *g /* 6*16 */)
+{
+	const int N = OR_RS_L * OR_RS_T;
+	const double fc = 18000.0 / 240000.0;
+	double tmp[OR_RS_L * OR_RS_T];
+	for (int i = 0; i < N; i++) {
+		const double t = (double)i - 0.5 * (double)(N - 1);
+		const double x = (double)i / (double)(N - 1);
+		const double w = 0.42 - 0.5 * cos(2.0 * CH_PI * x) + 0.08 * cos(4.0 * CH_PI * x);
+		const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * CH_PI * fc * t) / (CH_PI * t);
+		tmp[i] = s * w;
+	}
+	for (int p = 0; p < OR_RS_L; p++) {
+		double sum = 0.0;
+		for (int t = 0; t < OR_RS_T; t++) sum += tmp[t * OR_RS_L + p];
+		for (int t = 0; t < OR_RS_T; t++) g[p * OR_RS_T + t] = (float)(tmp[t * OR_RS_L + p] / sum);
+	}
+}
+
+/* in-place radix-2 decimation-in-time FFT, 512 points, bit-reversed load; each butterfly:
+ *   t = b * w  with  t.re = fmaf(-b.im, w.im, b.re*w.re),  t.im = fmaf(b.re, w.im, b.im*w.re);  a' = a + t, b' = a - t */
+void or_fft512(float *re, float *im, const float *tw)
+{
+	for (int i = 0; i < OR_CH_M; i++) {
+		int r = 0;
+		for (int b = 0; b < 9; b++) r |= ((i >> b) & 1) << (8 - b);
+		if (r > i) {
+			float t = re[i]; re[i] = re[r]; re[r] = t;
+			t = im[i]; im[i] = im[r]; im[r] = t;
+		}
+	}
+	for (int s = 1; s <= 9; s++) {
+		const int half = 1 << (s - 1), step = OR_CH_M >> s;
+		for (int g0 = 0; g0 < OR_CH_M; g0 += 2 * half) {
+			for (int j = 0; j < half; j++) {
+				const float wr = tw[2 * (j * step)], wi = tw[2 * (j * step) + 1];
+				const int a = g0 + j, b = a + half;
+				const float tr = fmaf(-im[b], wi, re[b] * wr);
+				const float ti = fmaf(re[b], wi, im[b] * wr);
+				const float ar = re[a], ai = im[a];
+				re[a] = ar + tr; im[a] = ai + ti;
+				re[b] = ar - tr; im[b] = ai - ti;
+			}
+		}
+	}
+}
+
+struct OrChan {
+	float h[OR_CH_L], tw[OR_CH_M], g[OR_RS_L * OR_RS_T];
+	float *hist;                 /* last L-D wideband samples (I,Q) */
+	float iq_last[OR_CH_M][2];   /* per bin: previous 40 kS/s sample */
+	float dhist[OR_CH_M][OR_RS_T];   /* per bin: last 16 discriminator samples (oldest first) */
+};
+
+OrChan *or_chan_new(void)
+{
+	OrChan *c = calloc(1, sizeof(*c));
+	or_chan_proto(c->h);
+	or_chan_twiddles(c->tw);
+	or_chan_resamp_taps(c->g);
+	c->hist = calloc(2 * (OR_CH_L - OR_CH_D), sizeof(float));
+	return c;
+}
+void or_chan_free(OrChan *c) { if (c) { free(c->hist); free(c); } }
+
+/* One block: n_steps*250 wideband samples in, per bin n_steps samples at 40 kS/s (bins: [512][n_steps][2]) and,
+ * if out48 != NULL, n_steps*6/5 real samples at 48 kS/s ([512][n_steps*6/5]); n_steps % 5 == 0. */
+void or_chan_block(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48)
+{
+	const size_t H = OR_CH_L - OR_CH_D, N = n_steps * OR_CH_D;
+	float *buf = malloc(2 * (H + N) * sizeof(float));
+	memcpy(buf, c->hist, 2 * H * sizeof(float));
+	memcpy(buf + 2 * H, iq, 2 * N * sizeof(float));
+	float re[OR_CH_M], im[OR_CH_M];
+	float *bl = bins ? bins : malloc((size_t)OR_CH_M * n_steps * 2 * sizeof(float));
+	for (size_t m = 0; m < n_steps; m++) {
+		const float *x = buf + 2 * m * OR_CH_D;
+		const int shift = (int)((m * OR_CH_D) % OR_CH_M);
+		for (int r = 0; r < OR_CH_M; r++) {
+			float ar = 0.0f, ai = 0.0f;
+			for (int t = 0; t < OR_CH_T; t++) {
+				const int i = r + t * OR_CH_M;
+				ar = fmaf(c->h[i], x[2 * i], ar);
+				ai = fmaf(c->h[i], x[2 * i + 1], ai);
+			}
+			re[(r + shift) & (OR_CH_M - 1)] = ar;
+			im[(r + shift) & (OR_CH_M - 1)] = ai;
+		}
+		or_fft512(re, im, c->tw);
+		for (int k = 0; k < OR_CH_M; k++) {
+			bl[((size_t)k * n_steps + m) * 2] = re[k];
+			bl[((size_t)k * n_steps + m) * 2 + 1] = im[k];
+		}
+	}
+	memcpy(c->hist, buf + 2 * N, 2 * H * sizeof(float));   /* last L-D samples of [hist|block] */
+	free(buf);
+	if (out48) {
+		const size_t n_out = n_steps * OR_RS_L / OR_RS_M;
+		float *d = malloc((OR_RS_T + n_steps) * sizeof(float));
+		for (int k = 0; k < OR_CH_M; k++) {
+			memcpy(d, c->dhist[k], OR_RS_T * sizeof(float));
+			or_discriminate(bl + (size_t)k * n_steps * 2, n_steps, d + OR_RS_T, c->iq_last[k]);
+			for (size_t j = 0; j < n_out; j++) {
+				const size_t i0 = (j * OR_RS_M) / OR_RS_L;
+				const int p = (int)((j * OR_RS_M) % OR_RS_L);
+				float acc = 0.0f;
+				for (int t = 0; t < OR_RS_T; t++) acc = fmaf(c->g[p * OR_RS_T + t], d[OR_RS_T + i0 - t], acc);
+				out48[(size_t)k * n_out + j] = acc;
+			}
+			memcpy(c->dhist[k], d + n_steps, OR_RS_T * sizeof(float));
+		}
+		free(d);
+	}
+	if (!bins) free(bl);
+}

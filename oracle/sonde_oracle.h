@@ -120,6 +120,24 @@ OrDemod   *or_channel_demod(OrChannel *c);
  * nthreads<=1: serial.  Used by bench.py cpu_baseline. */
 size_t     or_batch_run(int type, const float *iq, size_t nch, size_t n, int nthreads, OrFrame *out, size_t cap);
 
+/* ---- wideband front-end (config 4): 512-bin PFB channelizer + discriminator + 6/5 resampler ---- */
+#define OR_CH_FS   10000000.0   /* wideband sample rate */
+#define OR_CH_M    512          /* bins, spacing 19531.25 Hz */
+#define OR_CH_D    250          /* decimation: 40 kS/s per bin */
+#define OR_CH_T    16           /* prototype taps per bin */
+#define OR_CH_L    (OR_CH_M * OR_CH_T)
+#define OR_RS_L    6            /* resampler: up 6 */
+#define OR_RS_M    5            /*            down 5 : 40 kS/s -> 48 kS/s */
+#define OR_RS_T    16           /* taps per resampler phase */
+typedef struct OrChan OrChan;
+void    or_chan_proto(float *h);
+void    or_chan_twiddles(float *tw);
+void    or_chan_resamp_taps(float *g);
+void    or_fft512(float *re, float *im, const float *tw);
+OrChan *or_chan_new(void);
+void    or_chan_free(OrChan *c);
+void    or_chan_block(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48);
+
 /* ---- post-FEC derived values, restating /root/reference/src/decode/decoder.hpp:132-174 ---- */
 float or_dewpt(float temp, float rh);
 float or_altitude_to_pressure(float alt);

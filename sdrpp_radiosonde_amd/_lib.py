@@ -52,6 +52,8 @@ ABI_SYMBOLS = [
     "sonde_last_error", "sonde_version", "sonde_dewpt", "sonde_altitude_to_pressure",
     "sonde_gpx_open", "sonde_gpx_close", "sonde_gpx_start_track", "sonde_gpx_stop_track", "sonde_gpx_add_point",
     "sonde_ptu_open", "sonde_ptu_close", "sonde_ptu_add_point",
+    "sonde_chan_create", "sonde_chan_destroy", "sonde_chan_samples_per_submit", "sonde_chan_submit", "sonde_chan_batch",
+    "sonde_chan_read", "sonde_chan_tables",
 ] + [f"{x}_{fn}" for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1")
      for fn in ("decoder_init", "decoder_deinit", "decode")]
 
@@ -91,6 +93,16 @@ def load() -> C.CDLL:
     L.sonde_dewpt.argtypes = [C.c_float, C.c_float]
     L.sonde_altitude_to_pressure.restype = C.c_float
     L.sonde_altitude_to_pressure.argtypes = [C.c_float]
+    L.sonde_chan_create.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp)]
+    L.sonde_chan_destroy.argtypes = [vp]
+    L.sonde_chan_destroy.restype = None
+    L.sonde_chan_samples_per_submit.argtypes = [vp]
+    L.sonde_chan_samples_per_submit.restype = C.c_uint32
+    L.sonde_chan_submit.argtypes = [vp, vp, C.c_size_t, vp]
+    L.sonde_chan_batch.argtypes = [vp]
+    L.sonde_chan_batch.restype = vp
+    L.sonde_chan_read.argtypes = [vp, vp, vp]
+    L.sonde_chan_tables.argtypes = [vp, vp, vp]
     f = C.c_float
     L.sonde_gpx_open.restype = vp
     L.sonde_gpx_open.argtypes = [C.c_char_p]

@@ -100,6 +100,54 @@ class SondeBatch:
         return dict(t_next=t.value, period=p.value, bias=b.value, amp=a.value, yprev=y.value)
 
 
+class SondeChannelizer:
+    """Wideband front-end (BASELINE config 4): 10 MS/s complex IQ -> 512 bins -> per-bin decode."""
+
+    def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0):
+        self.L = _lib.load()
+        self._types = None
+        tp = None
+        if types is not None:
+            self._types = np.ascontiguousarray(types, dtype=np.uint8)
+            assert self._types.shape == (512,)
+            tp = self._types.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        if self.L.sonde_chan_create(tp, blocks_per_submit, device, C.byref(h)) != 0:
+            raise SondeError(_lib.last_error() or "sonde_chan_create failed")
+        self.h = h
+        self.samples_per_submit = int(self.L.sonde_chan_samples_per_submit(self.h))
+        self.n_steps = self.samples_per_submit // 250
+        self.batch = SondeBatch.__new__(SondeBatch)          # borrowed view of the embedded 512-channel batch
+        self.batch.L = self.L
+        self.batch.h = C.c_void_p(self.L.sonde_chan_batch(self.h))
+        self.batch.n_channels = 512
+        self.batch.close = lambda: None
+
+    def submit(self, iq, stream: int | None = None):
+        assert tuple(iq.shape) == (self.samples_per_submit, 2)
+        self._keep = iq
+        if self.L.sonde_chan_submit(self.h, C.c_void_p(iq.data_ptr()), self.samples_per_submit, C.c_void_p(stream or 0)) != 0:
+            raise SondeError(_lib.last_error() or "sonde_chan_submit failed")
+
+    def frames(self) -> np.ndarray:
+        return SondeBatch.frames(self.batch)
+
+    def read(self):
+        bins = np.zeros((512, self.n_steps, 2), dtype=np.float32)
+        out48 = np.zeros((512, self.n_steps * 6 // 5), dtype=np.float32)
+        if self.L.sonde_chan_read(self.h, bins.ctypes.data_as(C.c_void_p), out48.ctypes.data_as(C.c_void_p)) != 0:
+            raise SondeError("sonde_chan_read failed")
+        return bins, out48
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.batch.h = None
+            self.L.sonde_chan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 def get_taps(sonde_type: int) -> np.ndarray:
     out = np.zeros((32, 32), dtype=np.float32)
     if _lib.load().sonde_get_taps(sonde_type, out.ctypes.data_as(C.c_void_p)) != 0:

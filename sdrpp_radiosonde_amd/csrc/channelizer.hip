@@ -1,0 +1,246 @@
+// channelizer.hip -- wideband front-end (BASELINE config 4):
+//   10 MS/s complex IQ -> 512-bin oversampled polyphase filter bank (decimation 250 -> 40 kS/s per bin)
+//   -> per-bin FM discriminator at 40 kS/s -> real rational resampler 6/5 -> 48 kS/s -> kernel A (real input)
+// i.e. the reference's ordering  VFO channeliser -> dsp::demod::FM -> RationalResampler -> decoder
+// (/root/reference/src/main.cpp:55-60) for all 512 bins at once.  SPEC: DESIGN.md section 3.5; the CPU oracle is
+// oracle/or_chan.c.  A 10 MS/s stream is 80 MB/s: this stage is nowhere near a roofline, the kernels are
+// written for clarity and exact reproducibility (fixed summation orders), not tuned.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "sd_math.h"
+#include "sonde_dev.h"
+#include "../../include/sonde_abi.h"
+
+#define CH_M 512
+#define CH_D 250
+#define CH_T 16
+#define CH_L (CH_M * CH_T)
+#define CH_H (CH_L - CH_D)       // wideband samples of history in front of a block
+#define RS_UP 6
+#define RS_DN 5
+#define RS_TAPS 16
+
+// ---- PFB: one workgroup per output time step m.  Fold 16 taps per bin, circular shift by (m*D mod 512),
+// 512-point radix-2 DIT FFT in LDS (bit-reversed load), one butterfly per thread per stage.
+__global__ __launch_bounds__(256) void sd_pfb_kernel(const float2 *__restrict__ wbuf, const float *__restrict__ h,
+                                                      const float2 *__restrict__ tw, float2 *__restrict__ bins, uint32_t n_steps)
+{
+	__shared__ float s_re[CH_M], s_im[CH_M];
+	const uint32_t m = blockIdx.x;
+	const int tid = threadIdx.x;
+	const float2 *x = wbuf + (size_t)m * CH_D;
+	const uint32_t shift = (m * CH_D) & (CH_M - 1);
+#pragma unroll
+	for (int q = 0; q < 2; q++) {
+		const int r = tid + 256 * q;
+		float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+		for (int t = 0; t < CH_T; t++) {
+			const int i = r + t * CH_M;
+			const float2 v = x[i];
+			const float hv = h[i];
+			ar = __builtin_fmaf(hv, v.x, ar);
+			ai = __builtin_fmaf(hv, v.y, ai);
+		}
+		const uint32_t pos = ((uint32_t)r + shift) & (CH_M - 1);
+		const uint32_t rev = __brev(pos) >> 23;                  // 9-bit reversal
+		s_re[rev] = ar;
+		s_im[rev] = ai;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int st = 1; st <= 9; st++) {
+		const int half = 1 << (st - 1), step = CH_M >> st;
+		const int jj = tid & (half - 1);
+		const int a = ((tid >> (st - 1)) << st) + jj, b = a + half;
+		const float2 w = tw[jj * step];
+		const float br = s_re[b], bi = s_im[b];
+		const float tr = __builtin_fmaf(-bi, w.y, br * w.x);
+		const float ti = __builtin_fmaf(br, w.y, bi * w.x);
+		const float ar = s_re[a], ai = s_im[a];
+		__syncthreads();
+		s_re[a] = ar + tr; s_im[a] = ai + ti;
+		s_re[b] = ar - tr; s_im[b] = ai - ti;
+		__syncthreads();
+	}
+#pragma unroll
+	for (int q = 0; q < 2; q++) {
+		const int k = tid + 256 * q;
+		bins[(size_t)k * n_steps + m] = make_float2(s_re[k], s_im[k]);
+	}
+}
+
+// ---- per bin: discriminator at 40 kS/s + 6/5 polyphase resampler to 48 kS/s.  One workgroup per bin.
+__global__ __launch_bounds__(256) void sd_disc_resamp_kernel(const float2 *__restrict__ bins, uint32_t n_steps,
+                                                              const float *__restrict__ g, float2 *__restrict__ iq_last,
+                                                              float *__restrict__ dhist, float *__restrict__ out48)
+{
+	extern __shared__ float s_d[];            // [RS_TAPS history | n_steps]
+	__shared__ float s_g[RS_UP * RS_TAPS];
+	const uint32_t k = blockIdx.x;
+	const int tid = threadIdx.x;
+	const float2 *x = bins + (size_t)k * n_steps;
+	if (tid < RS_UP * RS_TAPS) s_g[tid] = g[tid];
+	if (tid < RS_TAPS) s_d[tid] = dhist[(size_t)k * RS_TAPS + tid];
+	const float2 first_prev = iq_last[k];
+	for (uint32_t i = tid; i < n_steps; i += 256) {
+		const float2 cur = x[i];
+		const float2 prv = i ? x[i - 1] : first_prev;
+		s_d[RS_TAPS + i] = sd_disc(cur.x, cur.y, prv.x, prv.y);
+	}
+	__syncthreads();
+	const uint32_t n_out = n_steps * RS_UP / RS_DN;
+	for (uint32_t j = tid; j < n_out; j += 256) {
+		const uint32_t i0 = (j * RS_DN) / RS_UP, p = (j * RS_DN) % RS_UP;
+		float acc = 0.0f;
+#pragma unroll
+		for (int t = 0; t < RS_TAPS; t++) acc = __builtin_fmaf(s_g[p * RS_TAPS + t], s_d[RS_TAPS + i0 - t], acc);
+		out48[(size_t)k * n_out + j] = acc;
+	}
+	if (tid < RS_TAPS) dhist[(size_t)k * RS_TAPS + tid] = s_d[n_steps + tid];
+	if (tid == 0) iq_last[k] = x[n_steps - 1];
+}
+
+// ---------------------------------------------------------------- host object
+static thread_local std::string g_cerr;
+extern "C" const char *sonde_last_error(void);
+
+struct SondeChannelizer {
+	int device = 0;
+	uint32_t n_steps = 0;
+	SondeBatch *batch = nullptr;
+	float2 *d_wbuf = nullptr, *d_bins = nullptr, *d_tw = nullptr, *d_iqlast = nullptr;
+	float *d_h = nullptr, *d_g = nullptr, *d_dhist = nullptr, *d_out48 = nullptr;
+};
+
+static void make_tables(std::vector<float> &h, std::vector<float> &tw, std::vector<float> &g)
+{
+	const double PI = 3.14159265358979323846;
+	h.resize(CH_L); tw.resize(CH_M); g.resize(RS_UP * RS_TAPS);
+	{
+		const double fc = 8000.0 / 10000000.0;
+		std::vector<double> tmp(CH_L);
+		double sum = 0.0;
+		for (int i = 0; i < CH_L; i++) {
+			const double t = (double)i - 0.5 * (double)(CH_L - 1);
+			const double x = (double)i / (double)(CH_L - 1);
+			const double w = 0.42 - 0.5 * cos(2.0 * PI * x) + 0.08 * cos(4.0 * PI * x);
+			const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * PI * fc * t) / (PI * t);
+			tmp[i] = s * w;
+			sum += tmp[i];
+		}
+		for (int i = 0; i < CH_L; i++) h[i] = (float)(tmp[i] / sum);
+	}
+	for (int k = 0; k < CH_M / 2; k++) {
+		tw[2 * k] = (float)cos(2.0 * PI * (double)k / (double)CH_M);
+		tw[2 * k + 1] = (float)(-sin(2.0 * PI * (double)k / (double)CH_M));
+	}
+	{
+		const int N = RS_UP * RS_TAPS;
+		const double fc = 18000.0 / 240000.0;
+		std::vector<double> tmp(N);
+		for (int i = 0; i < N; i++) {
+			const double t = (double)i - 0.5 * (double)(N - 1);
+			const double x = (double)i / (double)(N - 1);
+			const double w = 0.42 - 0.5 * cos(2.0 * PI * x) + 0.08 * cos(4.0 * PI * x);
+			const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * PI * fc * t) / (PI * t);
+			tmp[i] = s * w;
+		}
+		for (int p = 0; p < RS_UP; p++) {
+			double sum = 0.0;
+			for (int t = 0; t < RS_TAPS; t++) sum += tmp[t * RS_UP + p];
+			for (int t = 0; t < RS_TAPS; t++) g[p * RS_TAPS + t] = (float)(tmp[t * RS_UP + p] / sum);
+		}
+	}
+}
+
+extern "C" void sonde_chan_destroy(SondeChannelizer *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	sonde_batch_destroy(c->batch);
+	(void)hipFree(c->d_wbuf); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_iqlast);
+	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48);
+	delete c;
+}
+
+extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submit, int device, SondeChannelizer **out)
+{
+	if (!out || blocks_per_submit == 0 || blocks_per_submit > 2) return -1;   // LDS: (16 + 5120 q) floats per bin
+	*out = nullptr;
+	SondeChannelizer *c = new SondeChannelizer;
+	c->device = device;
+	c->n_steps = 5120u * blocks_per_submit;                  // 5120 steps = 1.28 M wideband samples = 6144 samples at 48 kS/s
+	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
+	SondeBatchConfig cfg;
+	memset(&cfg, 0, sizeof(cfg));
+	cfg.n_channels = CH_M;
+	cfg.types = types;
+	cfg.max_samples = n_out;
+	cfg.input_kind = SONDE_INPUT_REAL;
+	cfg.device = device;
+	if (sonde_batch_create(&cfg, &c->batch) != 0) { delete c; return -1; }
+	std::vector<float> h, tw, g;
+	make_tables(h, tw, g);
+	const size_t wn = (size_t)CH_H + (size_t)c->n_steps * CH_D;
+	bool ok = hipMalloc((void **)&c->d_wbuf, wn * sizeof(float2)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_bins, (size_t)CH_M * c->n_steps * sizeof(float2)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_out48, (size_t)CH_M * n_out * sizeof(float)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_h, CH_L * sizeof(float)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_tw, CH_M * sizeof(float)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_g, RS_UP * RS_TAPS * sizeof(float)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_iqlast, CH_M * sizeof(float2)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dhist, CH_M * RS_TAPS * sizeof(float)) == hipSuccess;
+	ok = ok && hipMemset(c->d_wbuf, 0, wn * sizeof(float2)) == hipSuccess && hipMemset(c->d_iqlast, 0, CH_M * sizeof(float2)) == hipSuccess &&
+	     hipMemset(c->d_dhist, 0, CH_M * RS_TAPS * sizeof(float)) == hipSuccess &&
+	     hipMemcpy(c->d_h, h.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(c->d_tw, tw.data(), CH_M * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(c->d_g, g.data(), RS_UP * RS_TAPS * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) { sonde_chan_destroy(c); return -1; }
+	*out = c;
+	return 0;
+}
+
+extern "C" uint32_t sonde_chan_samples_per_submit(const SondeChannelizer *c) { return c ? c->n_steps * CH_D : 0; }
+extern "C" SondeBatch *sonde_chan_batch(SondeChannelizer *c) { return c ? c->batch : nullptr; }
+
+extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t n_samples, void *stream_)
+{
+	if (!c || !iq_dev || n_samples != (size_t)c->n_steps * CH_D) return -1;
+	hipStream_t stream = (hipStream_t)stream_;
+	if (hipSetDevice(c->device) != hipSuccess) return -1;
+	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
+	// [history | block]: the block lands behind the 7942 samples carried from the previous submit
+	if (hipMemcpyAsync(c->d_wbuf + CH_H, iq_dev, n_samples * sizeof(float2), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
+	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps), dim3(256), 0, stream, c->d_wbuf, c->d_h, c->d_tw, c->d_bins, c->n_steps);
+	hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
+	                   c->d_bins, c->n_steps, c->d_g, c->d_iqlast, c->d_dhist, c->d_out48);
+	// roll the history: the last 7942 samples of [history | block] move to the front (regions do not overlap)
+	if (hipMemcpyAsync(c->d_wbuf, c->d_wbuf + n_samples, (size_t)CH_H * sizeof(float2), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
+	if (hipGetLastError() != hipSuccess) return -1;
+	return sonde_batch_submit(c->batch, c->d_out48, n_out, n_out, stream_);
+}
+
+// introspection for the parity tests: copies of the intermediate products of the last submit
+extern "C" int sonde_chan_read(SondeChannelizer *c, float *bins /* [512][n_steps][2] or NULL */, float *out48 /* [512][n_out] or NULL */)
+{
+	if (!c) return -1;
+	if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
+	if (bins && hipMemcpy(bins, c->d_bins, (size_t)CH_M * c->n_steps * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if (out48 && hipMemcpy(out48, c->d_out48, (size_t)CH_M * n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return 0;
+}
+
+extern "C" int sonde_chan_tables(float *h /* 8192 */, float *tw /* 512 */, float *g /* 96 */)
+{
+	std::vector<float> vh, vt, vg;
+	make_tables(vh, vt, vg);
+	if (h) memcpy(h, vh.data(), vh.size() * sizeof(float));
+	if (tw) memcpy(tw, vt.data(), vt.size() * sizeof(float));
+	if (g) memcpy(g, vg.data(), vg.size() * sizeof(float));
+	return 0;
+}

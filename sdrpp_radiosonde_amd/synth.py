@@ -232,11 +232,11 @@ def rs41_bitstreams(seed: int, channels: np.ndarray, nbits: int, extended: bool 
 
 def gfsk_modulate(bits: np.ndarray, n_samples: int, baud: float, *, seed: int = 0, ebn0_db: float = 30.0,
                   h: float = 1.0, bt: float = 0.5, cfo_max_hz: float = 500.0, amp_range=(0.25, 1.0),
-                  device: str | torch.device = "cpu", chunk: int = 256, invert: bool = False):
+                  device: str | torch.device = "cpu", chunk: int = 256, invert: bool = False, fs: float = FS):
     """bits: [C, nbits] -> IQ [C, n_samples, 2] float32.  Per channel: CFO ~ U(-cfo_max, cfo_max),
     timing offset ~ U(0, 1) symbol, amplitude ~ U(amp_range), complex AWGN at Eb/N0."""
     C, nbits = bits.shape
-    sps = FS / baud
+    sps = fs / baud
     assert nbits >= int(n_samples / sps) + 4, "need more bits"
     rng = np.random.Generator(np.random.Philox(key=(seed * 104729 + 5) & 0xFFFFFFFFFFFFFFFF))
     cfo = rng.uniform(-cfo_max_hz, cfo_max_hz, size=C)
@@ -264,7 +264,7 @@ def gfsk_modulate(bits: np.ndarray, n_samples: int, baud: float, *, seed: int = 
             x = u - k.to(torch.float64) - 0.5
             f += a * 0.5 * (torch.erf(k_erf * (x + 0.5)) - torch.erf(k_erf * (x - 0.5)))
         f = f * dev + torch.from_numpy(cfo[c0:c1]).to(device)[:, None]
-        ph = torch.cumsum(f, dim=1) * (2.0 * math.pi / FS)
+        ph = torch.cumsum(f, dim=1) * (2.0 * math.pi / fs)
         a_t = torch.from_numpy(amp[c0:c1]).to(device)[:, None]
         sig = a_t * math.sqrt(sps / (2.0 * 10.0 ** (ebn0_db / 10.0)))
         noise = torch.randn((c1 - c0, n_samples, 2), generator=gen, device=device, dtype=torch.float32)
@@ -526,3 +526,31 @@ def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 
     iq, cfo, tau, amp = gfsk_modulate(chips, n_samples, baud, seed=seed + first_channel + 1000 * sonde_type,
                                       ebn0_db=ebn0_db, device=device, invert=invert, **mod_kw)
     return SynthBatch(iq=iq, frames=frames, bits=chips, cfo_hz=cfo, tau=tau, amp=amp)
+
+
+
+# ================================================================ wideband scene for the channelizer (config 4)
+WB_FS = 10_000_000.0
+WB_BINS = 512
+
+
+def make_wideband_rs41(bins_active, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
+                       device: str | torch.device = "cpu"):
+    """RS41 transmitters at the centres of the given channelizer bins (spacing 19531.25 Hz), summed into one
+    10 MS/s complex stream [n_samples, 2].  Returns (iq, {bin: [(bit offset, frame bytes), ...]})."""
+    bins_active = list(bins_active)
+    baud = 4800.0
+    nbits = int(n_samples * baud / WB_FS) + 16
+    chans = np.array(bins_active)
+    bits, frames = rs41_bitstreams(seed, chans, nbits)
+    total = torch.zeros((n_samples, 2), dtype=torch.float32, device=device)
+    n = torch.arange(n_samples, device=device, dtype=torch.float64)
+    for i, k in enumerate(bins_active):
+        # noise is added once per transmitter at its own Eb/N0 (white over the full 10 MHz)
+        iq, _, _, _ = gfsk_modulate(bits[i: i + 1], n_samples, baud, seed=seed + 31 * i, ebn0_db=ebn0_db, device=device,
+                                    cfo_max_hz=300.0, amp_range=(0.5, 0.9), fs=WB_FS)
+        ph = (2.0 * math.pi * k / WB_BINS) * n
+        c, s_ = torch.cos(ph).to(torch.float32), torch.sin(ph).to(torch.float32)
+        total[:, 0] += iq[0, :, 0] * c - iq[0, :, 1] * s_
+        total[:, 1] += iq[0, :, 0] * s_ + iq[0, :, 1] * c
+    return total, {k: frames[i] for i, k in enumerate(bins_active)}

@@ -70,6 +70,13 @@ def lib():
     L.or_channel_demod.argtypes = [C.c_void_p]
     L.or_batch_run.restype = C.c_size_t
     L.or_batch_run.argtypes = [C.c_int, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+    L.or_chan_new.restype = C.c_void_p
+    L.or_chan_free.argtypes = [C.c_void_p]
+    L.or_chan_block.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, f32p]
+    L.or_chan_proto.argtypes = [f32p]
+    L.or_chan_twiddles.argtypes = [f32p]
+    L.or_chan_resamp_taps.argtypes = [f32p]
+    L.or_fft512.argtypes = [f32p, f32p, f32p]
     L.or_dewpt.restype = C.c_float
     L.or_dewpt.argtypes = [C.c_float, C.c_float]
     L.or_altitude_to_pressure.restype = C.c_float
