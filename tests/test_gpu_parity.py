@@ -115,3 +115,52 @@ def test_host_submit_path(oracle):
     b = SondeBatch(C, n)
     b.submit_host(sb.iq.numpy())
     assert b.frames().tobytes() == oracle.batch_run(0, sb.iq.numpy()).tobytes()
+
+
+def test_degenerate_inputs_match_oracle(oracle):
+    """Edge cases: all-zero IQ, noise only, tiny and huge amplitudes, a dead channel next to live ones,
+    a one-tile submit.  No frames where there is no signal, and bits/state equal the oracle's throughout."""
+    C, n = 6, TILE * 36
+    sb = synth.make_rs41_batch(C, n, seed=44, ebn0_db=24.0)
+    iq = sb.iq.clone()
+    g = torch.Generator().manual_seed(1)
+    iq[0] = 0.0                                                   # silence
+    iq[1] = 0.05 * torch.randn((n, 2), generator=g)               # noise only
+    iq[2] *= 1.0e-6                                               # very weak front-end level
+    iq[3] *= 1.0e4                                                # very hot
+    iq[4, TILE * 10: TILE * 20] = 0.0                             # drop-out in the middle of the stream
+    b = SondeBatch(C, n)
+    b.submit(_dev(iq))
+    got = b.frames()
+    chs = _oracle_channels(oracle, iq.numpy())
+    ref = np.concatenate([ch.frames() for ch in chs])
+    assert got.tobytes() == ref.tobytes()
+    assert not np.isin(got["channel"], [0, 1]).any()             # nothing decoded out of silence or noise
+    assert {2, 3, 5} <= set(got["channel"].tolist())              # level does not matter to an FM receiver
+    for c, ch in enumerate(chs):
+        rb = ch.bits()
+        assert b.nbits(c) == len(rb) and np.array_equal(b.read_bits(c, 0, len(rb)), rb)
+        st, rs = b.state(c), ch.state()
+        assert (st["t_next"], st["period"]) == (rs["t_next"], rs["period"])
+    one = SondeBatch(2, TILE)                                     # smallest legal submit, repeated
+    chs2 = [oracle.Channel(0, c) for c in range(2)]
+    for k in range(12):
+        part = sb.iq[:2, k * TILE: (k + 1) * TILE].contiguous()
+        one.submit(_dev(part))
+        one.sync()
+        for c in range(2):
+            chs2[c].feed(part[c].numpy())
+    for c in range(2):
+        assert one.state(c)["t_next"] == chs2[c].state()["t_next"]
+        assert np.array_equal(one.read_bits(c, 0, one.nbits(c)), chs2[c].bits())
+
+
+def test_argument_errors_are_loud():
+    b = SondeBatch(2, TILE * 4)
+    x = torch.zeros((2, TILE * 8, 2), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(Exception):
+        b.submit(x)                                               # longer than max_samples
+    with pytest.raises(Exception):
+        b.submit(x[:, :1000].contiguous())                        # not a multiple of the tile
+    with pytest.raises(Exception):
+        b.submit(x[:1, : TILE * 4].contiguous())                  # wrong channel count
