@@ -137,7 +137,8 @@ int  sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *framer_ms);
 /* introspection for staged parity tests */
 int      sonde_batch_read_bits(SondeBatch *b, uint32_t channel, uint64_t from, size_t count, uint8_t *out /* one bit per byte */);
 uint64_t sonde_batch_nbits(SondeBatch *b, uint32_t channel);
-int      sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp, float *yprev);
+int      sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp,
+                                float *yprev /* reserved, reads 0 */);
 int      sonde_get_taps(int type, float *out /* 32*32 floats, [phase][tap] */);
 
 /* frame -> SondeData fragments (what one X_decode call sequence yields for this frame).

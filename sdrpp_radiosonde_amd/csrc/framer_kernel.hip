@@ -65,14 +65,6 @@ __device__ __forceinline__ uint8_t gdiv(const FramerTabs &s, uint8_t a, uint8_t 
 	return a ? s.exp[s.log[a] + 255 - s.log[b]] : 0;
 }
 
-// 64 stream bits starting at absolute bit index p (LSB = bit p)
-__device__ __forceinline__ uint64_t window64(const uint32_t *ring, uint32_t mask, uint64_t p)
-{
-	const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
-	const uint64_t lo = (uint64_t)ring[w & mask] | ((uint64_t)ring[(w + 1) & mask] << 32);
-	const uint64_t hi = ring[(w + 2) & mask];
-	return sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
-}
 __device__ __forceinline__ uint8_t byte_at(const uint32_t *ring, uint32_t mask, uint64_t p)
 {
 	const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
@@ -92,6 +84,7 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 		const uint8_t *mj = tb.mulk + 256 * j;
 		const int q = (n + 3) >> 2;                 // quarter length; the top quarter may be shorter
 		uint8_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll 2
 		for (int i = q - 1; i >= 0; i--) {
 			p0 = (uint8_t)(mj[p0] ^ s.cw[c][i]);
 			p1 = (uint8_t)(mj[p1] ^ s.cw[c][q + i]);
@@ -122,6 +115,7 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 		uint8_t Bp = (idx == 1) ? 1 : 0;
 		int L = 0;
 		uint8_t bb = 1;
+#pragma unroll 1
 		for (int r = 0; r < RS_R; r++) {
 			const uint8_t sv = (live && idx <= r && idx <= L && idx < RS_R + 1) ? s.S[h][r - idx] : 0;
 			int t = gmul(tb, lam, sv);
@@ -164,11 +158,13 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 		// ---- Chien search: position i = lane + 64*it
 		int npos = 0;
 		bool fail = false;
+#pragma unroll 1
 		for (int it = 0; it < 4; it++) {
 			const int i = lane + 64 * it;
 			bool root = false;
 			if (i < 255) {
 				uint8_t v = 0;
+#pragma unroll 1
 				for (int k = 0; k <= L; k++)
 					if (lam[k]) v ^= tb.exp[(tb.log[lam[k]] + (255 - i) * k) % 255];
 				root = (v == 0);
@@ -189,6 +185,7 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 		// ---- omega = S*lam mod x^24
 		if (lane < RS_R) {
 			uint8_t v = 0;
+#pragma unroll 1
 			for (int k = 0; k <= lane && k <= L; k++) v ^= gmul(tb, lam[k], s.S[c][lane - k]);
 			s.om[c][lane] = v;
 		}
@@ -201,8 +198,10 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 			p = s.pos[c][lane];
 			const int xi = (255 - p) % 255;
 			uint8_t num = 0, den = 0;
+#pragma unroll 1
 			for (int k = 0; k < RS_R; k++)
 				if (s.om[c][k]) num ^= tb.exp[(tb.log[s.om[c][k]] + xi * k) % 255];
+#pragma unroll 1
 			for (int k = 1; k <= L; k += 2)
 				if (lam[k]) den ^= tb.exp[(tb.log[lam[k]] + xi * (k - 1)) % 255];
 			if (!den) bad = true;

@@ -30,7 +30,7 @@ struct SdChanState {        // demodulator state, one per channel (64 B)
 	int64_t  n0;            // samples consumed
 	uint64_t wpos;          // bits produced
 	int32_t  period;        // Q16
-	float    yprev;
+	float    yprev;         // reserved (0): the Gardner term no longer crosses rounds, SPEC 3.2
 	float    bias;
 	float    amp;
 	float    iq_last[2];    // previous IQ sample (I, Q) of the discriminator
