@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--tiles", type=int, default=96, help="2048-sample tiles per channel per step (96 = 4.096 s)")
-    ap.add_argument("--ebn0", type=float, default=18.0)
+    ap.add_argument("--ebn0", type=float, default=14.0)
     ap.add_argument("--cpu-channels", type=int, default=0, help="channels of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--scatter", action="store_true", help="ingest on rank 0 and scatter IQ shards over RCCL before timing")

@@ -98,13 +98,13 @@ void or_discriminate(const float *iq, size_t n, float *d, float *last)
 /* ---- modem table.  Baud rates: SURVEY.md Appendix B [RECALL]; VFO bandwidths in
  * /root/reference/src/main.hpp:44-52 bound them from above. ---- */
 static const OrModem g_modems[OR_NTYPES] = {
-	{ OR_RS41,   4800.0, 0, 0.65f },  /* RS41: 4800 Bd GFSK, NRZ */
-	{ OR_DFM09,  5000.0, 0, 0.65f },  /* DFM: 2500 bit/s Manchester => 5000 chips/s */
-	{ OR_IMS100, 4800.0, 0, 0.65f },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
-	{ OR_M10,    9600.0, 0, 0.65f },  /* M10/M20: 9600 chips/s Manchester */
-	{ OR_IMET4,  2400.0, 0, 0.65f },  /* placeholders (AFSK sondes) */
-	{ OR_C50,    2400.0, 0, 0.65f },
-	{ OR_MRZN1,  2400.0, 0, 0.65f },
+	{ OR_RS41,   4800.0, 0, 0.65f, 2 },  /* RS41: 4800 Bd GFSK, NRZ */
+	{ OR_DFM09,  5000.0, 0, 0.65f, 2 },  /* DFM: 2500 bit/s Manchester => 5000 chips/s */
+	{ OR_IMS100, 4800.0, 0, 0.65f, 2 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
+	{ OR_M10,    9600.0, 0, 0.65f, 1 },  /* M10/M20: 9600 chips/s Manchester: stays at 48 kS/s (5 samples/chip) */
+	{ OR_IMET4,  2400.0, 0, 0.65f, 2 },  /* placeholders (AFSK sondes) */
+	{ OR_C50,    2400.0, 0, 0.65f, 2 },
+	{ OR_MRZN1,  2400.0, 0, 0.65f, 2 },
 };
 static OrModem g_modem_rt[OR_NTYPES];
 
@@ -113,7 +113,7 @@ const OrModem *or_modem(int type)
 	if (type < 0 || type >= OR_NTYPES) return NULL;
 	if (g_modem_rt[type].period0 == 0) {
 		g_modem_rt[type] = g_modems[type];
-		g_modem_rt[type].period0 = (int)llrint(65536.0 * (double)OR_FS / g_modems[type].baud);
+		g_modem_rt[type].period0 = (int)llrint(65536.0 * ((double)OR_FS / g_modems[type].decim) / g_modems[type].baud);
 	}
 	return &g_modem_rt[type];
 }
@@ -122,18 +122,20 @@ const OrModem *or_modem(int type)
  * each row normalised to unit DC gain.  H[p][j] = f(j - N/2 + p/P). */
 void or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS])
 {
-	const double fc = (double)m->cutoff * m->baud / (double)OR_FS; /* cycles/sample */
+	const int nt = OR_NTAPS / m->decim;      /* taps in use: 16 at the decimated rate, 32 at 48 kS/s (same span in time) */
+	memset(taps, 0, sizeof(float) * OR_NPHASE * OR_NTAPS);
+	const double fc = (double)m->cutoff * m->baud / ((double)OR_FS / m->decim); /* cycles per (decimated) sample */
 	for (int p = 0; p < OR_NPHASE; p++) {
 		double h[OR_NTAPS], sum = 0.0;
-		for (int j = 0; j < OR_NTAPS; j++) {
-			const double t = (double)j - (double)(OR_NTAPS / 2) + (double)p / (double)OR_NPHASE;
-			const double x = (t + (double)(OR_NTAPS / 2)) / (double)OR_NTAPS;
+		for (int j = 0; j < nt; j++) {
+			const double t = (double)j - (double)(nt / 2) + (double)p / (double)OR_NPHASE;
+			const double x = (t + (double)(nt / 2)) / (double)nt;
 			const double w = 0.42 - 0.5 * cos(2.0 * OR_PI_D * x) + 0.08 * cos(4.0 * OR_PI_D * x);
 			const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * OR_PI_D * fc * t) / (OR_PI_D * t);
 			h[j] = s * w;
 			sum += h[j];
 		}
-		for (int j = 0; j < OR_NTAPS; j++) taps[p][j] = (float)(h[j] / sum);
+		for (int j = 0; j < nt; j++) taps[p][j] = (float)(h[j] / sum);
 	}
 }
 
@@ -169,10 +171,11 @@ static inline float interp(const OrDemod *d, int64_t pos)
 	const int64_t n = pos >> 16;
 	const int p = (int)((pos >> 11) & (OR_NPHASE - 1));
 	/* even and odd taps accumulate separately (one v_pk_fma_f32 per tap pair on the GPU) */
+	const int nt = OR_NTAPS / d->m->decim;
 	float acc_e = 0.0f, acc_o = 0.0f;
-	for (int j = 0; j < OR_NTAPS; j += 2) {
-		acc_e = fmaf(d->taps[p][j], d->ring[(n + OR_NTAPS / 2 - j) & (OR_RING - 1)], acc_e);
-		acc_o = fmaf(d->taps[p][j + 1], d->ring[(n + OR_NTAPS / 2 - j - 1) & (OR_RING - 1)], acc_o);
+	for (int j = 0; j < nt; j += 2) {
+		acc_e = fmaf(d->taps[p][j], d->ring[(n + nt / 2 - j) & (OR_RING - 1)], acc_e);
+		acc_o = fmaf(d->taps[p][j + 1], d->ring[(n + nt / 2 - j - 1) & (OR_RING - 1)], acc_o);
 	}
 	return acc_e + acc_o;
 }
@@ -194,7 +197,7 @@ static void push_bit(OrDemod *d, int b)
  * FIR support inside the data when a mid-tile correction moves the instants later. */
 static void run_rounds(OrDemod *d)
 {
-	const int64_t limit = (((d->n0 - 1 - OR_NTAPS / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
+	const int64_t limit = (((d->n0 - 1 - (OR_NTAPS / d->m->decim) / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
 	float y[OR_ROUND_MAX], m[OR_ROUND_MAX];
 	int64_t K_total = (d->t_next <= limit) ? (limit - d->t_next) / d->period + 1 : 0;
 
@@ -256,18 +259,40 @@ static void run_rounds(OrDemod *d)
 	}
 }
 
+/* One 2048-sample input tile at a time.  Stage K0 (SPEC 3.0): sondes whose symbol rate leaves room
+ * (decim = 2: RS41, DFM, iMS-100) are first decimated 2:1 by a two-sample boxcar -- z[m] = x[2m] + x[2m+1]
+ * on IQ, 0.5*(d[2m] + d[2m+1]) on real discriminator input -- so that the discriminator and everything
+ * behind it run at 24 kS/s.  This is the reference's own ordering (the VFO hands dsp::demod::FM a stream
+ * at the channel bandwidth, 10 kS/s for RS41: /root/reference/src/main.cpp:55-57, src/main.hpp:45),
+ * halves the arithmetic per input sample and lowers the FM threshold by narrowing the pre-detection
+ * noise bandwidth.  M10 (9600 chips/s) stays at 48 kS/s. */
 void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 {
-	float tile[OR_TILE];
+	const int dec = d->m->decim, it = OR_TILE / dec;
+	float tile[OR_TILE], z[2 * OR_TILE];
 	for (size_t off = 0; off + OR_TILE <= n; off += OR_TILE) {
 		if (is_iq) {
-			or_discriminate(src + 2 * off, OR_TILE, tile, d->iq_last);
+			const float *x = src + 2 * off;
+			if (dec == 2) {
+				for (int m = 0; m < it; m++) {
+					z[2 * m] = x[4 * m] + x[4 * m + 2];
+					z[2 * m + 1] = x[4 * m + 1] + x[4 * m + 3];
+				}
+				or_discriminate(z, (size_t)it, tile, d->iq_last);
+			} else {
+				or_discriminate(x, (size_t)it, tile, d->iq_last);
+			}
 		} else {
-			memcpy(tile, src + off, sizeof(tile));
+			const float *x = src + off;
+			if (dec == 2) {
+				for (int m = 0; m < it; m++) tile[m] = (x[2 * m] + x[2 * m + 1]) * 0.5f;
+			} else {
+				memcpy(tile, x, sizeof(float) * (size_t)it);
+			}
 		}
-		for (int i = 0; i < OR_TILE; i++)
+		for (int i = 0; i < it; i++)
 			d->ring[(d->n0 + i) & (OR_RING - 1)] = tile[i];
-		d->n0 += OR_TILE;
+		d->n0 += it;
 		run_rounds(d);
 	}
 }

@@ -52,8 +52,9 @@ enum { OR_RS41 = 0, OR_DFM09 = 1, OR_IMS100 = 2, OR_M10 = 3, OR_IMET4 = 4, OR_C5
 typedef struct {
 	int    type;
 	double baud;        /* on-air symbol (chip) rate */
-	int    period0;     /* Q16 samples per symbol = rint(65536*FS/baud) */
+	int    period0;     /* Q16 (internal-rate) samples per symbol = rint(65536*(FS/decim)/baud) */
 	float  cutoff;      /* low-pass cutoff, in units of baud */
+	int    decim;       /* 2: IQ is decimated 2:1 before the discriminator (internal rate 24 kS/s); 1: not */
 } OrModem;
 
 typedef struct {

@@ -31,34 +31,36 @@ extern "C" const char *sonde_version(void) { return "sonde_mi355 0.1 (gfx950)"; 
 // ---------------------------------------------------------------- modem table (SPEC)
 // Symbol (chip) rates: SURVEY.md Appendix B; the VFO bandwidths of /root/reference/src/main.hpp:44-52
 // bound them from above.
-struct ModemDef { double baud; float cutoff; };
+struct ModemDef { double baud; float cutoff; int decim; };
 static const ModemDef k_modems[SONDE_NTYPES] = {
-	{ 4800.0, 0.65f },   // RS41   4800 Bd GFSK NRZ
-	{ 5000.0, 0.65f },   // DFM    2500 bit/s Manchester -> 5000 chips/s
-	{ 4800.0, 0.65f },   // iMS100 2400 bit/s biphase    -> 4800 chips/s
-	{ 9600.0, 0.65f },   // M10    9600 chips/s Manchester
-	{ 2400.0, 0.65f },   // iMet-4  (AFSK, SURVEY 8f-4: not implemented)
-	{ 2400.0, 0.65f },   // SRS-C50 (AFSK, not implemented)
-	{ 2400.0, 0.65f },   // MRZ-N1  (not implemented)
+	{ 4800.0, 0.65f, 2 },   // RS41   4800 Bd GFSK NRZ; IQ decimated 2:1 before the discriminator (SPEC 3.0)
+	{ 5000.0, 0.65f, 2 },   // DFM    2500 bit/s Manchester -> 5000 chips/s
+	{ 4800.0, 0.65f, 2 },   // iMS100 2400 bit/s biphase    -> 4800 chips/s
+	{ 9600.0, 0.65f, 1 },   // M10    9600 chips/s Manchester: stays at 48 kS/s (5 samples per chip)
+	{ 2400.0, 0.65f, 2 },   // iMet-4  (AFSK, SURVEY 8f-4: not implemented)
+	{ 2400.0, 0.65f, 2 },   // SRS-C50 (AFSK, not implemented)
+	{ 2400.0, 0.65f, 2 },   // MRZ-N1  (not implemented)
 };
 
-static int32_t modem_period0(int type) { return (int32_t)llrint(65536.0 * (double)SD_FS / k_modems[type].baud); }
+static int32_t modem_period0(int type) { return (int32_t)llrint(65536.0 * ((double)SD_FS / k_modems[type].decim) / k_modems[type].baud); }
 
 static void make_taps(int type, float *out /* [32][32] */)
 {
 	const double PI = 3.14159265358979323846;
-	const double fc = (double)k_modems[type].cutoff * k_modems[type].baud / (double)SD_FS;
+	const double fc = (double)k_modems[type].cutoff * k_modems[type].baud / ((double)SD_FS / k_modems[type].decim);
+	const int nt = SD_NTAPS / k_modems[type].decim;    // taps in use: 16 at the decimated rate, 32 at 48 kS/s
+	memset(out, 0, sizeof(float) * SD_NPHASE * SD_NTAPS);
 	for (int p = 0; p < SD_NPHASE; p++) {
 		double h[SD_NTAPS], sum = 0.0;
-		for (int j = 0; j < SD_NTAPS; j++) {
-			const double t = (double)j - (double)(SD_NTAPS / 2) + (double)p / (double)SD_NPHASE;
-			const double x = (t + (double)(SD_NTAPS / 2)) / (double)SD_NTAPS;
+		for (int j = 0; j < nt; j++) {
+			const double t = (double)j - (double)(nt / 2) + (double)p / (double)SD_NPHASE;
+			const double x = (t + (double)(nt / 2)) / (double)nt;
 			const double w = 0.42 - 0.5 * cos(2.0 * PI * x) + 0.08 * cos(4.0 * PI * x);
 			const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * PI * fc * t) / (PI * t);
 			h[j] = s * w;
 			sum += h[j];
 		}
-		for (int j = 0; j < SD_NTAPS; j++) out[p * SD_NTAPS + j] = (float)(h[j] / sum);
+		for (int j = 0; j < nt; j++) out[p * SD_NTAPS + j] = (float)(h[j] / sum);
 	}
 }
 
@@ -136,15 +138,14 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	b->device = cfg->device;
 	b->types.assign(cfg->n_channels, SONDE_RS41);
 	if (cfg->types) b->types.assign(cfg->types, cfg->types + cfg->n_channels);
-	int32_t pmin = INT32_MAX;
+	uint64_t max_bits = 0;
 	for (uint32_t c = 0; c < b->n_channels; c++) {
 		const int t = b->types[c];
 		if (t < 0 || t >= SONDE_NTYPES) { delete b; return fail("sonde_batch_create: bad sonde type"); }
 		b->chlist[t].push_back(c);
-		pmin = std::min(pmin, modem_period0(t));
+		const int32_t p = modem_period0(t) - (modem_period0(t) >> 8);      // fastest symbol clock the loop allows
+		max_bits = std::max(max_bits, ((uint64_t)(cfg->max_samples / k_modems[t].decim) << 16) / (uint64_t)p + 2);
 	}
-	pmin -= pmin >> 8;
-	const uint64_t max_bits = ((uint64_t)cfg->max_samples << 16) / (uint64_t)pmin + 2;
 	b->ring_words = pow2ceil((uint32_t)((max_bits + 8 * SONDE_FRAME_MAX + 1024 + 31) / 32));
 	b->max_frames = 2;
 	{	// frames per submit per type: submit bits (at that type's fastest period) / shortest frame of the type, + carry-over
@@ -152,7 +153,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		for (int t = 0; t < SONDE_NTYPES; t++) {
 			if (b->chlist[t].empty()) continue;
 			const int32_t p = modem_period0(t) - (modem_period0(t) >> 8);
-			const uint64_t bits_t = ((uint64_t)cfg->max_samples << 16) / (uint64_t)p + 2;
+			const uint64_t bits_t = ((uint64_t)(cfg->max_samples / k_modems[t].decim) << 16) / (uint64_t)p + 2;
 			b->type_frames[t] = (uint32_t)(bits_t / min_frame_bits[t]) + 2;
 			b->max_frames = std::max(b->max_frames, b->type_frames[t]);
 		}
@@ -189,7 +190,9 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		modems[t].ki = modems[t].kp * (1.0f / 4096.0f);
 		modems[t].pmin = p0 - (p0 >> 8);
 		modems[t].pmax = p0 + (p0 >> 8);
-		modems[t].rounds = ((((int64_t)SD_TILE << 16) / modems[t].pmin) + 2 > SD_ROUND_MAX) ? 2 : 1;
+		modems[t].decim = k_modems[t].decim;
+		modems[t].itile = SD_TILE / k_modems[t].decim;
+		modems[t].rounds = ((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 > SD_ROUND_MAX) ? 2 : 1;
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
 	CHK(hipMemcpy(b->d_modems, modems, sizeof(modems), hipMemcpyHostToDevice));

@@ -64,22 +64,30 @@ __device__ __forceinline__ void store_pair(DemodLds &s, int b, uint32_t i, float
 	s.B[b][SD_LH + i] = d1;
 }
 
+// one sample i of a tile into buffer b
+__device__ __forceinline__ void store_one(DemodLds &s, int b, uint32_t i, float d0)
+{
+	s.A[b][SD_LH + i] = d0;
+	s.B[b][SD_LH + i - 1] = d0;
+}
+
 // y(pos) = (sum_{j even} H[p][j] d[n+16-j]) + (sum_{j odd} H[p][j] d[n+16-j]), each an fmaf chain with j
 // ascending (SPEC 3.2): one v_pk_fma_f32 per tap pair.  The tap rows are stored pair-swapped
 // (T[2i] = H[2i+1], T[2i+1] = H[2i]) so that they line up with the (d[x], d[x+1]) pairs.
 // rel = pos relative to A[0], Q16.
+template <int NT>   // taps in use: 32 at 48 kS/s, 16 at the decimated rate (same span in time)
 __device__ __forceinline__ float interp(const float *A, const float *B, const float *taps, uint32_t rel)
 {
-	const uint32_t top = (rel >> 16) + SD_NTAPS / 2;                    // buffer index of d for j = 0
+	const uint32_t top = (rel >> 16) + NT / 2;                          // buffer index of d for j = 0
 	const float *h = taps + ((rel >> 11) & (SD_NPHASE - 1)) * SD_TAPS_LD;
 	// pair i holds (d[top-1-2i], d[top-2i]); it is 8-byte aligned in A when top is odd, in B otherwise
-	const float *lo = (top & 1u) ? (A + (top - 31u)) : (B + (top - 32u));
+	const float *lo = (top & 1u) ? (A + (top - (NT - 1))) : (B + (top - NT));
 	f32x2 acc = {0.0f, 0.0f};                                           // (odd chain, even chain)
 #pragma unroll
-	for (int q = 0; q < SD_NTAPS / 4; q++) {
+	for (int q = 0; q < NT / 4; q++) {
 		const float4 hv = *reinterpret_cast<const float4 *>(h + 4 * q);
-		const float2 v0 = *reinterpret_cast<const float2 *>(lo + 30 - 4 * q);
-		const float2 v1 = *reinterpret_cast<const float2 *>(lo + 28 - 4 * q);
+		const float2 v0 = *reinterpret_cast<const float2 *>(lo + (NT - 2) - 4 * q);
+		const float2 v1 = *reinterpret_cast<const float2 *>(lo + (NT - 4) - 4 * q);
 		const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
 		const f32x2 d0 = {v0.x, v0.y}, d1 = {v1.x, v1.y};
 		acc = pk_fma(h0, d0, acc);
@@ -113,6 +121,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	SdChanState st = states[ch];
 	const SdModem md = modems[st.type];
 	const int rounds = md.rounds;          // sub-phases (= barriers) per tile: 1, or 2 for M10
+	const int IT = md.itile;               // internal samples per input tile: 1024 after 2:1 decimation, else 2048
+	const bool dec2 = md.decim == 2;
 	const float *taps_g = taps_all + (size_t)st.type * SD_NPHASE * SD_NTAPS;
 	for (int i = tid; i < SD_NPHASE * SD_NTAPS; i += SD_WGT)
 		s.taps[(i >> 5) * SD_TAPS_LD + ((i & 31) ^ 1)] = taps_g[i];     // pair-swapped rows, see interp()
@@ -135,37 +145,61 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
 	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)ch * ch_stride);
 	const float2 *src2 = reinterpret_cast<const float2 *>(src);
-	float4 v[NLD];
-	float2 pv[NLD];                        // IQ: the sample just before each wave's first sample of a load
+	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
+	float2 pa, pb;                         // lane 0: the (decimated) sample just before the wave's first one
 	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);
+	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
+	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
+	// of the same wave at r - 1 (no extra load); only each wave's very first sample needs the float4 before it.
+	const int kw = wave & 3;
+	auto f4_index = [&](int r) { return SD_WG / 4 * (NLD * kw + r) + lane; };      // float4 index inside the tile
 
-	auto load_tile = [&](int tile) {
+	auto load_tile = [&](int tile, float4 (&v)[NLD], float2 &pv) {
 #pragma unroll
-		for (int r = 0; r < NLD; r++) {
-			v[r] = src[(size_t)tile * TILE_F4 + t + SD_WG * r];
-			if (IS_IQ && lane == 0) {
-				const long idx = (long)tile * SD_TILE + 2 * (t + SD_WG * r) - 1;
-				pv[r] = idx >= 0 ? src2[idx] : make_float2(st.iq_last[0], st.iq_last[1]);
+		for (int r = 0; r < NLD; r++) v[r] = src[(size_t)tile * TILE_F4 + f4_index(r)];
+		if (IS_IQ && lane == 0) {
+			const long f4 = (long)tile * TILE_F4 + f4_index(0);
+			if (dec2) {
+				const float4 p4 = f4 > 0 ? src[f4 - 1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				pv = f4 > 0 ? make_float2(p4.x + p4.z, p4.y + p4.w) : make_float2(st.iq_last[0], st.iq_last[1]);
+			} else {
+				pv = f4 > 0 ? src2[2 * f4 - 1] : make_float2(st.iq_last[0], st.iq_last[1]);
 			}
 		}
 	};
-	// K1: d[n] = atan2q(x[n] * conj(x[n-1])) for the lane's 8 samples, straight into buffer b
-	auto k1_tile = [&](int b) {
+	// K0+K1: (2:1 boxcar decimation,) d[n] = atan2q(z[n] * conj(z[n-1])), straight into buffer b
+	auto k1_tile = [&](int b, const float4 (&v)[NLD], const float2 &pv) {
+		float cx = pv.x, cy = pv.y;        // lane 0's predecessor sample; after each load: lane 63's last sample
 #pragma unroll
 		for (int r = 0; r < NLD; r++) {
+			const uint32_t fi = (uint32_t)f4_index(r);
 			if (IS_IQ) {
-				float px = __shfl_up(v[r].z, 1, 64), py = __shfl_up(v[r].w, 1, 64);
-				if (lane == 0) { px = pv[r].x; py = pv[r].y; }
-				const float d0 = sd_disc(v[r].x, v[r].y, px, py);
-				const float d1 = sd_disc(v[r].z, v[r].w, v[r].x, v[r].y);
-				store_pair(s, b, 2u * (uint32_t)(t + SD_WG * r), d0, d1);
+				if (dec2) {
+					// one float4 = two input samples = one decimated sample z, index fi
+					const float zx = v[r].x + v[r].z, zy = v[r].y + v[r].w;
+					float px = __shfl_up(zx, 1, 64), py = __shfl_up(zy, 1, 64);
+					if (lane == 0) { px = cx; py = cy; }
+					store_one(s, b, fi, sd_disc(zx, zy, px, py));
+					cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zx), 63));
+					cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zy), 63));
+				} else {
+					float px = __shfl_up(v[r].z, 1, 64), py = __shfl_up(v[r].w, 1, 64);
+					if (lane == 0) { px = cx; py = cy; }
+					const float d0 = sd_disc(v[r].x, v[r].y, px, py);
+					const float d1 = sd_disc(v[r].z, v[r].w, v[r].x, v[r].y);
+					store_pair(s, b, 2u * fi, d0, d1);
+					cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[r].z), 63));
+					cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[r].w), 63));
+				}
+			} else if (dec2) {
+				// real input: average pairs, 4 inputs -> 2 consecutive decimated samples
+				store_pair(s, b, 2u * fi, (v[r].x + v[r].y) * 0.5f, (v[r].z + v[r].w) * 0.5f);
 			} else {
-				const uint32_t i = 4u * (uint32_t)(t + SD_WG * r);
-				store_pair(s, b, i, v[r].x, v[r].y);
-				store_pair(s, b, i + 2u, v[r].z, v[r].w);
+				store_pair(s, b, 4u * fi, v[r].x, v[r].y);
+				store_pair(s, b, 4u * fi + 2u, v[r].z, v[r].w);
 			}
 		}
-		if (IS_IQ) last_iq = make_float2(v[NLD - 1].z, v[NLD - 1].w);
+		if (IS_IQ) last_iq = make_float2(cx, cy);      // wave 7: the last (decimated) sample of the tile
 	};
 
 	// ================================================================ round role (waves 0-3)
@@ -181,10 +215,15 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	auto round_front = [&](int K, int b, int par) {
 		float y = 0.0f, m = 0.0f;
 		if (t < K) {
-			const int64_t base = (n0 - SD_TILE - SD_LH) << 16;
+			const int64_t base = (n0 - IT - SD_LH) << 16;
 			const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)t * (uint32_t)period;
-			y = interp(s.A[b], s.B[b], s.taps, rel);
-			m = interp(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+			if (dec2) {
+				y = interp<SD_NTAPS / 2>(s.A[b], s.B[b], s.taps, rel);
+				m = interp<SD_NTAPS / 2>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+			} else {
+				y = interp<SD_NTAPS>(s.A[b], s.B[b], s.taps, rel);
+				m = interp<SD_NTAPS>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+			}
 		}
 		const float yprev = __shfl_up(y, 1, 64);
 		const bool act = t < K;
@@ -267,18 +306,27 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// ---- the two roles run separate loops (so that neither carries the other's live registers) with the
 	// same number of s_barriers: one after the prologue, then `rounds` per tile.  is_k is wave-uniform.
 	if (is_k) {
-		load_tile(0);
-		k1_tile(0);
-		if (n_tiles > 1) load_tile(1);
+		load_tile(0, va, pa);
+		if (n_tiles > 1) load_tile(1, vb, pb);
+		k1_tile(0, va, pa);
+		if (n_tiles > 2) load_tile(2, va, pa);
 		__syncthreads();
-		for (int tile = 0; tile < n_tiles; tile++) {
-			const int b = tile & 1;
+		// phase `tile`: tile+1 goes from registers into the other LDS buffer, tile+3 is requested from HBM
+		// (two phases of latency budget); the loop is unrolled by two so the register sets are static
+		for (int tile = 0; tile < n_tiles; tile += 2) {
 			if (tile + 1 < n_tiles) {
-				// history roll: the last 64 samples of tile `tile` in front of tile+1 in the other buffer
-				if (t < SD_LH) s.A[b ^ 1][t] = s.A[b][SD_TILE + t];
-				else if (t < 2 * SD_LH - 1) s.B[b ^ 1][t - SD_LH] = s.B[b][SD_TILE + t - SD_LH];
-				k1_tile(b ^ 1);
-				if (tile + 2 < n_tiles) load_tile(tile + 2);
+				if (t < SD_LH) s.A[1][t] = s.A[0][IT + t];            // history roll into the other buffer
+				else if (t < 2 * SD_LH - 1) s.B[1][t - SD_LH] = s.B[0][IT + t - SD_LH];
+				k1_tile(1, vb, pb);
+				if (tile + 3 < n_tiles) load_tile(tile + 3, vb, pb);
+			}
+			for (int r = 0; r < rounds; r++) __syncthreads();
+			if (tile + 1 >= n_tiles) break;
+			if (tile + 2 < n_tiles) {
+				if (t < SD_LH) s.A[0][t] = s.A[1][IT + t];
+				else if (t < 2 * SD_LH - 1) s.B[0][t - SD_LH] = s.B[1][IT + t - SD_LH];
+				k1_tile(0, va, pa);
+				if (tile + 4 < n_tiles) load_tile(tile + 4, va, pa);
 			}
 			for (int r = 0; r < rounds; r++) __syncthreads();
 		}
@@ -294,11 +342,11 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			for (int r = 0; r < rounds; r++) {
 				const int par = (int)(seq & 1u);                      // slots of the round about to run
 				int K;
-				if (r == 0) n0 += SD_TILE;                            // the tile in buffer b is now counted
+				if (r == 0) n0 += IT;                                 // the tile in buffer b is now counted
 				if (lead) {
 					if (pendK >= 0) round_back(pendK, par ^ 1);       // the previous round's update
 					if (r == 0) {
-						const int64_t limit = (((n0 - 1 - SD_NTAPS / 2 - SD_MARGIN) << 16) | 0xFFFF);
+						const int64_t limit = (((n0 - 1 - (SD_NTAPS / md.decim) / 2 - SD_MARGIN) << 16) | 0xFFFF);
 						K_total = (st.t_next <= limit) ? (int)((uint32_t)(limit - st.t_next) / (uint32_t)st.period) + 1 : 0;
 					}
 					K = K_total > SD_ROUND_MAX ? SD_ROUND_MAX : K_total;
@@ -326,7 +374,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	if (!is_k && lead && pendK >= 0) round_back(pendK, (int)((seq & 1u) ^ 1u));
 	__syncthreads();
 	const int bl = (n_tiles - 1) & 1;
-	if (tid < SD_LH) hist[(size_t)ch * SD_HIST + tid] = s.A[bl][SD_TILE + tid];
+	if (tid < SD_LH) hist[(size_t)ch * SD_HIST + tid] = s.A[bl][IT + tid];
 	if (tid == 0) {
 		st.n0 = n0;
 		if (IS_IQ) { st.iq_last[0] = s.iq_last[0]; st.iq_last[1] = s.iq_last[1]; }

@@ -18,11 +18,13 @@
 #define SD_WG         256
 
 struct SdModem {            // per sonde type, built on the host
-	int32_t period0;        // Q16 samples per symbol
+	int32_t period0;        // Q16 internal-rate samples per symbol
 	float   kp;             // proportional gain, Q16 samples per unit error
 	float   ki;             // integral gain
 	int32_t pmin, pmax;     // period clamp
 	int32_t rounds;         // timing-loop rounds per tile: 1, or 2 when a tile can hold > 256 symbols (M10)
+	int32_t decim;          // 2: IQ decimated 2:1 before the discriminator (internal rate 24 kS/s), 1: not (SPEC 3.0)
+	int32_t itile;          // internal samples per 2048-sample input tile = 2048 / decim
 };
 
 struct SdChanState {        // demodulator state, one per channel (64 B)

@@ -13,8 +13,9 @@ NAMES = {0: "RS41", 1: "DFM09", 2: "iMS100", 3: "M10"}
 
 
 @pytest.mark.parametrize("stype", [1, 3, 2])
-@pytest.mark.parametrize("ebn0", [30.0, 15.0])
-def test_single_type_bit_exact(oracle, stype, ebn0):
+@pytest.mark.parametrize("noisy", [False, True])
+def test_single_type_bit_exact(oracle, stype, noisy):
+    ebn0 = {1: 12.0, 2: 12.5, 3: 15.0}[stype] if noisy else 30.0
     C, n = 12, TILE * 40
     sb = synth.make_batch(stype, C, n, seed=40 + stype, ebn0_db=ebn0, invert=(stype == 1 and ebn0 < 20))
     b = SondeBatch(C, n, types=np.full(C, stype, dtype=np.uint8))

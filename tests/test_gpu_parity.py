@@ -25,7 +25,7 @@ def _oracle_channels(oracle, iq, is_iq=True):
     return chs
 
 
-@pytest.mark.parametrize("ebn0", [30.0, 16.0])
+@pytest.mark.parametrize("ebn0", [30.0, 13.0])
 def test_bits_state_frames_bit_exact(oracle, ebn0):
     C, n = 24, TILE * 60
     sb = synth.make_rs41_batch(C, n, seed=5, ebn0_db=ebn0)
