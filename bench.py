@@ -116,6 +116,14 @@ def main():
     else:
         nfr_total = float(nfr_step)
 
+    # read-only streaming kernel over the same IQ buffer: what this GPU's HBM delivers to a pure read
+    import ctypes
+    from sdrpp_radiosonde_amd import _lib
+    gbs = ctypes.c_float(0.0)
+    if _lib.load().sonde_hbm_read_probe(ctypes.c_void_p(iq.data_ptr()), iq.numel() * 4, 10, ctypes.byref(gbs)) != 0:
+        raise RuntimeError(_lib.last_error())
+    achievable = float(gbs.value)
+
     samples_per_step = C * n * world
     msps = samples_per_step * args.steps / dt / 1e6
     # roofline of the dominant kernel (kernel A): algorithmic bytes = 8 B per complex64 sample read once
@@ -154,6 +162,7 @@ def main():
         "kernel_ms": {"demod": round(demod_ms, 4), "framer_fec": round(framer_ms, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "achievable_read": round(achievable, 1), "frac_of_achievable": round(achieved / achievable, 4),
                      "algorithmic_bytes": alg_bytes, "kernel": "sd_demod_kernel<true>"},
     }
     if scatter_ms is not None:

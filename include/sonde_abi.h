@@ -176,6 +176,10 @@ void  sonde_ptu_close(void *p);
 void  sonde_ptu_add_point(void *p, long t, float temp, float rh, float dewpt, float pressure, float lat, float lon,
                           float alt, float spd, float hdg, float climb, const char *aux);
 
+/* Measurement aid (bench.py): best-of-`reps` bandwidth, in GB/s, of a read-only streaming kernel over a device
+ * buffer -- the HBM read rate this GPU can actually deliver, quoted beside the spec peak. */
+int sonde_hbm_read_probe(const void *d_buf, size_t bytes, int reps, float *gbs_out);
+
 const char *sonde_last_error(void);
 const char *sonde_version(void);
 

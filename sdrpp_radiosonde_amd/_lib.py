@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
     "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_kernel_ms", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_get_taps", "sonde_parse_frame",
-    "sonde_last_error", "sonde_version", "sonde_dewpt", "sonde_altitude_to_pressure",
+    "sonde_last_error", "sonde_version", "sonde_hbm_read_probe", "sonde_dewpt", "sonde_altitude_to_pressure",
     "sonde_gpx_open", "sonde_gpx_close", "sonde_gpx_start_track", "sonde_gpx_stop_track", "sonde_gpx_add_point",
     "sonde_ptu_open", "sonde_ptu_close", "sonde_ptu_add_point",
     "sonde_chan_create", "sonde_chan_destroy", "sonde_chan_samples_per_submit", "sonde_chan_submit", "sonde_chan_batch",
@@ -70,6 +70,8 @@ def load() -> C.CDLL:
                            "(or __graft_entry__.build()); there is no CPU fallback")
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
+    L.sonde_hbm_read_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    L.sonde_hbm_read_probe.restype = C.c_int
     L.sonde_last_error.restype = C.c_char_p
     L.sonde_version.restype = C.c_char_p
     L.sonde_batch_create.argtypes = [C.POINTER(SondeBatchConfig), C.POINTER(vp)]

@@ -411,3 +411,59 @@ extern "C" int sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *
 	if (yprev) *yprev = st.yprev;
 	return 0;
 }
+
+// ---- read-only streaming probe: the HBM read bandwidth this GPU actually delivers, measured in the same
+// process as the bench so that kernel A's GB/s can be quoted against *achievable* as well as against the
+// 8 TB/s spec peak (SURVEY.md section 8d asks for both).  Not on the product path.
+// 8 independent 16-byte loads in flight per lane, grid-stride; the xor keeps the loads alive and the store
+// never happens for real data.
+typedef uint32_t sd_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void sd_read_probe_kernel(const sd_u32x4 *__restrict__ src, size_t n16, uint32_t *sink)
+{
+	const size_t stride = (size_t)gridDim.x * 256;
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	uint32_t acc = 0;
+	for (; i + 7 * stride < n16; i += 8 * stride) {
+		sd_u32x4 v[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+		for (int k = 0; k < 8; k++) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+	}
+	for (; i < n16; i += stride) {
+		const sd_u32x4 v = src[i];
+		acc ^= v.x ^ v.y ^ v.z ^ v.w;
+	}
+	if (acc == 0x5EEDBEEFu) sink[0] = acc;
+}
+
+extern "C" int sonde_hbm_read_probe(const void *d_buf, size_t bytes, int reps, float *gbs_out)
+{
+	if (!d_buf || bytes < 16 || reps < 1 || !gbs_out) return fail("sonde_hbm_read_probe: bad argument");
+	uint32_t *sink = nullptr;
+	HIPCHK(hipMalloc(&sink, 4));
+	hipEvent_t e0, e1;
+	HIPCHK(hipEventCreate(&e0));
+	HIPCHK(hipEventCreate(&e1));
+	const size_t n16 = bytes / 16;
+	float best = 1e30f;
+	for (int grid = 256 * 4; grid <= 256 * 32; grid *= 2) {      // best over a few occupancies
+		sd_read_probe_kernel<<<grid, 256>>>((const sd_u32x4 *)d_buf, n16, sink);   // warm-up
+		for (int r = 0; r < reps; r++) {
+			(void)hipEventRecord(e0, 0);
+			sd_read_probe_kernel<<<grid, 256>>>((const sd_u32x4 *)d_buf, n16, sink);
+			(void)hipEventRecord(e1, 0);
+			(void)hipEventSynchronize(e1);
+			float ms = 0.f;
+			(void)hipEventElapsedTime(&ms, e0, e1);
+			if (ms < best) best = ms;
+		}
+	}
+	const hipError_t err = hipGetLastError();
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	(void)hipFree(sink);
+	if (err != hipSuccess) return fail("sonde_hbm_read_probe", err);
+	*gbs_out = (float)((double)(n16 * 16) / ((double)best * 1e-3) / 1e9);
+	return 0;
+}
