@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--cpu-channels", type=int, default=0, help="channels of the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time spent on the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stride-pad", type=int, default=0, help="experiment: extra samples between channels in HBM")
     ap.add_argument("--scatter", action="store_true", help="ingest on rank 0 and scatter IQ shards over RCCL before timing")
     args = ap.parse_args()
 
@@ -80,6 +81,10 @@ def main():
         del full
     else:
         iq = synth.make_rs41_batch(C, n, seed=1000 + rank, ebn0_db=args.ebn0, device=dev, first_channel=rank * C).iq
+    if args.stride_pad:
+        padded = torch.empty((C, n + args.stride_pad, 2), dtype=torch.float32, device=dev)
+        padded[:, :n] = iq
+        iq = padded[:, :n]
     torch.cuda.synchronize()
 
     batch = SondeBatch(C, n, device=local_rank)
@@ -120,7 +125,7 @@ def main():
     import ctypes
     from sdrpp_radiosonde_amd import _lib
     gbs = ctypes.c_float(0.0)
-    if _lib.load().sonde_hbm_read_probe(ctypes.c_void_p(iq.data_ptr()), iq.numel() * 4, 10, ctypes.byref(gbs)) != 0:
+    if _lib.load().sonde_hbm_read_probe(ctypes.c_void_p(iq.data_ptr()), C * n * 8, 10, ctypes.byref(gbs)) != 0:
         raise RuntimeError(_lib.last_error())
     achievable = float(gbs.value)
 

@@ -16,6 +16,8 @@
 
 #include "sd_math.h"
 
+typedef float sd_f32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float sd_clamp(float v, float lo, float hi)
 {
 	return __builtin_fminf(__builtin_fmaxf(v, lo), hi);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)ch * ch_stride);
 	const float2 *src2 = reinterpret_cast<const float2 *>(src);
 	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
-	float2 pa, pb;                         // lane 0: the (decimated) sample just before the wave's first one
+	float4 pa, pb;                         // the float4 (two input samples) just before the wave's first one
 	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);
 	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
 	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
@@ -154,22 +156,25 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const int kw = wave & 3;
 	auto f4_index = [&](int r) { return SD_WG / 4 * (NLD * kw + r) + lane; };      // float4 index inside the tile
 
-	auto load_tile = [&](int tile, float4 (&v)[NLD], float2 &pv) {
+	auto load_tile = [&](int tile, float4 (&v)[NLD], float4 &pv) {
 #pragma unroll
-		for (int r = 0; r < NLD; r++) v[r] = src[(size_t)tile * TILE_F4 + f4_index(r)];
-		if (IS_IQ && lane == 0) {
-			const long f4 = (long)tile * TILE_F4 + f4_index(0);
-			if (dec2) {
-				const float4 p4 = f4 > 0 ? src[f4 - 1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-				pv = f4 > 0 ? make_float2(p4.x + p4.z, p4.y + p4.w) : make_float2(st.iq_last[0], st.iq_last[1]);
-			} else {
-				pv = f4 > 0 ? src2[2 * f4 - 1] : make_float2(st.iq_last[0], st.iq_last[1]);
-			}
+		for (int r = 0; r < NLD; r++) {                    // read-once data: streaming (nontemporal) loads
+			const sd_f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const sd_f32x4 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
+			v[r] = make_float4(q.x, q.y, q.z, q.w);
+		}
+		if (IS_IQ) {
+			// the float4 just before this wave's first one: a wave-uniform address, so a scalar load (no VGPRs,
+			// not counted by vmcnt); the very first one of the stream stands for the carried sample instead.
+			// -0.0f is the additive identity for every float (+0 and -0 included), so k1_tile needs no case split
+			const long f4 = (long)tile * TILE_F4 + SD_WG / 4 * NLD * kw;
+			if (f4 > 0) pv = src[f4 - 1];
+			else pv = dec2 ? make_float4(st.iq_last[0], st.iq_last[1], -0.0f, -0.0f) : make_float4(0.0f, 0.0f, st.iq_last[0], st.iq_last[1]);
 		}
 	};
 	// K0+K1: (2:1 boxcar decimation,) d[n] = atan2q(z[n] * conj(z[n-1])), straight into buffer b
-	auto k1_tile = [&](int b, const float4 (&v)[NLD], const float2 &pv) {
-		float cx = pv.x, cy = pv.y;        // lane 0's predecessor sample; after each load: lane 63's last sample
+	auto k1_tile = [&](int b, const float4 (&v)[NLD], const float4 &pv) {
+		// lane 0's predecessor (decimated) sample; after each load: lane 63's last sample
+		float cx = dec2 ? pv.x + pv.z : pv.z, cy = dec2 ? pv.y + pv.w : pv.w;
 #pragma unroll
 		for (int r = 0; r < NLD; r++) {
 			const uint32_t fi = (uint32_t)f4_index(r);
