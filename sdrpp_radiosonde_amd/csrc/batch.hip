@@ -259,7 +259,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], stream));
-	HIPCHK(hipMemsetAsync(b->d_counts, 0, b->n_channels * sizeof(uint32_t), stream));
+	// d_counts: zeroed at creation; every sync kernel rewrites the entry of each channel it owns on every submit
 	if (!b->chlist[SONDE_RS41].empty()) {
 		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
 			b->d_states, b->d_fstates, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfmulk, b->d_descs,

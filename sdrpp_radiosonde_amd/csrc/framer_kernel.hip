@@ -1,5 +1,5 @@
 // framer_kernel.hip -- kernels B1/B2: bit ring -> sync search -> de-whitening -> RS(255,231) -> frame records.
-// B1 (sd_sync_rs41_kernel): one 64-lane wave per channel walks the new bits and lists frame starts.
+// B1 (sd_sync_rs41_kernel): one workgroup per channel walks the new bits and lists frame starts.
 // B2 (sd_rsdec_rs41_kernel): one 64-lane wave per listed frame extracts, de-whitens and RS-decodes it,
 //     so the latency-bound GF(2^8) chains of thousands of frames overlap.
 //
@@ -44,7 +44,7 @@ struct FramerTabs {                // shared by the waves of a workgroup
 };
 struct FramerLds {                 // one per wave (= per frame)
 	uint8_t frame[SONDE_FRAME_MAX];
-	uint8_t cw[2][256];
+	alignas(4) uint8_t cw[2][256];
 	uint8_t S[2][RS_R];
 	uint8_t lam[2][RS_R + 2];
 	uint8_t B[2][RS_R + 2];
@@ -72,30 +72,50 @@ __device__ __forceinline__ uint8_t byte_at(const uint32_t *ring, uint32_t mask, 
 	return (uint8_t)(lo >> sh);
 }
 
-// Decode both codewords held in s.cw[c][0..n).  Wave-synchronous; 64 lanes.
+// One syndrome S_j = r(alpha^j) of the codeword cw[0..4Q) (zero-padded, Q a multiple of 4), as four interleaved
+// Horner chains.  The kernel is bound by the CU's one LDS pipe, so the codeword is read a word at a time (one
+// ds_read_b32 per chain per four steps; the byte select folds into the xor) and only the multiplication
+// table costs one LDS access per step.
+template <int Q>
+__device__ __forceinline__ uint32_t syndrome4(const FramerTabs &tb, const uint8_t *cw, int j)
+{
+	static_assert(Q % 4 == 0, "chain length must be a whole number of words");
+	const uint8_t *mj = tb.mulk + 256 * j;      // mj[v] = v * alpha^j
+	const uint32_t *cww = reinterpret_cast<const uint32_t *>(cw);
+	uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll 1
+	for (int w = Q / 4 - 1; w >= 0; w--) {
+		const uint32_t w0 = cww[w], w1 = cww[Q / 4 + w], w2 = cww[2 * (Q / 4) + w], w3 = cww[3 * (Q / 4) + w];
+#pragma unroll
+		for (int b = 3; b >= 0; b--) {
+			p0 = (uint32_t)mj[p0] ^ ((w0 >> (8 * b)) & 0xFFu);
+			p1 = (uint32_t)mj[p1] ^ ((w1 >> (8 * b)) & 0xFFu);
+			p2 = (uint32_t)mj[p2] ^ ((w2 >> (8 * b)) & 0xFFu);
+			p3 = (uint32_t)mj[p3] ^ ((w3 >> (8 * b)) & 0xFFu);
+		}
+	}
+	const uint8_t A = tb.exp[(j * Q) % 255];
+	uint32_t syn = (uint32_t)gmul(tb, (uint8_t)p3, A) ^ p2;
+	syn = (uint32_t)gmul(tb, (uint8_t)syn, A) ^ p1;
+	syn = (uint32_t)gmul(tb, (uint8_t)syn, A) ^ p0;
+	return syn;
+}
+
+// Decode both codewords held in s.cw[c][0..n) (zero-padded to 256).  Wave-synchronous; 64 lanes.
 __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int lane)
 {
 	// ---- syndromes: lane = 24*c + j, Horner from the highest position down
-	uint8_t syn = 0;
+	uint32_t syn = 0;
 	if (lane < 2 * RS_R) {
 		const int c = lane / RS_R, j = lane % RS_R;
 		// Horner in four independent quarter-chains (4x shorter dependent LDS-lookup chain), then
-		// S = ((S3*A + S2)*A + S1)*A + S0 with A = alpha^(j*q): same field element as one long chain
-		const uint8_t *mj = tb.mulk + 256 * j;
-		const int q = (n + 3) >> 2;                 // quarter length; the top quarter may be shorter
-		uint8_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll 2
-		for (int i = q - 1; i >= 0; i--) {
-			p0 = (uint8_t)(mj[p0] ^ s.cw[c][i]);
-			p1 = (uint8_t)(mj[p1] ^ s.cw[c][q + i]);
-			p2 = (uint8_t)(mj[p2] ^ s.cw[c][2 * q + i]);
-			p3 = (uint8_t)(mj[p3] ^ (3 * q + i < n ? s.cw[c][3 * q + i] : 0));
-		}
-		const uint8_t A = tb.exp[(j * q) % 255];
-		syn = (uint8_t)(gmul(tb, p3, A) ^ p2);
-		syn = (uint8_t)(gmul(tb, syn, A) ^ p1);
-		syn = (uint8_t)(gmul(tb, syn, A) ^ p0);
-		s.S[c][j] = syn;
+		// S = ((S3*A + S2)*A + S1)*A + S0 with A = alpha^(j*q): same field element as one long chain.
+		// The codeword buffer is zero-padded to 256 and 4q <= 256, so no chain needs a bounds test; each
+		// chain keeps "table base + value" in one register, so a step is two LDS byte reads and one
+		// xor-add.  The two RS41 frame lengths get their own instantiation (constant chain offsets).
+		if (n == RS_R + (RS41_LEN_STD - 56) / 2) syn = syndrome4<((RS_R + (RS41_LEN_STD - 56) / 2 + 15) / 16) * 4>(tb, s.cw[c], j);
+		else syn = syndrome4<64>(tb, s.cw[c], j);
+		s.S[c][j] = (uint8_t)syn;
 	}
 	const unsigned long long nzm = __ballot(syn != 0);
 	if (lane < 2) {
@@ -103,7 +123,8 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 		s.status[lane] = nz ? 1 : 0;
 		s.L[lane] = 0;
 	}
-		WAVE_SYNC();
+	WAVE_SYNC();
+	if (nzm == 0ull) return;                    // both codewords clean (wave-uniform): nothing to correct
 
 	// ---- Berlekamp-Massey, one coefficient per lane: half-wave h handles codeword h, lane idx = lane&31
 	// holds lam[idx] and Bp[idx] where Bp = x^m * B.  Same recurrence as the sequential form
@@ -227,41 +248,53 @@ struct SdFrameDesc {            // one frame located by B1, decoded by B2
 #define RS41_SYNC_HI 0xF8129622u
 
 // ---------------------------------------------------------------- B1: sync search
-__global__ __launch_bounds__(64) void sd_sync_rs41_kernel(
+// One 256-thread workgroup per channel.  The channel's bit ring is staged in LDS; a search step covers the 2048
+// bit positions of 64 ring words, thread t testing the 8 positions  8*(t&3) .. 8*(t&3)+7  of word t>>2, so that
+// position order = thread order and "the earliest hit wins" is: lowest wave with a hit, lowest lane in it,
+// lowest offset in that lane.  The frame bookkeeping that follows a hit is replicated in every thread (the
+// state is tiny), so all control flow is workgroup-uniform and one s_barrier per search step is enough
+// (the per-wave results are double-buffered by step parity).
+#define B1_WAVES 4
+__global__ __launch_bounds__(64 * B1_WAVES) void sd_sync_rs41_kernel(
 	const SdChanState *__restrict__ states, SdFramerState *__restrict__ fstates,
 	const uint32_t *__restrict__ bitring, uint32_t ring_words,
 	SdFrameDesc *__restrict__ descs, uint32_t *__restrict__ counts, uint32_t max_frames,
 	const uint32_t *__restrict__ chlist)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_ring[];   // the channel's whole bit ring
-	const int lane = threadIdx.x;
+	__shared__ int s_hit[2][B1_WAVES];       // [step parity][wave]: (bit offset inside the 2048-block) << 8 | hd, or -1
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
 	const uint32_t ch = chlist ? chlist[blockIdx.x] : blockIdx.x;
 	const uint32_t mask = ring_words - 1;
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(bitring + (size_t)ch * ring_words);
 		uint4 *dst = reinterpret_cast<uint4 *>(s_ring);
-		for (uint32_t i = lane; i < ring_words / 4; i += 64) dst[i] = src[i];
+		for (uint32_t i = tid; i < ring_words / 4; i += 64 * B1_WAVES) dst[i] = src[i];
 	}
 	const uint64_t wpos = states[ch].wpos;
 	SdFramerState fs = fstates[ch];
 	uint32_t nout = 0;
+	int par = 0;
 	__syncthreads();
 
 	for (;;) {
 		if (!fs.collecting) {
 			bool found = false;
 			while (fs.rpos + 64 <= wpos) {
-				// lane l owns the 32 positions of ring word (rpos>>5)+l
-				const uint64_t pos0 = (fs.rpos & ~31ull) + 32ull * (uint64_t)lane;
+				const uint64_t blk = fs.rpos & ~31ull;
+				const uint64_t pos0 = blk + 32ull * (uint64_t)(tid >> 2);
 				const uint32_t wi = (uint32_t)(pos0 >> 5);
 				const uint32_t w0 = s_ring[wi & mask], w1 = s_ring[(wi + 1) & mask], w2 = s_ring[(wi + 2) & mask];
 				// valid offsets s: pos0+s >= rpos and pos0+s+64 <= wpos
 				const int s_lo = pos0 >= fs.rpos ? 0 : (int)(fs.rpos - pos0);
 				const int64_t room = (int64_t)(wpos - 64) - (int64_t)pos0;
 				const int s_hi = room < 0 ? -1 : (room > 31 ? 31 : (int)room);
+				const int sub = 8 * (tid & 3);
 				int first = 64, hd_first = 0;
-#pragma unroll 4
-				for (int sft = 31; sft >= 0; sft--) {
+#pragma unroll
+				for (int q = 7; q >= 0; q--) {
+					const int sft = sub + q;
 					const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sft);
 					const uint32_t c = __popc(lo ^ RS41_SYNC_LO);
 					// necessary condition on the low half: c <= THR or c >= 32-THR
@@ -272,17 +305,27 @@ __global__ __launch_bounds__(64) void sd_sync_rs41_kernel(
 					}
 				}
 				const unsigned long long hm = __ballot(first < 64);
+				if (lane == 0) s_hit[par][wave] = -1;
 				if (hm) {
 					const int fl = __ffsll((long long)hm) - 1;
-					const int sf = __shfl(first, fl, 64);
-					const int hd1 = __shfl(hd_first, fl, 64);
-					fs.fstart = (fs.rpos & ~31ull) + 32ull * (uint64_t)fl + (uint64_t)sf;
-					fs.inv = hd1 >= 64 - RS41_SYNC_THR;
+					if (lane == fl) s_hit[par][wave] = ((32 * (tid >> 2) + first) << 8) | hd_first;
+				}
+				__syncthreads();
+				int hit = -1;
+#pragma unroll
+				for (int w = B1_WAVES - 1; w >= 0; w--) {
+					const int hw = s_hit[par][w];
+					if (hw >= 0) hit = hw;
+				}
+				par ^= 1;
+				if (hit >= 0) {
+					fs.fstart = blk + (uint64_t)(hit >> 8);
+					fs.inv = (hit & 0xFF) >= 64 - RS41_SYNC_THR;
 					fs.collecting = 1;
 					found = true;
 					break;
 				}
-				uint64_t next = (fs.rpos & ~31ull) + 32ull * 64ull;
+				uint64_t next = blk + 32ull * 64ull;
 				if (next > wpos - 63) next = wpos - 63;
 				fs.rpos = next;
 			}
@@ -294,7 +337,7 @@ __global__ __launch_bounds__(64) void sd_sync_rs41_kernel(
 		const bool ext = __popc(tb ^ 0xF0u) < __popc(tb ^ 0x0Fu);
 		const int flen = ext ? RS41_LEN_EXT : RS41_LEN_STD;
 		if (wpos < fs.fstart + 8 * (uint64_t)flen) break;
-		if (nout < max_frames && lane == 0) {
+		if (nout < max_frames && tid == 0) {
 			SdFrameDesc d;
 			d.fstart = fs.fstart; d.flen = flen; d.inv = fs.inv;
 			descs[(size_t)ch * max_frames + nout] = d;
@@ -303,7 +346,7 @@ __global__ __launch_bounds__(64) void sd_sync_rs41_kernel(
 		fs.rpos = fs.fstart + 8 * (uint64_t)flen;
 		fs.collecting = 0;
 	}
-	if (lane == 0) {
+	if (tid == 0) {
 		fstates[ch] = fs;
 		counts[ch] = nout;
 	}
@@ -392,7 +435,7 @@ void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,
 	const uint8_t *gf_exp, const uint8_t *gf_log, const uint8_t *gf_mulk, void *descs,
 	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist)
 {
-	hipLaunchKernelGGL(sd_sync_rs41_kernel, dim3(n_list), dim3(64), ring_words * sizeof(uint32_t), stream,
+	hipLaunchKernelGGL(sd_sync_rs41_kernel, dim3(n_list), dim3(64 * B1_WAVES), ring_words * sizeof(uint32_t), stream,
 		states, fstates, bitring, ring_words, (SdFrameDesc *)descs, counts, max_frames, chlist);
 	hipLaunchKernelGGL(sd_rsdec_rs41_kernel, dim3((grid_frames + B2_WAVES - 1) / B2_WAVES, n_list), dim3(64 * B2_WAVES), 0, stream,
 		bitring, ring_words, gf_exp, gf_log, gf_mulk, (const SdFrameDesc *)descs, counts, max_frames, frames, chlist);
