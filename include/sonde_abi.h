@@ -145,6 +145,18 @@ int      sonde_get_taps(int type, float *out /* 32*32 floats, [phase][tap] */);
  * Returns number of fragments written (<= cap). */
 int  sonde_parse_frame(const SondeFrame *f, SondeData *out, int cap);
 
+/* The same with per-channel memory: RS41 temperature/humidity need the calibration table that arrives 16 bytes per
+ * frame (51 frames), DFM positions arrive over three frames.  One handle per channel, frames fed in order. */
+typedef struct SondeParserHandle SondeParserHandle;
+SondeParserHandle *sonde_parser_create(int sonde_type);
+int  sonde_parser_feed(SondeParserHandle *p, const SondeFrame *f, SondeData *out, int cap);
+void sonde_parser_destroy(SondeParserHandle *p);
+
+/* RS41 sensor conversions behind fragment.temp / fragment.rh (decoder.hpp:87-88; bodies in the absent sondedump):
+ * counts f between the reference counts f1 < f2, calibration words from the sonde's table. */
+float sonde_rs41_temp(uint32_t f, uint32_t f1, uint32_t f2, float rf1, float rf2, const float co[3], const float cal[3]);
+float sonde_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float temp);
+
 /* ------------------------------------------------------------------ wideband front-end (BASELINE config 4)
  * 10 MS/s complex IQ -> 512-bin polyphase channelizer (19531.25 Hz spacing, 40 kS/s per bin) -> per-bin FM
  * discriminator -> 6/5 rational resampler -> 48 kS/s -> the decoder of the bin's sonde type: the reference's

@@ -48,3 +48,28 @@ float or_altitude_to_pressure(float alt)
 	}
 	return (float)(1e-2 * l->Pb * expf(-g0 * M * (alt - l->hb) / (R_star * l->Tb)));
 }
+
+/* RS41 sensor conversions (public RS41 decoder formulas, SURVEY.md Appendix B.2 [RECALL]; the reference only
+ * reads the results, /root/reference/src/decode/decoder.hpp:87-88).  Single precision, one operation per operator. */
+float or_rs41_temp(uint32_t f, uint32_t f1, uint32_t f2, float rf1, float rf2, const float *co, const float *cal)
+{
+	const float ff = (float)f, ff1 = (float)f1, ff2 = (float)f2;
+	const float gain = (ff2 - ff1) / (rf2 - rf1);
+	const float ofs = (ff1 * rf2 - ff2 * rf1) / (ff2 - ff1);
+	const float rc = ff / gain - ofs;
+	const float r = rc * cal[0];
+	return (co[0] + co[1] * r + co[2] * r * r + cal[1]) * (1.0f + cal[2]);
+}
+
+float or_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float T)
+{
+	const float a0 = 7.5f, a1 = 350.0f / calh0;
+	const float fh = ((float)f - (float)f1) / ((float)f2 - (float)f1);
+	float rh = 100.0f * (a1 * fh - a0);
+	rh = rh - T / 5.5f;
+	if (T < -25.0f) rh = rh * (1.0f + (-25.0f - T) / 90.0f);
+	if (rh < 0.0f) rh = 0.0f;
+	if (rh > 100.0f) rh = 100.0f;
+	if (T < -273.0f) rh = -1.0f;
+	return rh;
+}

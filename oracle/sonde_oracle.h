@@ -142,6 +142,8 @@ void    or_chan_block(OrChan *c, const float *iq, size_t n_steps, float *bins, f
 /* ---- post-FEC derived values, restating /root/reference/src/decode/decoder.hpp:132-174 ---- */
 float or_dewpt(float temp, float rh);
 float or_altitude_to_pressure(float alt);
+float or_rs41_temp(uint32_t f, uint32_t f1, uint32_t f2, float rf1, float rf2, const float *co, const float *cal);
+float or_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float T);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,38 @@ static inline uint32_t rd_u16(const uint8_t *p) { return (uint32_t)p[0] | ((uint
 static inline uint32_t rd_u32(const uint8_t *p) { return rd_u16(p) | (rd_u16(p + 2) << 16); }
 static inline int32_t rd_i32(const uint8_t *p) { return (int32_t)rd_u32(p); }
 static inline int16_t rd_i16(const uint8_t *p) { return (int16_t)rd_u16(p); }
+static inline uint32_t rd_u24(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+static inline float rd_f32(const uint8_t *p) { const uint32_t u = rd_u32(p); float f; memcpy(&f, &u, 4); return f; }
+
+// ---- RS41 PTU conversions.  The sensor maths live in the absent sondedump submodule (the reference reads only
+// fragment.temp / .rh / .pressure, /root/reference/src/decode/decoder.hpp:84-91); these are the formulas of the
+// public RS41 decoders ([RECALL]): the temperature sensor is a resistance measured as a
+// frequency count between two reference resistors Rf1, Rf2; R -> T by the calibration polynomial.
+// Single-precision throughout, one IEEE operation per written operator (-ffp-contract=off): the oracle
+// (oracle/or_physics.c) computes the same bits.
+extern "C" float sonde_rs41_temp(uint32_t f, uint32_t f1, uint32_t f2, float rf1, float rf2, const float *co, const float *cal)
+{
+	const float ff = (float)f, ff1 = (float)f1, ff2 = (float)f2;
+	const float g = (ff2 - ff1) / (rf2 - rf1);                 // counts per ohm
+	const float Rb = (ff1 * rf2 - ff2 * rf1) / (ff2 - ff1);    // offset, ohm
+	const float Rc = ff / g - Rb;
+	const float R = Rc * cal[0];
+	return (co[0] + co[1] * R + co[2] * R * R + cal[1]) * (1.0f + cal[2]);
+}
+
+// Capacitive humidity sensor between two reference capacitors, empirical temperature compensation.
+extern "C" float sonde_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float T)
+{
+	const float a0 = 7.5f, a1 = 350.0f / calh0;
+	const float fh = ((float)f - (float)f1) / ((float)f2 - (float)f1);
+	float rh = 100.0f * (a1 * fh - a0);
+	rh = rh - T / 5.5f;
+	if (T < -25.0f) rh = rh * (1.0f + (-25.0f - T) / 90.0f);
+	if (rh < 0.0f) rh = 0.0f;
+	if (rh > 100.0f) rh = 100.0f;
+	if (T < -273.0f) rh = -1.0f;
+	return rh;
+}
 
 // WGS84 ECEF (metres) -> geodetic latitude/longitude (degrees) and height (metres)
 static void ecef_to_lla(double x, double y, double z, double *lat, double *lon, double *alt)
@@ -90,11 +122,28 @@ void SondeParser::feed_rs41(const SondeFrame &f, std::vector<SondeData> &out)
 			sd.climb = (float)vu;
 			break;
 		}
-		case 0x7A: { // measurements: calibration progress only (PTU physics: DESIGN.md "next")
+		case 0x7A: { // measurements: 12 x 24-bit counts (temperature, humidity, humidity-sensor temperature,
+			// pressure; each: sensor, reference 1, reference 2), converted with the calibration memory that the
+			// 0x79 blocks deliver 16 bytes at a time: Rf1 @0x3D, Rf2 @0x41, co1[3] @0x4D, calT1[3] @0x59, calH @0x75
+			if (len < 36) break;
 			int have = 0;
 			for (int i = 0; i < 51; i++) have += (int)((m_calib_mask >> i) & 1);
-			sd.fields = 0;   // no DATA_PTU until the calibrated conversion lands
 			sd.calib_percent = 100.0f * (float)have / 51.0f;
+			const uint64_t need = (1ull << 3) | (1ull << 4) | (1ull << 5) | (1ull << 6) | (1ull << 7);
+			if ((m_calib_mask & need) != need) break;
+			uint32_t m[12];
+			for (int i = 0; i < 12; i++) m[i] = rd_u24(body + 3 * i);
+			const float rf1 = rd_f32(m_calib + 0x3D), rf2 = rd_f32(m_calib + 0x41);
+			float co1[3], calT1[3];
+			for (int i = 0; i < 3; i++) { co1[i] = rd_f32(m_calib + 0x4D + 4 * i); calT1[i] = rd_f32(m_calib + 0x59 + 4 * i); }
+			const float calh0 = rd_f32(m_calib + 0x75);
+			if (m[2] <= m[1] || m[5] <= m[4] || !(rf2 > rf1) || !(calh0 > 0.0f)) break;
+			const float T = sonde_rs41_temp(m[0], m[1], m[2], rf1, rf2, co1, calT1);
+			if (!(T > -273.0f && T < 200.0f)) break;
+			sd.fields = DATA_PTU;
+			sd.temp = T;
+			sd.rh = sonde_rs41_rh(m[3], m[4], m[5], calh0, T);
+			sd.pressure = 0.0f;      // RS41-SG has no pressure sensor: the caller falls back to the ISA model (decoder.hpp:108-110)
 			break;
 		}
 		default:
@@ -203,6 +252,21 @@ void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
 	case SONDE_M10: feed_m10(f, out); break;
 	default: break;   // iMS-100: frames are delivered, field layout not implemented
 	}
+}
+
+// Stateful parser handle: what a host keeps per channel (RS41 calibration and DFM date/position arrive
+// spread over many frames).
+struct SondeParserHandle { SondeParser p; explicit SondeParserHandle(int t) : p(t) {} };
+extern "C" SondeParserHandle *sonde_parser_create(int type) { return new SondeParserHandle(type); }
+extern "C" void sonde_parser_destroy(SondeParserHandle *h) { delete h; }
+extern "C" int sonde_parser_feed(SondeParserHandle *h, const SondeFrame *f, SondeData *out, int cap)
+{
+	if (!h || !f || !out || cap <= 0) return 0;
+	std::vector<SondeData> v;
+	h->p.feed(*f, v);
+	int n = 0;
+	for (; n < (int)v.size() && n < cap; n++) out[n] = v[n];
+	return n;
 }
 
 extern "C" int sonde_parse_frame(const SondeFrame *f, SondeData *out, int cap)

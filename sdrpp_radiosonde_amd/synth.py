@@ -103,6 +103,48 @@ def _put_le(buf: np.ndarray, off: int, val: np.ndarray, nbytes: int) -> None:
         buf[:, off + b] = (v >> (8 * b)) & 0xFF
 
 
+# ---- RS41 sensor model for the generator (inverse of the parser's conversion; values of a typical RS41-SG)
+RS41_RF1, RS41_RF2 = 750.0, 1100.0
+RS41_CO1 = (-243.911, 0.187654, 8.2e-06)
+RS41_CALT1 = (1.0, 0.0, 0.0)
+RS41_CALH0 = 45.0
+RS41_F1, RS41_F2 = 133000, 190000           # reference counts (temperature and humidity channels alike)
+
+
+def rs41_calibration_memory(channel: int) -> np.ndarray:
+    """The 816-byte calibration table of a sonde (51 fragments of 16 bytes); only the words the PTU
+    conversion reads are meaningful, the rest is a channel-dependent pattern."""
+    mem = ((np.arange(51 * 16) * 37 + 11 * (channel % 251)) & 0xFF).astype(np.uint8)
+    def putf(off, vals):
+        mem[off: off + 4 * len(vals)] = np.frombuffer(np.asarray(vals, dtype="<f4").tobytes(), dtype=np.uint8)
+    putf(0x3D, [RS41_RF1]); putf(0x41, [RS41_RF2])
+    putf(0x4D, RS41_CO1); putf(0x59, RS41_CALT1)
+    putf(0x75, [RS41_CALH0, 0.0])
+    putf(0x125, RS41_CO1); putf(0x131, RS41_CALT1)
+    return mem
+
+
+def rs41_true_ptu(channel_ids, frame_idx):
+    """Temperature (deg C) and relative humidity (%) the generator encodes for (channel, frame)."""
+    alt = 1000.0 + 5.0 * np.asarray(frame_idx, dtype=np.float64)
+    T = 15.0 - 0.0065 * alt - 0.01 * (np.asarray(channel_ids) % 100)
+    RH = 30.0 + 40.0 * np.exp(-alt / 8000.0)
+    return T, RH
+
+
+def rs41_ptu_counts(T, RH):
+    """Sensor counts that the conversion of sonde_rs41_temp / sonde_rs41_rh maps back to (T, RH)."""
+    p0, p1, p2 = RS41_CO1
+    R = (-p1 + np.sqrt(p1 * p1 - 4.0 * p2 * (p0 - T))) / (2.0 * p2)        # T = p0 + p1 R + p2 R^2
+    g = (RS41_F2 - RS41_F1) / (RS41_RF2 - RS41_RF1)
+    Rb = (RS41_F1 * RS41_RF2 - RS41_F2 * RS41_RF1) / (RS41_F2 - RS41_F1)
+    fT = np.rint((R + Rb) * g).astype(np.int64)
+    rh_raw = RH + T / 5.5                                                  # undo the temperature term (T >= -25)
+    fh = (rh_raw / 100.0 + 7.5) / (350.0 / RS41_CALH0)
+    fH = np.rint(RS41_F1 + fh * (RS41_F2 - RS41_F1)).astype(np.int64)
+    return fT, fH
+
+
 def rs41_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray, extended: bool = False) -> np.ndarray:
     """Return unscrambled RS41 frames [F, len] (uint8) for the (channel, frame number) pairs.
 
@@ -139,6 +181,17 @@ def rs41_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray,
             for i in range(F):
                 body[i, 2:10] = np.frombuffer(("S%07d" % (int(channel_ids[i]) % 10000000)).encode(), dtype=np.uint8)
             body[:, 23] = (seq % 51).astype(np.uint8)  # calibration fragment index
+            for i in range(F):
+                k = int(seq[i] % 51)
+                body[i, 24:40] = rs41_calibration_memory(int(channel_ids[i]))[16 * k: 16 * k + 16]
+        elif stype == 0x7A:  # measurements: 12 x 24-bit counts
+            T, RH = rs41_true_ptu(channel_ids, frame_idx)
+            fT, fH = rs41_ptu_counts(T, RH)
+            for k, v in enumerate((fT, np.full(F, RS41_F1), np.full(F, RS41_F2),
+                                   fH, np.full(F, RS41_F1), np.full(F, RS41_F2),
+                                   fT, np.full(F, RS41_F1), np.full(F, RS41_F2),
+                                   np.zeros(F), np.zeros(F), np.zeros(F))):
+                _put_le(body, 3 * k, v, 3)
         elif stype == 0x7C:  # GPS info: week, ms of week
             _put_le(body, 0, np.full(F, 2200), 2)
             _put_le(body, 2, (frame_idx * 1000 + 123456000) % 604800000, 4)

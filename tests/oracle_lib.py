@@ -81,6 +81,10 @@ def lib():
     L.or_dewpt.argtypes = [C.c_float, C.c_float]
     L.or_altitude_to_pressure.restype = C.c_float
     L.or_altitude_to_pressure.argtypes = [C.c_float]
+    L.or_rs41_temp.restype = C.c_float
+    L.or_rs41_temp.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, f32p, f32p]
+    L.or_rs41_rh.restype = C.c_float
+    L.or_rs41_rh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
     L.or_gf256_init()
     _lib = L
     return L

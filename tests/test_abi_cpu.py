@@ -87,3 +87,57 @@ def test_parse_frame_fields(lib):
     f.data[60] ^= 0xFF
     n2 = lib.sonde_parse_frame(C.byref(f), out, 8)
     assert n2 == n - 1
+
+
+def test_rs41_ptu_through_the_stateful_parser(lib):
+    """RS41 temperature / humidity: the calibration table arrives 16 bytes per frame, so PTU fragments start once
+    the fragments holding Rf1, Rf2, the polynomial and calH have been seen; values match what the generator encoded."""
+    from sdrpp_radiosonde_amd import synth
+    nfr = 70
+    frames = synth.rs41_build_frames(3, np.full(nfr, 42), np.arange(nfr))
+    Tt, RHt = synth.rs41_true_ptu(np.full(nfr, 42), np.arange(nfr))
+    h = lib.sonde_parser_create(0)
+    out = (_lib.SondeData * 8)()
+    first_ptu, pct = None, []
+    for k in range(nfr):
+        f = _lib.SondeFrame()
+        f.type, f.len = 0, 320
+        C.memmove(f.data, frames[k].ctypes.data, 320)
+        n = lib.sonde_parser_feed(h, C.byref(f), out, 8)
+        ptu = [out[i] for i in range(n) if out[i].fields & _lib.DATA_PTU]
+        if ptu:
+            if first_ptu is None:
+                first_ptu = k
+            assert abs(ptu[0].temp - Tt[k]) < 0.02, (k, ptu[0].temp, Tt[k])
+            assert abs(ptu[0].rh - RHt[k]) < 0.05, (k, ptu[0].rh, RHt[k])
+            assert ptu[0].pressure == 0.0                      # RS41-SG: the adaptor falls back to the ISA model
+            pct.append(ptu[0].calib_percent)
+    lib.sonde_parser_destroy(h)
+    # sequence numbers start at 1000 -> fragment index 1000 % 51 = 31; fragments 3..7 are complete 28 frames later
+    assert first_ptu == (7 - 1000 % 51) % 51
+    assert pct == sorted(pct) and abs(pct[-1] - 100.0) < 1e-3
+    # the stateless entry point has no calibration memory: no PTU fragment
+    f = _lib.SondeFrame()
+    f.type, f.len = 0, 320
+    C.memmove(f.data, frames[60].ctypes.data, 320)
+    n = lib.sonde_parse_frame(C.byref(f), out, 8)
+    assert not any(out[i].fields & _lib.DATA_PTU for i in range(n))
+
+
+def test_rs41_conversions_equal_oracle_bit_for_bit(lib):
+    import oracle_lib
+    O = oracle_lib.lib()
+    rng = np.random.default_rng(5)
+    co = (C.c_float * 3)(-243.911, 0.187654, 8.2e-06)
+    cal = (C.c_float * 3)(1.0007, 0.013, -2e-4)
+    for _ in range(2000):
+        f1 = int(rng.integers(100000, 150000)); f2 = f1 + int(rng.integers(30000, 80000))
+        f = int(rng.integers(f1 - 20000, f2 + 60000))
+        rf1 = float(rng.uniform(700, 800)); rf2 = float(rng.uniform(1050, 1150))
+        a = np.float32(lib.sonde_rs41_temp(f, f1, f2, rf1, rf2, co, cal))
+        b = np.float32(O.or_rs41_temp(f, f1, f2, rf1, rf2, co, cal))
+        assert a.tobytes() == b.tobytes()
+        T = float(rng.uniform(-90, 40))
+        a = np.float32(lib.sonde_rs41_rh(f, f1, f2, 45.0, T))
+        b = np.float32(O.or_rs41_rh(f, f1, f2, 45.0, T))
+        assert a.tobytes() == b.tobytes() and (0.0 <= a <= 100.0)
