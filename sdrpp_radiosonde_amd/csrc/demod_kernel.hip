@@ -146,7 +146,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
 	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
 	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)ch * ch_stride);
-	const float2 *src2 = reinterpret_cast<const float2 *>(src);
 	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
 	float4 pa, pb;                         // the float4 (two input samples) just before the wave's first one
 	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);

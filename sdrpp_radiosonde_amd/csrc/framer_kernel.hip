@@ -37,32 +37,32 @@ __constant__ uint8_t c_rs41_mask[64] = {
 // wave see each other's LDS writes once the compiler is kept from reordering across this point
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+// GF(2^8) arithmetic in the log domain without zero tests: log of 0 is GF_LZ, larger than any sum of valid
+// logarithms (<= 254 + 509), and the antilog table is periodic below GF_LZ and zero from there on, so a product
+// with a zero factor reads a zero.  The kernel is bound by the CU's LDS pipe, so a product is one table read once
+// the logarithms of its factors are at hand.
+#define GF_LZ    768
+#define GF_EXP2  (3 * GF_LZ)
 struct FramerTabs {                // shared by the waves of a workgroup
-	uint8_t mulk[RS_R * 256];      // mulk[j][v] = v * alpha^j : one dependent lookup per Horner step
-	uint8_t exp[512];
-	uint8_t log[256];
+	uint8_t  mulk[RS_R * 256];     // mulk[j][v] = v * alpha^j : one dependent lookup per Horner step
+	uint8_t  exp2[GF_EXP2];        // alpha^(i mod 255) for i < GF_LZ, 0 above
+	uint16_t log2[256];            // log2[0] = GF_LZ
 };
 struct FramerLds {                 // one per wave (= per frame)
 	uint8_t frame[SONDE_FRAME_MAX];
 	alignas(4) uint8_t cw[2][256];
-	uint8_t S[2][RS_R];
-	uint8_t lam[2][RS_R + 2];
-	uint8_t B[2][RS_R + 2];
-	uint8_t T[2][RS_R + 2];
-	uint8_t om[2][RS_R];
-	uint8_t ev[2][RS_T];
+	uint16_t logS[2][RS_R];        // logarithms of the syndromes
+	uint8_t  lam[2][RS_R + 2];
+	uint16_t loglam[2][RS_R + 2];
+	uint16_t logom[2][RS_R];
 	int     pos[2][RS_T];
 	int     L[2];
 	int     status[2];     // 0 clean, >0 errors to fix, -1 fail
 };
 
-__device__ __forceinline__ uint8_t gmul(const FramerTabs &s, uint8_t a, uint8_t b)
+__device__ __forceinline__ uint32_t gmul(const FramerTabs &s, uint32_t a, uint32_t b)
 {
-	return (a && b) ? s.exp[s.log[a] + s.log[b]] : 0;
-}
-__device__ __forceinline__ uint8_t gdiv(const FramerTabs &s, uint8_t a, uint8_t b)
-{
-	return a ? s.exp[s.log[a] + 255 - s.log[b]] : 0;
+	return s.exp2[(uint32_t)s.log2[a] + (uint32_t)s.log2[b]];
 }
 
 __device__ __forceinline__ uint8_t byte_at(const uint32_t *ring, uint32_t mask, uint64_t p)
@@ -94,10 +94,10 @@ __device__ __forceinline__ uint32_t syndrome4(const FramerTabs &tb, const uint8_
 			p3 = (uint32_t)mj[p3] ^ ((w3 >> (8 * b)) & 0xFFu);
 		}
 	}
-	const uint8_t A = tb.exp[(j * Q) % 255];
-	uint32_t syn = (uint32_t)gmul(tb, (uint8_t)p3, A) ^ p2;
-	syn = (uint32_t)gmul(tb, (uint8_t)syn, A) ^ p1;
-	syn = (uint32_t)gmul(tb, (uint8_t)syn, A) ^ p0;
+	const uint32_t la = (uint32_t)(j * Q) % 255u;          // log of A = alpha^(j*Q)
+	uint32_t syn = (uint32_t)tb.exp2[tb.log2[p3] + la] ^ p2;
+	syn = (uint32_t)tb.exp2[tb.log2[syn] + la] ^ p1;
+	syn = (uint32_t)tb.exp2[tb.log2[syn] + la] ^ p0;
 	return syn;
 }
 
@@ -115,7 +115,7 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 		// xor-add.  The two RS41 frame lengths get their own instantiation (constant chain offsets).
 		if (n == RS_R + (RS41_LEN_STD - 56) / 2) syn = syndrome4<((RS_R + (RS41_LEN_STD - 56) / 2 + 15) / 16) * 4>(tb, s.cw[c], j);
 		else syn = syndrome4<64>(tb, s.cw[c], j);
-		s.S[c][j] = (uint8_t)syn;
+		s.logS[c][j] = tb.log2[syn];
 	}
 	const unsigned long long nzm = __ballot(syn != 0);
 	if (lane < 2) {
@@ -126,20 +126,22 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 	WAVE_SYNC();
 	if (nzm == 0ull) return;                    // both codewords clean (wave-uniform): nothing to correct
 
-	// ---- Berlekamp-Massey, one coefficient per lane: half-wave h handles codeword h, lane idx = lane&31
-	// holds lam[idx] and Bp[idx] where Bp = x^m * B.  Same recurrence as the sequential form
-	// (delta, then lam -= delta/b * x^m B, length change iff 2L <= r), so the same Lambda comes out.
+	// ---- Berlekamp-Massey, one coefficient per lane: half-wave h handles codeword h, lane idx = lane&31 holds
+	// lam[idx] and (the logarithm of) Bp[idx] where Bp = x^m * B.  Same recurrence as the sequential form (delta,
+	// then lam -= delta/b * x^m B, length change iff 2L <= r), so the same Lambda comes out.  Log domain: the
+	// discrepancy term is one antilog read, the update one more, plus the logarithm of the new coefficient.
 	{
 		const int h = lane >> 5, idx = lane & 31;
 		const bool live = s.status[h] > 0;
-		uint8_t lam = (idx == 0) ? 1 : 0;
-		uint8_t Bp = (idx == 1) ? 1 : 0;
+		uint32_t lam = (idx == 0) ? 1u : 0u;
+		uint32_t loglam = (idx == 0) ? 0u : (uint32_t)GF_LZ;
+		uint32_t logBp = (idx == 1) ? 0u : (uint32_t)GF_LZ;
 		int L = 0;
-		uint8_t bb = 1;
+		uint32_t logbb = 0;                                     // b = 1
 #pragma unroll 1
 		for (int r = 0; r < RS_R; r++) {
-			const uint8_t sv = (live && idx <= r && idx <= L && idx < RS_R + 1) ? s.S[h][r - idx] : 0;
-			int t = gmul(tb, lam, sv);
+			const uint32_t ls = (live && idx <= r && idx <= L) ? (uint32_t)s.logS[h][r - idx] : (uint32_t)GF_LZ;
+			int t = tb.exp2[loglam + ls];
 			// xor-reduce over the 32 lanes of this half (two DPP rows)
 			t ^= __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true);
 			t ^= __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xF, 0xF, true);
@@ -147,21 +149,20 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 			t ^= __builtin_amdgcn_update_dpp(0, t, 0x140, 0xF, 0xF, true);
 			t ^= __builtin_amdgcn_update_dpp(0, t, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1 and 3
 			const int d0 = __builtin_amdgcn_readlane(t, 31), d1 = __builtin_amdgcn_readlane(t, 63);
-			const uint8_t delta = (uint8_t)(h ? d1 : d0);
-			const uint8_t lam_old = lam;
-			bool change = false;
-			if (delta) {
-				const uint8_t f = gdiv(tb, delta, bb);
-				lam = (uint8_t)(lam ^ gmul(tb, f, Bp));
-				change = 2 * L <= r;
-			}
-			const int shifted_src = change ? (int)lam_old : (int)Bp;
-			int up = __shfl_up(shifted_src, 1, 32);
-			if (idx == 0) up = 0;
-			Bp = (uint8_t)up;
-			if (change) { L = r + 1 - L; bb = delta; }
+			const uint32_t delta = (uint32_t)(h ? d1 : d0);
+			const uint32_t logd = tb.log2[delta];
+			// lam -= (delta / b) * Bp ; with delta = 0 the index lands in the zero part of the table
+			const uint32_t upd = tb.exp2[logd + 255u - logbb + logBp];
+			const bool change = delta != 0u && 2 * L <= r;
+			const uint32_t loglam_old = loglam;
+			lam ^= upd;
+			loglam = tb.log2[lam];
+			int up = __shfl_up((int)(change ? loglam_old : logBp), 1, 32);
+			if (idx == 0) up = GF_LZ;
+			logBp = (uint32_t)up;
+			if (change) { L = r + 1 - L; logbb = logd; }
 		}
-		if (idx < RS_R + 2) s.lam[h][idx] = lam;
+		if (idx < RS_R + 2) { s.lam[h][idx] = (uint8_t)lam; s.loglam[h][idx] = (uint16_t)loglam; }
 		const unsigned long long nzl = __ballot(lam != 0);
 		const uint32_t halfmask = (uint32_t)(h ? (nzl >> 32) : nzl);
 		const int deg = halfmask ? 31 - __clz(halfmask) : 0;
@@ -175,66 +176,86 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 	for (int c = 0; c < 2; c++) {
 		if (s.status[c] <= 0) continue;          // wave-uniform
 		const int L = s.L[c];
-		const uint8_t *lam = s.lam[c];
-		// ---- Chien search: position i = lane + 64*it
-		int npos = 0;
-		bool fail = false;
+		// ---- Chien search over the n positions of the shortened codeword, position i = lane + 64*it.
+		// Lambda has degree L, hence at most L roots among the 255 candidates: "L roots inside [0, n)" is the
+		// same condition as "L roots in all and none in the padding" (SPEC 3.3).  Term k at position i is
+		// lam[k] * alpha^(-i*k): its logarithm advances by (255 - i) mod 255 per k.
+		const int nit = (n + 63) >> 6;
+		uint32_t v[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, st[4];
+#pragma unroll
+		for (int it = 0; it < 4; it++) { const uint32_t i = (uint32_t)(lane + 64 * it); st[it] = i ? 255u - i : 0u; }
 #pragma unroll 1
-		for (int it = 0; it < 4; it++) {
-			const int i = lane + 64 * it;
-			bool root = false;
-			if (i < 255) {
-				uint8_t v = 0;
-#pragma unroll 1
-				for (int k = 0; k <= L; k++)
-					if (lam[k]) v ^= tb.exp[(tb.log[lam[k]] + (255 - i) * k) % 255];
-				root = (v == 0);
+		for (int k = 0; k <= L; k++) {
+			const uint32_t ll = s.loglam[c][k];
+#pragma unroll
+			for (int it = 0; it < 4; it++) {
+				if (it < nit) {
+					v[it] ^= tb.exp2[ll + e[it]];
+					e[it] += st[it];
+					if (e[it] >= 255u) e[it] -= 255u;
+				}
 			}
-			const unsigned long long rm = __ballot(root);
-			if (root) {
-				const int idx = npos + __popcll(rm & ((1ull << lane) - 1ull));
-				if (idx < RS_T) s.pos[c][idx] = i;
-				if (i >= n) fail = true;
-			}
-			npos += __popcll(rm);
 		}
-		if (__ballot(fail) != 0ull || npos != L) {
+		int npos = 0;
+#pragma unroll
+		for (int it = 0; it < 4; it++) {
+			if (it < nit) {
+				const int i = lane + 64 * it;
+				const bool root = i < n && v[it] == 0u;
+				const unsigned long long rm = __ballot(root);
+				if (root) {
+					const int idx = npos + __popcll(rm & ((1ull << lane) - 1ull));
+					if (idx < RS_T) s.pos[c][idx] = i;
+				}
+				npos += __popcll(rm);
+			}
+		}
+		if (npos != L) {
 			if (lane == 0) s.status[c] = -1;
-						WAVE_SYNC();
+			WAVE_SYNC();
 			continue;
 		}
 		// ---- omega = S*lam mod x^24
 		if (lane < RS_R) {
-			uint8_t v = 0;
+			uint32_t om = 0;
 #pragma unroll 1
-			for (int k = 0; k <= lane && k <= L; k++) v ^= gmul(tb, lam[k], s.S[c][lane - k]);
-			s.om[c][lane] = v;
+			for (int k = 0; k <= lane && k <= L; k++) om ^= tb.exp2[(uint32_t)s.loglam[c][k] + (uint32_t)s.logS[c][lane - k]];
+			s.logom[c][lane] = tb.log2[om];
 		}
-				WAVE_SYNC();
+		WAVE_SYNC();
 		// ---- Forney: e = X * omega(X^-1) / lam'(X^-1)
 		bool bad = false;
-		uint8_t ev = 0;
+		uint32_t ev = 0;
 		int p = 0;
 		if (lane < npos) {
 			p = s.pos[c][lane];
-			const int xi = (255 - p) % 255;
-			uint8_t num = 0, den = 0;
+			const uint32_t xi = p ? 255u - (uint32_t)p : 0u;
+			uint32_t num = 0, den = 0, ex = 0;
 #pragma unroll 1
-			for (int k = 0; k < RS_R; k++)
-				if (s.om[c][k]) num ^= tb.exp[(tb.log[s.om[c][k]] + xi * k) % 255];
+			for (int k = 0; k < RS_R; k++) {
+				num ^= tb.exp2[(uint32_t)s.logom[c][k] + ex];
+				ex += xi;
+				if (ex >= 255u) ex -= 255u;
+			}
+			uint32_t xi2 = 2u * xi;
+			if (xi2 >= 255u) xi2 -= 255u;
+			ex = 0;
 #pragma unroll 1
-			for (int k = 1; k <= L; k += 2)
-				if (lam[k]) den ^= tb.exp[(tb.log[lam[k]] + xi * (k - 1)) % 255];
+			for (int k = 1; k <= L; k += 2) {
+				den ^= tb.exp2[(uint32_t)s.loglam[c][k] + ex];
+				ex += xi2;
+				if (ex >= 255u) ex -= 255u;
+			}
 			if (!den) bad = true;
-			else ev = gmul(tb, tb.exp[p], gdiv(tb, num, den));
+			else ev = tb.exp2[(uint32_t)p + (uint32_t)tb.log2[num] + 255u - (uint32_t)tb.log2[den]];
 		}
 		if (__ballot(bad) != 0ull) {
 			if (lane == 0) s.status[c] = -1;
 		} else {
-			if (lane < npos) s.cw[c][p] ^= ev;
+			if (lane < npos) s.cw[c][p] ^= (uint8_t)ev;
 			if (lane == 0) s.status[c] = npos;
 		}
-				WAVE_SYNC();
+		WAVE_SYNC();
 	}
 }
 
@@ -357,6 +378,7 @@ __global__ __launch_bounds__(64 * B1_WAVES) void sd_sync_rs41_kernel(
 // workgroup, each wave then works alone on its own frame (wave-scope synchronisation only), so that
 // all frames of a step are resident at once and their latency-bound GF(2^8) chains overlap.
 #define B2_WAVES 4
+static_assert(64 * B2_WAVES == 256, "the table staging below writes one log2 entry per thread");
 __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 	const uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const uint8_t *__restrict__ gf_exp, const uint8_t *__restrict__ gf_log, const uint8_t *__restrict__ gf_mulk,
@@ -373,8 +395,8 @@ __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 		const uint4 *src = reinterpret_cast<const uint4 *>(gf_mulk);
 		uint4 *dst = reinterpret_cast<uint4 *>(tabs.mulk);
 		for (int i = tid; i < RS_R * 256 / 16; i += 64 * B2_WAVES) dst[i] = src[i];
-		if (tid < 512 / 4) reinterpret_cast<uint32_t *>(tabs.exp)[tid] = reinterpret_cast<const uint32_t *>(gf_exp)[tid];
-		else if (tid < 512 / 4 + 256 / 4) reinterpret_cast<uint32_t *>(tabs.log)[tid - 128] = reinterpret_cast<const uint32_t *>(gf_log)[tid - 128];
+		for (int i = tid; i < GF_EXP2; i += 64 * B2_WAVES) tabs.exp2[i] = i < GF_LZ ? gf_exp[i % 255] : (uint8_t)0;
+		tabs.log2[tid] = tid ? (uint16_t)gf_log[tid] : (uint16_t)GF_LZ;          // 256 threads, 256 entries
 	}
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
