@@ -89,6 +89,10 @@ int main()
 	rep("streams wg512 load8 depth2 bar nt", timeit([&] { streams<512, 8, 2, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
 	rep("streams wg512 load8 depth4 bar nt", timeit([&] { streams<512, 8, 4, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
 	rep("streams wg512 load4 depth4 bar nt", timeit([&] { streams<512, 4, 4, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
+	rep("streams wg384 load4 depth2 bar nt", timeit([&] { streams<384, 4, 2, true, true><<<C, 384>>>(buf, ch_f4, steps, sink); }));
+	rep("streams wg384 load4 depth3 bar nt", timeit([&] { streams<384, 4, 3, true, true><<<C, 384>>>(buf, ch_f4, steps, sink); }));
+	rep("streams wg384 load4 depth4 bar nt", timeit([&] { streams<384, 4, 4, true, true><<<C, 384>>>(buf, ch_f4, steps, sink); }));
+	rep("streams wg512 load4 depth3 bar nt", timeit([&] { streams<512, 4, 3, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
 	rep("streams wg512 load2 depth2 bar nt", timeit([&] { streams<512, 2, 2, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
 	return 0;
 }
