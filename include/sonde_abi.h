@@ -140,6 +140,7 @@ uint64_t sonde_batch_nbits(SondeBatch *b, uint32_t channel);
 int      sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp,
                                 float *yprev /* reserved, reads 0 */);
 int      sonde_get_taps(int type, float *out /* 32*32 floats, [phase][tap] */);
+int      sonde_get_afsk_table(float *out /* 480*2 floats: the iMet tone demodulator's mixer table (cos, -sin) */);
 
 /* frame -> SondeData fragments (what one X_decode call sequence yields for this frame).
  * Returns number of fragments written (<= cap). */

@@ -98,13 +98,13 @@ void or_discriminate(const float *iq, size_t n, float *d, float *last)
 /* ---- modem table.  Baud rates: SURVEY.md Appendix B [RECALL]; VFO bandwidths in
  * /root/reference/src/main.hpp:44-52 bound them from above. ---- */
 static const OrModem g_modems[OR_NTYPES] = {
-	{ OR_RS41,   4800.0, 0, 0.65f, 2 },  /* RS41: 4800 Bd GFSK, NRZ */
-	{ OR_DFM09,  5000.0, 0, 0.65f, 2 },  /* DFM: 2500 bit/s Manchester => 5000 chips/s */
-	{ OR_IMS100, 4800.0, 0, 0.65f, 2 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
-	{ OR_M10,    9600.0, 0, 0.65f, 1 },  /* M10/M20: 9600 chips/s Manchester: stays at 48 kS/s (5 samples/chip) */
-	{ OR_IMET4,  2400.0, 0, 0.65f, 2 },  /* placeholders (AFSK sondes) */
-	{ OR_C50,    2400.0, 0, 0.65f, 2 },
-	{ OR_MRZN1,  2400.0, 0, 0.65f, 2 },
+	{ OR_RS41,   4800.0, 0, 0.65f, 2, 1 },  /* RS41: 4800 Bd GFSK, NRZ */
+	{ OR_DFM09,  5000.0, 0, 0.65f, 2, 1 },  /* DFM: 2500 bit/s Manchester => 5000 chips/s */
+	{ OR_IMS100, 4800.0, 0, 0.65f, 2, 1 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
+	{ OR_M10,    9600.0, 0, 0.65f, 1, 1 },  /* M10/M20: 9600 chips/s Manchester: stays at 48 kS/s (5 samples/chip) */
+	{ OR_IMET4,  1200.0, 0, 0.65f, 1, 8 },  /* iMet-1/4: Bell-202 AFSK 1200 Bd; tone demodulator in front, 6 kS/s behind it */
+	{ OR_C50,    2400.0, 0, 0.65f, 2, 1 },  /* placeholders */
+	{ OR_MRZN1,  2400.0, 0, 0.65f, 2, 1 },
 };
 static OrModem g_modem_rt[OR_NTYPES];
 
@@ -113,7 +113,7 @@ const OrModem *or_modem(int type)
 	if (type < 0 || type >= OR_NTYPES) return NULL;
 	if (g_modem_rt[type].period0 == 0) {
 		g_modem_rt[type] = g_modems[type];
-		g_modem_rt[type].period0 = (int)llrint(65536.0 * ((double)OR_FS / g_modems[type].decim) / g_modems[type].baud);
+		g_modem_rt[type].period0 = (int)llrint(65536.0 * ((double)OR_FS / (g_modems[type].decim * g_modems[type].pre)) / g_modems[type].baud);
 	}
 	return &g_modem_rt[type];
 }
@@ -124,7 +124,7 @@ void or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS])
 {
 	const int nt = OR_NTAPS / m->decim;      /* taps in use: 16 at the decimated rate, 32 at 48 kS/s (same span in time) */
 	memset(taps, 0, sizeof(float) * OR_NPHASE * OR_NTAPS);
-	const double fc = (double)m->cutoff * m->baud / ((double)OR_FS / m->decim); /* cycles per (decimated) sample */
+	const double fc = (double)m->cutoff * m->baud / ((double)OR_FS / (m->decim * m->pre)); /* cycles per internal sample */
 	for (int p = 0; p < OR_NPHASE; p++) {
 		double h[OR_NTAPS], sum = 0.0;
 		for (int j = 0; j < nt; j++) {
@@ -145,6 +145,10 @@ struct OrDemod {
 	float ring[OR_RING];
 	int64_t n0;          /* samples consumed so far */
 	float iq_last[2];
+	/* AFSK front-end state (SPEC 3.6) */
+	float af_b[OR_AF_WIN - 1][2];   /* the four block sums before the current one, oldest first */
+	float af_z[2];                  /* previous boxcar output */
+	uint64_t af_n;                  /* input samples consumed (mixer phase = af_n mod 480) */
 	int64_t t_next;      /* Q16 absolute on-time instant of the next symbol */
 	int32_t period;      /* Q16 samples per symbol */
 	float bias, amp;
@@ -259,6 +263,50 @@ static void run_rounds(OrDemod *d)
 	}
 }
 
+/* ---- AFSK tone demodulator (SPEC 3.6; iMet-1/4: Bell-202 tones 1200 Hz = mark, 2200 Hz = space at 1200 Bd on the
+ * FM audio; SURVEY.md Appendix B [RECALL]).  The discriminator output d[n] (the audio) is mixed with a 1700 Hz
+ * complex oscillator, so mark/space sit at -/+500 Hz, low-passed by a one-symbol boxcar (40 samples, nulls at
+ * multiples of 1200 Hz: the images at -2900/-3900 Hz are down 18-23 dB), decimated 8:1 and FM-discriminated
+ * again: q[m] ~ -/+ 1/3 quadrant per sample at 6 kS/s, which the same timing loop / slicer as for the GFSK
+ * sondes turns into bits.  Mixer table: 480 entries = 17 cycles (1700/48000 = 17/480), (cos, -sin) from double. */
+void or_afsk_table(float *w)
+{
+	for (int k = 0; k < OR_AF_PER; k++) {
+		const double a = 2.0 * OR_PI_D * 17.0 * (double)k / (double)OR_AF_PER;
+		w[2 * k] = (float)cos(a);
+		w[2 * k + 1] = (float)(-sin(a));
+	}
+}
+
+/* n_in input samples (a multiple of 8) -> n_in/8 samples of q */
+static void afsk_front(OrDemod *d, const float *src, size_t n_in, int is_iq, float *q)
+{
+	static float W[2 * OR_AF_PER];
+	static int have;
+	if (!have) { or_afsk_table(W); have = 1; }
+	for (size_t m = 0; m < n_in / OR_AF_DEC; m++) {
+		float dv[OR_AF_DEC];
+		if (is_iq) or_discriminate(src + 2 * OR_AF_DEC * m, OR_AF_DEC, dv, d->iq_last);
+		else memcpy(dv, src + OR_AF_DEC * m, sizeof(dv));
+		float br = 0.0f, bi = 0.0f;
+		for (int i = 0; i < OR_AF_DEC; i++) {
+			const unsigned k = (unsigned)((d->af_n + OR_AF_DEC * m + (size_t)i) % OR_AF_PER);
+			br = fmaf(dv[i], W[2 * k], br);
+			bi = fmaf(dv[i], W[2 * k + 1], bi);
+		}
+		/* boxcar over the last five block sums, oldest first */
+		const float zr = (((d->af_b[0][0] + d->af_b[1][0]) + d->af_b[2][0]) + d->af_b[3][0]) + br;
+		const float zi = (((d->af_b[0][1] + d->af_b[1][1]) + d->af_b[2][1]) + d->af_b[3][1]) + bi;
+		for (int h = 0; h < OR_AF_WIN - 2; h++) { d->af_b[h][0] = d->af_b[h + 1][0]; d->af_b[h][1] = d->af_b[h + 1][1]; }
+		d->af_b[OR_AF_WIN - 2][0] = br;
+		d->af_b[OR_AF_WIN - 2][1] = bi;
+		/* second discriminator: the same product form as stage 1 */
+		const float zz[2] = { zr, zi };
+		or_discriminate(zz, 1, &q[m], d->af_z);
+	}
+	d->af_n += n_in;
+}
+
 /* One 2048-sample input tile at a time.  Stage K0 (SPEC 3.0): sondes whose symbol rate leaves room
  * (decim = 2: RS41, DFM, iMS-100) are first decimated 2:1 by a two-sample boxcar -- z[m] = x[2m] + x[2m+1]
  * on IQ, 0.5*(d[2m] + d[2m+1]) on real discriminator input -- so that the discriminator and everything
@@ -268,6 +316,19 @@ static void run_rounds(OrDemod *d)
  * noise bandwidth.  M10 (9600 chips/s) stays at 48 kS/s. */
 void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 {
+	if (d->m->pre > 1) {
+		/* AFSK: one tile of the demodulator = 2048 samples behind the tone demodulator = 16384 input samples
+		 * (n must be a multiple of that) */
+		const size_t blk = (size_t)OR_TILE * (size_t)d->m->pre;
+		float q[OR_TILE];
+		for (size_t off = 0; off + blk <= n; off += blk) {
+			afsk_front(d, src + (is_iq ? 2 : 1) * off, blk, is_iq, q);
+			for (int i = 0; i < OR_TILE; i++) d->ring[(d->n0 + i) & (OR_RING - 1)] = q[i];
+			d->n0 += OR_TILE;
+			run_rounds(d);
+		}
+		return;
+	}
 	const int dec = d->m->decim, it = OR_TILE / dec;
 	float tile[OR_TILE], z[2 * OR_TILE];
 	for (size_t off = 0; off + OR_TILE <= n; off += OR_TILE) {

@@ -324,6 +324,71 @@ static int ims100_run(OrFramerPub *f, const uint8_t *bits, uint64_t wpos)
 	}
 }
 
+/* ------------------------------------------------------------------ iMet-1 / iMet-4 (SPEC 3.3c)
+ * Asynchronous characters at 1200 Bd: start bit 0, eight data bits LSB first, stop bit 1; idle = mark = 1.
+ * A packet starts with 0x01, then the type: 1 PTU (14 bytes), 2 GPS (18), 3 XDATA (5 + byte 2), 4 PTUX (20);
+ * the last two bytes are CRC16-CCITT (init 0x1D0F) big-endian over the rest.  [RECALL: public iMet notes.]
+ * Sync = the 12 bits  1 | 0 1000 0000 1 | 0  (stop/idle, the character 0x01, the next start bit), exact match in
+ * either polarity (the slicer's polarity depends on which side of the 1700 Hz mixer the mark tone falls).
+ * A candidate is dropped (search resumes one bit later) if the type is unknown or any character of the packet
+ * has a wrong start/stop bit; it waits if the packet is not complete yet.  CRC failures are recorded, not dropped. */
+uint16_t or_imet_crc(const uint8_t *p, size_t n)
+{
+	uint16_t crc = 0x1D0F;
+	for (size_t i = 0; i < n; i++) {
+		crc ^= (uint16_t)((uint16_t)p[i] << 8);
+		for (int k = 0; k < 8; k++) crc = (crc & 0x8000) ? (uint16_t)((crc << 1) ^ 0x1021) : (uint16_t)(crc << 1);
+	}
+	return crc;
+}
+
+static const uint8_t imet_sync[12] = { 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
+
+static inline int imet_char(const uint8_t *bits, uint64_t at, int inv, uint8_t *out)
+{
+	uint8_t v = 0;
+	for (int m = 0; m < 8; m++) v |= (uint8_t)((bits[at + 1 + m] ^ inv) << m);
+	*out = v;
+	return (bits[at] ^ inv) == 0 && (bits[at + 9] ^ inv) == 1;
+}
+
+static int imet4_run(OrFramerPub *f, const uint8_t *bits, uint64_t wpos)
+{
+	int added = 0;
+	while (f->rpos + 12 <= wpos) {
+		int hd = 0;
+		for (int i = 0; i < 12; i++) hd += bits[f->rpos + i] ^ imet_sync[i];
+		if (hd != 0 && hd != 12) { f->rpos++; continue; }
+		const int inv = hd == 12;
+		const uint64_t c0 = f->rpos + 1;                 /* start bit of the 0x01 character */
+		if (c0 + 30 > wpos) break;                       /* need the type and (for XDATA) the length byte */
+		uint8_t type, lenb;
+		int ok = imet_char(bits, c0 + 10, inv, &type);
+		ok &= imet_char(bits, c0 + 20, inv, &lenb);
+		int len = 0;
+		if (type == 1) len = 14;
+		else if (type == 2) len = 18;
+		else if (type == 3) len = 5 + lenb;
+		else if (type == 4) len = 20;
+		if (!ok || len == 0 || len > 64) { f->rpos++; continue; }
+		if (c0 + 10 * (uint64_t)len > wpos) break;       /* wait for the rest */
+		uint8_t pkt[64];
+		for (int j = 0; j < len; j++) ok &= imet_char(bits, c0 + 10 * (uint64_t)j, inv, &pkt[j]);
+		if (!ok) { f->rpos++; continue; }
+		OrFrame *fr = push_frame(f);
+		fr->len = len;
+		memcpy(fr->data, pkt, (size_t)len);
+		const uint16_t crc = or_imet_crc(pkt, (size_t)len - 2);
+		fr->nerr[0] = (crc == (uint16_t)((pkt[len - 2] << 8) | pkt[len - 1])) ? 0 : -1;
+		fr->nerr[1] = 0;
+		fr->flags = inv ? 1u : 0u;
+		fr->bitpos = c0;
+		f->rpos = c0 + 10 * (uint64_t)len - 1;          /* the last stop bit may open the next sync */
+		added++;
+	}
+	return added;
+}
+
 int or_framer_run_other(void *fp, const uint8_t *bits, uint64_t wpos)
 {
 	OrFramerPub *f = fp;
@@ -331,6 +396,7 @@ int or_framer_run_other(void *fp, const uint8_t *bits, uint64_t wpos)
 	case OR_DFM09:  return dfm09_run(f, bits, wpos);
 	case OR_M10:    return m10_run(f, bits, wpos);
 	case OR_IMS100: return ims100_run(f, bits, wpos);
+	case OR_IMET4:  return imet4_run(f, bits, wpos);
 	default: return 0;
 	}
 }

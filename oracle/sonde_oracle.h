@@ -55,6 +55,7 @@ typedef struct {
 	int    period0;     /* Q16 (internal-rate) samples per symbol = rint(65536*(FS/decim)/baud) */
 	float  cutoff;      /* low-pass cutoff, in units of baud */
 	int    decim;       /* 2: IQ is decimated 2:1 before the discriminator (internal rate 24 kS/s); 1: not */
+	int    pre;         /* 8: AFSK sonde, the tone demodulator in front delivers FS/8 samples (SPEC 3.6); else 1 */
 } OrModem;
 
 typedef struct {
@@ -88,6 +89,12 @@ void     or_demod_getbits(const OrDemod *d, uint64_t from, size_t count, uint8_t
 /* debug taps for staged parity tests */
 void     or_demod_state(const OrDemod *d, int64_t *t_next, int32_t *period, float *bias, float *amp, float *yprev);
 
+/* ---- stage 1b: AFSK tone demodulator (iMet-4; SPEC 3.6) ---- */
+#define OR_AF_DEC  8          /* 48 kS/s -> 6 kS/s */
+#define OR_AF_PER  480        /* period of the 1700 Hz mixer table at 48 kS/s (17 cycles) */
+#define OR_AF_WIN  5          /* boxcar: 5 blocks of 8 samples = one 1200 Bd symbol */
+void     or_afsk_table(float *w /* [480][2]: cos, -sin */);
+
 /* ---- stage 3: framer + FEC ---- */
 void     or_gf256_init(void);
 uint8_t  or_gf256_mul(uint8_t a, uint8_t b);
@@ -97,6 +104,7 @@ int      or_rs255_decode(uint8_t *cw, int n);
 void     or_rs255_encode(uint8_t *cw, int n);   /* fills cw[0..23] from cw[24..n) */
 uint16_t or_crc16_ccitt(const uint8_t *p, size_t n);
 uint16_t or_m10_checksum(const uint8_t *p, size_t n);
+uint16_t or_imet_crc(const uint8_t *p, size_t n);        /* CRC16-CCITT, init 0x1D0F */
 uint32_t or_bch_parity(uint64_t data34);                 /* BCH(63,51) shortened to (46,34) */
 uint64_t or_bch_decode(uint64_t blk46, int *st);         /* st: errors corrected (0..2) or -1 */
 

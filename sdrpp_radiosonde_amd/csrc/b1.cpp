@@ -16,7 +16,7 @@ struct SondeB1Decoder {
 	int type = 0;
 	SondeBatch *batch = nullptr;      // null for sonde types that are not implemented (always PROCEED)
 	SondeParser parser;
-	std::vector<float> pending;       // samples waiting for a full 2048-sample tile
+	std::vector<float> pending;       // samples waiting for a full tile (b1_granule)
 	std::deque<SondeData> frags;
 	std::vector<SondeFrame> frames;
 	bool consumed = false;
@@ -24,6 +24,8 @@ struct SondeB1Decoder {
 };
 
 static const uint32_t kB1MaxSamples = 16 * SONDE_TILE;
+// submit granule: one tile, or one tile behind the 8:1 tone demodulator for the AFSK sondes
+static size_t b1_granule(int type) { return type == SONDE_IMET4 ? 8 * (size_t)SONDE_TILE : (size_t)SONDE_TILE; }
 
 static SondeB1Decoder *b1_init(int type, int samplerate, bool implemented)
 {
@@ -56,8 +58,9 @@ static ParserStatus b1_decode(SondeB1Decoder *d, SondeData *dst, const float *sr
 	if (!d->consumed) {
 		d->pending.insert(d->pending.end(), src, src + len);
 		size_t off = 0;
-		while (d->pending.size() - off >= SONDE_TILE) {
-			size_t n = ((d->pending.size() - off) / SONDE_TILE) * SONDE_TILE;
+		const size_t gran = b1_granule(d->type);
+		while (d->pending.size() - off >= gran) {
+			size_t n = ((d->pending.size() - off) / gran) * gran;
 			if (n > kB1MaxSamples) n = kB1MaxSamples;
 			if (sonde_batch_submit_host(d->batch, d->pending.data() + off, n, n) != 0) break;
 			const long nf = sonde_batch_sync(d->batch);
@@ -91,6 +94,6 @@ SONDE_B1_DEF(RS41Decoder,   rs41,   SONDE_RS41,   true)
 SONDE_B1_DEF(DFM09Decoder,  dfm09,  SONDE_DFM09,  true)
 SONDE_B1_DEF(IMS100Decoder, ims100, SONDE_IMS100, true)
 SONDE_B1_DEF(M10Decoder,    m10,    SONDE_M10,    true)
-SONDE_B1_DEF(IMET4Decoder,  imet4,  SONDE_IMET4,  false)   // AFSK sondes: SURVEY 8f-4
+SONDE_B1_DEF(IMET4Decoder,  imet4,  SONDE_IMET4,  true)    // Bell-202 AFSK: tone demodulator in front (SPEC 3.6)
 SONDE_B1_DEF(C50Decoder,    c50,    SONDE_C50,    false)
 SONDE_B1_DEF(MRZN1Decoder,  mrzn1,  SONDE_MRZN1,  false)

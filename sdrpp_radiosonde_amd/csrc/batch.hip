@@ -31,23 +31,24 @@ extern "C" const char *sonde_version(void) { return "sonde_mi355 0.1 (gfx950)"; 
 // ---------------------------------------------------------------- modem table (SPEC)
 // Symbol (chip) rates: SURVEY.md Appendix B; the VFO bandwidths of /root/reference/src/main.hpp:44-52
 // bound them from above.
-struct ModemDef { double baud; float cutoff; int decim; };
+struct ModemDef { double baud; float cutoff; int decim; int pre; };   // pre = 8: AFSK tone demodulator in front (SPEC 3.6)
 static const ModemDef k_modems[SONDE_NTYPES] = {
-	{ 4800.0, 0.65f, 2 },   // RS41   4800 Bd GFSK NRZ; IQ decimated 2:1 before the discriminator (SPEC 3.0)
-	{ 5000.0, 0.65f, 2 },   // DFM    2500 bit/s Manchester -> 5000 chips/s
-	{ 4800.0, 0.65f, 2 },   // iMS100 2400 bit/s biphase    -> 4800 chips/s
-	{ 9600.0, 0.65f, 1 },   // M10    9600 chips/s Manchester: stays at 48 kS/s (5 samples per chip)
-	{ 2400.0, 0.65f, 2 },   // iMet-4  (AFSK, SURVEY 8f-4: not implemented)
-	{ 2400.0, 0.65f, 2 },   // SRS-C50 (AFSK, not implemented)
-	{ 2400.0, 0.65f, 2 },   // MRZ-N1  (not implemented)
+	{ 4800.0, 0.65f, 2, 1 },   // RS41   4800 Bd GFSK NRZ; IQ decimated 2:1 before the discriminator (SPEC 3.0)
+	{ 5000.0, 0.65f, 2, 1 },   // DFM    2500 bit/s Manchester -> 5000 chips/s
+	{ 4800.0, 0.65f, 2, 1 },   // iMS100 2400 bit/s biphase    -> 4800 chips/s
+	{ 9600.0, 0.65f, 1, 1 },   // M10    9600 chips/s Manchester: stays at 48 kS/s (5 samples per chip)
+	{ 1200.0, 0.65f, 1, 8 },   // iMet-1/4 Bell-202 AFSK 1200 Bd: tone demodulator, then 6 kS/s through the same loop
+	{ 2400.0, 0.65f, 2, 1 },   // SRS-C50 (AFSK, not implemented)
+	{ 2400.0, 0.65f, 2, 1 },   // MRZ-N1  (not implemented)
 };
 
-static int32_t modem_period0(int type) { return (int32_t)llrint(65536.0 * ((double)SD_FS / k_modems[type].decim) / k_modems[type].baud); }
+static int modem_div(int type) { return k_modems[type].decim * k_modems[type].pre; }     // input samples per internal sample
+static int32_t modem_period0(int type) { return (int32_t)llrint(65536.0 * ((double)SD_FS / modem_div(type)) / k_modems[type].baud); }
 
 static void make_taps(int type, float *out /* [32][32] */)
 {
 	const double PI = 3.14159265358979323846;
-	const double fc = (double)k_modems[type].cutoff * k_modems[type].baud / ((double)SD_FS / k_modems[type].decim);
+	const double fc = (double)k_modems[type].cutoff * k_modems[type].baud / ((double)SD_FS / modem_div(type));
 	const int nt = SD_NTAPS / k_modems[type].decim;    // taps in use: 16 at the decimated rate, 32 at 48 kS/s
 	memset(out, 0, sizeof(float) * SD_NPHASE * SD_NTAPS);
 	for (int p = 0; p < SD_NPHASE; p++) {
@@ -62,6 +63,19 @@ static void make_taps(int type, float *out /* [32][32] */)
 		}
 		for (int j = 0; j < nt; j++) out[p * SD_NTAPS + j] = (float)(h[j] / sum);
 	}
+}
+
+// mixer table of the AFSK tone demodulator: (cos, -sin) of 2 pi 17 k / 480 (1700 Hz at 48 kS/s), SPEC 3.6
+extern "C" int sonde_get_afsk_table(float *out /* [480][2] */)
+{
+	if (!out) return fail("sonde_get_afsk_table: null argument");
+	const double PI = 3.14159265358979323846;
+	for (int k = 0; k < SD_AF_PER; k++) {
+		const double a = 2.0 * PI * 17.0 * (double)k / (double)SD_AF_PER;
+		out[2 * k] = (float)cos(a);
+		out[2 * k + 1] = (float)(-sin(a));
+	}
+	return 0;
 }
 
 extern "C" int sonde_get_taps(int type, float *out)
@@ -93,6 +107,12 @@ struct SondeBatch {
 	uint32_t *d_chlist[SONDE_NTYPES] = {};
 	void *d_stage = nullptr;
 	size_t stage_bytes = 0;
+	// AFSK sondes (iMet): tone-demodulator state, mixer table, 6 kS/s scratch rows; the other channels' list for kernel A
+	SdAfskState *d_astates = nullptr;
+	float *d_wtab = nullptr, *d_afq = nullptr;
+	uint32_t *d_nonafsk = nullptr;
+	uint32_t n_nonafsk = 0;
+	uint32_t granule = SONDE_TILE;         // submit sizes must be a multiple of this
 
 	static const int kEvSlots = 128;       // submits timed between two sonde_batch_kernel_ms() calls
 	hipEvent_t ev[3 * kEvSlots] = {};
@@ -113,6 +133,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	if (b->pending) (void)hipStreamSynchronize(b->last_stream);
 	(void)hipFree(b->d_states); (void)hipFree(b->d_fstates); (void)hipFree(b->d_hist); (void)hipFree(b->d_bitring);
 	(void)hipFree(b->d_frames); (void)hipFree(b->d_counts); (void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
+	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); (void)hipFree(b->d_nonafsk);
 	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfmulk); (void)hipFree(b->d_g64); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
@@ -144,16 +165,16 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		if (t < 0 || t >= SONDE_NTYPES) { delete b; return fail("sonde_batch_create: bad sonde type"); }
 		b->chlist[t].push_back(c);
 		const int32_t p = modem_period0(t) - (modem_period0(t) >> 8);      // fastest symbol clock the loop allows
-		max_bits = std::max(max_bits, ((uint64_t)(cfg->max_samples / k_modems[t].decim) << 16) / (uint64_t)p + 2);
+		max_bits = std::max(max_bits, ((uint64_t)(cfg->max_samples / modem_div(t)) << 16) / (uint64_t)p + 2);
 	}
 	b->ring_words = pow2ceil((uint32_t)((max_bits + 8 * SONDE_FRAME_MAX + 1024 + 31) / 32));
 	b->max_frames = 2;
 	{	// frames per submit per type: submit bits (at that type's fastest period) / shortest frame of the type, + carry-over
-		static const uint32_t min_frame_bits[SONDE_NTYPES] = { 320 * 8, 560, 1152, 1648, 1u << 30, 1u << 30, 1u << 30 };
+		static const uint32_t min_frame_bits[SONDE_NTYPES] = { 320 * 8, 560, 1152, 1648, 140, 1u << 30, 1u << 30 };
 		for (int t = 0; t < SONDE_NTYPES; t++) {
 			if (b->chlist[t].empty()) continue;
 			const int32_t p = modem_period0(t) - (modem_period0(t) >> 8);
-			const uint64_t bits_t = ((uint64_t)(cfg->max_samples / k_modems[t].decim) << 16) / (uint64_t)p + 2;
+			const uint64_t bits_t = ((uint64_t)(cfg->max_samples / modem_div(t)) << 16) / (uint64_t)p + 2;
 			b->type_frames[t] = (uint32_t)(bits_t / min_frame_bits[t]) + 2;
 			b->max_frames = std::max(b->max_frames, b->type_frames[t]);
 		}
@@ -177,6 +198,18 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
+	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
+	std::vector<uint32_t> nonafsk;
+	if (n_afsk) {
+		if (cfg->max_samples % (SONDE_TILE * SD_AF_DEC)) { sonde_batch_destroy(b); return fail("sonde_batch_create: with iMet channels max_samples must be a multiple of 16384"); }
+		b->granule = SONDE_TILE * SD_AF_DEC;
+		ALLOC(b->d_astates, C * sizeof(SdAfskState));
+		ALLOC(b->d_wtab, SD_AF_PER * 2 * sizeof(float));
+		ALLOC(b->d_afq, n_afsk * (size_t)(cfg->max_samples / SD_AF_DEC) * sizeof(float));
+		for (uint32_t c = 0; c < b->n_channels; c++) if (b->types[c] != SONDE_IMET4) nonafsk.push_back(c);
+		b->n_nonafsk = (uint32_t)nonafsk.size();
+		if (b->n_nonafsk) ALLOC(b->d_nonafsk, nonafsk.size() * sizeof(uint32_t));
+	}
 #undef ALLOC
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { sonde_batch_destroy(b); return fail(#x, e_); } } while (0)
 	// modem tables
@@ -191,7 +224,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		modems[t].pmin = p0 - (p0 >> 8);
 		modems[t].pmax = p0 + (p0 >> 8);
 		modems[t].decim = k_modems[t].decim;
-		modems[t].itile = SD_TILE / k_modems[t].decim;
+		modems[t].itile = SD_TILE / k_modems[t].decim;      // AFSK: kernel A sees the 6 kS/s stream as plain real input
 		modems[t].rounds = ((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 > SD_ROUND_MAX) ? 2 : 1;
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -235,6 +268,13 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	CHK(hipMemset(b->d_hist, 0, C * SD_HIST * sizeof(float)));
 	CHK(hipMemset(b->d_bitring, 0, C * (size_t)b->ring_words * sizeof(uint32_t)));
 	CHK(hipMemset(b->d_counts, 0, C * sizeof(uint32_t)));
+	if (n_afsk) {
+		float wtab[2 * SD_AF_PER];
+		sonde_get_afsk_table(wtab);
+		CHK(hipMemcpy(b->d_wtab, wtab, sizeof(wtab), hipMemcpyHostToDevice));
+		CHK(hipMemset(b->d_astates, 0, C * sizeof(SdAfskState)));
+		if (b->n_nonafsk) CHK(hipMemcpy(b->d_nonafsk, nonafsk.data(), nonafsk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty())
 			CHK(hipMemcpy(b->d_chlist[t], b->chlist[t].data(), b->chlist[t].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -248,15 +288,29 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_)
 {
 	if (!b || !samples) return fail("sonde_batch_submit: null argument");
-	if (n_samples == 0 || n_samples % SONDE_TILE || n_samples > b->max_samples) return fail("sonde_batch_submit: n_samples must be a multiple of SONDE_TILE and <= max_samples");
+	if (n_samples == 0 || n_samples % b->granule || n_samples > b->max_samples) return fail("sonde_batch_submit: n_samples must be a multiple of SONDE_TILE (16384 with iMet channels) and <= max_samples");
 	if (channel_stride < n_samples) return fail("sonde_batch_submit: channel_stride < n_samples");
 	HIPCHK(hipSetDevice(b->device));
 	hipStream_t stream = (hipStream_t)stream_;
 	const int n_tiles = (int)(n_samples / SONDE_TILE);
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	HIPCHK(hipEventRecord(ev[0], stream));
-	sd_launch_demod(b->input_kind == SONDE_INPUT_IQ, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
-		b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems);
+	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
+	if (!n_afsk) {
+		sd_launch_demod(b->input_kind == SONDE_INPUT_IQ, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
+			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems);
+	} else {
+		// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows
+		// (one kernel-A tile = 2048 scratch samples = 16384 input samples); everything else as usual
+		if (b->n_nonafsk)
+			sd_launch_demod(b->input_kind == SONDE_INPUT_IQ, b->n_nonafsk, stream, (const float *)samples, channel_stride, n_tiles,
+				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_nonafsk, false);
+		const size_t nq = n_samples / SD_AF_DEC;
+		sd_launch_afsk(b->input_kind == SONDE_INPUT_IQ, (uint32_t)n_afsk, stream, (const float *)samples, channel_stride, n_tiles,
+			b->d_chlist[SONDE_IMET4], b->d_astates, b->d_wtab, b->d_afq, nq);
+		sd_launch_demod(false, (uint32_t)n_afsk, stream, b->d_afq, nq, (int)(nq / SONDE_TILE),
+			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[SONDE_IMET4], true);
+	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], stream));
 	// d_counts: zeroed at creation; every sync kernel rewrites the entry of each channel it owns on every submit
@@ -272,6 +326,11 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 			b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t]);
 		HIPCHK(hipGetLastError());
 	}
+	if (n_afsk) {
+		sd_launch_framer_imet((uint32_t)n_afsk, stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
+			b->d_frames, b->d_counts, b->max_frames, b->d_chlist[SONDE_IMET4]);
+		HIPCHK(hipGetLastError());
+	}
 	HIPCHK(hipEventRecord(ev[2], stream));
 	b->ev_used++;
 	b->last_stream = stream;
@@ -283,7 +342,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 extern "C" int sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride)
 {
 	if (!b || !samples) return fail("sonde_batch_submit_host: null argument");
-	if (n_samples == 0 || n_samples % SONDE_TILE || n_samples > b->max_samples) return fail("sonde_batch_submit_host: bad n_samples");
+	if (n_samples == 0 || n_samples % b->granule || n_samples > b->max_samples) return fail("sonde_batch_submit_host: bad n_samples");
 	HIPCHK(hipSetDevice(b->device));
 	const size_t elem = b->input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : sizeof(float);
 	const size_t need = (size_t)b->n_channels * b->max_samples * elem;

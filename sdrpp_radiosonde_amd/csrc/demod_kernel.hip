@@ -103,12 +103,13 @@ __device__ __forceinline__ float interp(const float *A, const float *B, const fl
 // latency-bound chain (loop update -> FIR reads -> reduction).  Running them as different waves of the
 // same workgroup doubles the waves per SIMD and lets the hardware overlap them; the only hand-over is
 // the double-buffered LDS tile, one s_barrier per tile (two for sondes with > 256 symbols per tile).
-template <bool IS_IQ>
+template <bool IS_IQ, bool LIST>      // LIST: work on the channels of `chlist` (mixed batches with AFSK sondes); the plain instantiation ignores it
 __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
-	const float *__restrict__ taps_all, const SdModem *__restrict__ modems)
+	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
+	const uint32_t *__restrict__ chlist, int compact_in)
 {
 	__shared__ __attribute__((aligned(16))) DemodLds s;
 
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const bool is_k = wave >= 4;           // wave-uniform role
 	const int t = tid & 255;               // index inside the role group
 	const int rwave = wave & 3;
-	const uint32_t ch = blockIdx.x;
+	const uint32_t ch = LIST ? chlist[blockIdx.x] : blockIdx.x;        // channel (state, bit ring)
+	const uint32_t row = (LIST && compact_in) ? blockIdx.x : ch;       // row of `in`
 
 	SdChanState st = states[ch];
 	const SdModem md = modems[st.type];
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// ================================================================ discriminator role (waves 4-7)
 	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
 	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
-	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)ch * ch_stride);
+	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)row * ch_stride);
 	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
 	float4 pa, pb;                         // the float4 (two input samples) just before the wave's first one
 	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);
@@ -389,12 +391,15 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 
 void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
-	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems)
+	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
+	const uint32_t *chlist, bool compact_in)
 {
-	if (is_iq)
-		hipLaunchKernelGGL(sd_demod_kernel<true>, dim3(n_channels), dim3(SD_WGT), 0, stream,
-			in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems);
-	else
-		hipLaunchKernelGGL(sd_demod_kernel<false>, dim3(n_channels), dim3(SD_WGT), 0, stream,
-			in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems);
+	const dim3 g(n_channels), blk(SD_WGT);
+	const int ci = compact_in ? 1 : 0;
+#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci
+	if (is_iq && !chlist) hipLaunchKernelGGL((sd_demod_kernel<true, false>), g, blk, 0, stream, SD_DEMOD_ARGS);
+	else if (is_iq) hipLaunchKernelGGL((sd_demod_kernel<true, true>), g, blk, 0, stream, SD_DEMOD_ARGS);
+	else if (!chlist) hipLaunchKernelGGL((sd_demod_kernel<false, false>), g, blk, 0, stream, SD_DEMOD_ARGS);
+	else hipLaunchKernelGGL((sd_demod_kernel<false, true>), g, blk, 0, stream, SD_DEMOD_ARGS);
+#undef SD_DEMOD_ARGS
 }

@@ -4,9 +4,17 @@
 #include "sonde_dev.h"
 #include "../../include/sonde_abi.h"
 
+// chlist: null = channels 0..n_channels-1 read their own row of `in`; else block i works on channel chlist[i] and reads
+// row chlist[i] (compact_in = false: the caller's buffer) or row i (compact_in = true: a per-list scratch buffer)
 void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
-	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems);
+	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
+	const uint32_t *chlist = nullptr, bool compact_in = false);
+
+void sd_launch_afsk(bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
+	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride);
+void sd_launch_framer_imet(uint32_t n_list, hipStream_t stream, const SdChanState *states, SdFramerState *fstates,
+	const uint32_t *bitring, uint32_t ring_words, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist);
 
 #define SD_DESC_BYTES 16   // sizeof(SdFrameDesc)
 void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,

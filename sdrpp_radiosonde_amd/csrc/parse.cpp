@@ -244,12 +244,40 @@ void SondeParser::feed_m10(const SondeFrame &f, std::vector<SondeData> &out)
 	out.push_back(sd);
 }
 
+// iMet-1 / iMet-4 packets (SPEC 3.3c; field layout: public iMet notes, [RECALL]):
+//   01 01 pkt#(u16) P(u24, 0.01 hPa) T(i16, 0.01 C) U(u16, 0.01 %) Vbat(u8) crc      PTU  (type 4 PTUX: the same, longer)
+//   01 02 lat(f32 deg) lon(f32 deg) alt(u16, m + 5000) nsat(u8) hh mm ss crc          GPS
+// little-endian fields, CRC big-endian.  Packets with a bad CRC are dropped.
+void SondeParser::feed_imet(const SondeFrame &f, std::vector<SondeData> &out)
+{
+	if (f.nerr[0] != 0 || f.len < 14) return;
+	const uint8_t *d = f.data;
+	SondeData sd;
+	memset(&sd, 0, sizeof(sd));
+	if (d[1] == 1 || d[1] == 4) {
+		sd.fields = DATA_SEQ | DATA_PTU;
+		sd.seq = (int)rd_u16(d + 2);
+		sd.pressure = (float)rd_u24(d + 4) / 100.0f;
+		sd.temp = (float)rd_i16(d + 7) / 100.0f;
+		sd.rh = (float)rd_u16(d + 9) / 100.0f;
+		sd.calib_percent = 100.0f;
+	} else if (d[1] == 2 && f.len >= 18) {
+		sd.fields = DATA_POS | DATA_TIME;
+		sd.lat = rd_f32(d + 2);
+		sd.lon = rd_f32(d + 6);
+		sd.alt = (float)rd_u16(d + 10) - 5000.0f;
+		sd.time = (time_t)(3600 * (int)d[13] + 60 * (int)d[14] + (int)d[15]);      // time of day only: no date on air
+	}
+	if (sd.fields) out.push_back(sd);
+}
+
 void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
 {
 	switch (f.type) {
 	case SONDE_RS41: feed_rs41(f, out); break;
 	case SONDE_DFM09: feed_dfm(f, out); break;
 	case SONDE_M10: feed_m10(f, out); break;
+	case SONDE_IMET4: feed_imet(f, out); break;
 	default: break;   // iMS-100: frames are delivered, field layout not implemented
 	}
 }

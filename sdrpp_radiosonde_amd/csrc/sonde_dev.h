@@ -27,6 +27,16 @@ struct SdModem {            // per sonde type, built on the host
 	int32_t itile;          // internal samples per 2048-sample input tile = 2048 / decim
 };
 
+#define SD_AF_DEC 8        // AFSK tone demodulator (SPEC 3.6): 48 kS/s -> 6 kS/s
+#define SD_AF_PER 480      // mixer table period: 17 cycles of 1700 Hz at 48 kS/s
+struct SdAfskState {        // tone-demodulator state, one per channel (64 B)
+	float    iq_last[2];    // previous IQ sample of the first discriminator
+	float    b[4][2];       // the four 8-sample block sums before the next one, oldest first
+	float    z[2];          // previous boxcar output
+	uint64_t n;             // input samples consumed (mixer phase = n mod 480)
+	uint32_t pad[2];
+};
+
 struct SdChanState {        // demodulator state, one per channel (64 B)
 	int64_t  t_next;        // Q16 absolute on-time instant of the next symbol
 	int64_t  n0;            // samples consumed

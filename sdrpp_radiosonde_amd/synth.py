@@ -568,7 +568,9 @@ def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int):
 
 def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
                device: str | torch.device = "cpu", first_channel: int = 0, invert: bool = False, **mod_kw) -> SynthBatch:
-    """Synthetic batch of any supported sonde type (0 RS41, 1 DFM09, 2 iMS-100, 3 M10)."""
+    """Synthetic batch of any supported sonde type (0 RS41, 1 DFM09, 2 iMS-100, 3 M10, 4 iMet-4)."""
+    if sonde_type == 4:
+        return make_imet_batch(n_channels, n_samples, seed=seed, snr_db=ebn0_db, device=device, first_channel=first_channel)
     if sonde_type == 0:
         return make_rs41_batch(n_channels, n_samples, seed=seed, ebn0_db=ebn0_db, device=device,
                                first_channel=first_channel, invert=invert, **mod_kw)
@@ -580,6 +582,116 @@ def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 
                                       ebn0_db=ebn0_db, device=device, invert=invert, **mod_kw)
     return SynthBatch(iq=iq, frames=frames, bits=chips, cfo_hz=cfo, tau=tau, amp=amp)
 
+
+# ================================================================ iMet-1 / iMet-4 (Bell-202 AFSK, asynchronous characters)
+# Protocol facts: public iMet notes ([RECALL]); independent of the decoders' code.
+IMET_BAUD = 1200.0
+IMET_MARK_HZ, IMET_SPACE_HZ = 1200.0, 2200.0
+
+
+def imet_crc(data: np.ndarray) -> int:
+    crc = 0x1D0F
+    for b in data.tolist():
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc
+
+
+def imet_true_values(channel: int, k: int):
+    """What packet pair k of a channel encodes: (pressure hPa, temperature C, humidity %, lat, lon, alt m, h, m, s)."""
+    alt = 1200.0 + 5.0 * k
+    return (1013.25 * math.exp(-alt / 8000.0), 15.0 - 0.0065 * alt, 40.0 + (channel % 30), 47.0 + 1e-3 * channel,
+            8.0 + 1e-4 * k, alt, 12, (k // 60) % 60, k % 60)
+
+
+def imet_build_packets(channel: int, k: int):
+    """[PTU packet, GPS packet] of second k (uint8 arrays, CRC included)."""
+    P, T, U, lat, lon, alt, hh, mm, ss = imet_true_values(channel, k)
+    ptu = bytearray([0x01, 0x01])
+    ptu += int(k & 0xFFFF).to_bytes(2, "little")
+    ptu += int(round(P * 100)).to_bytes(3, "little")
+    ptu += int(round(T * 100)).to_bytes(2, "little", signed=True)
+    ptu += int(round(U * 100)).to_bytes(2, "little")
+    ptu += bytes([52])                                       # 5.2 V
+    gps = bytearray([0x01, 0x02])
+    gps += np.asarray([lat, lon], dtype="<f4").tobytes()
+    gps += int(round(alt) + 5000).to_bytes(2, "little")
+    gps += bytes([9, hh, mm, ss])
+    out = []
+    for pkt in (ptu, gps):
+        a = np.frombuffer(bytes(pkt), dtype=np.uint8)
+        c = imet_crc(a)
+        out.append(np.concatenate([a, np.array([c >> 8, c & 0xFF], dtype=np.uint8)]))
+    return out
+
+
+def uart_bits(pkt: np.ndarray) -> np.ndarray:
+    """8N1 characters, LSB first: start 0, data, stop 1."""
+    b = np.zeros((len(pkt), 10), dtype=np.uint8)
+    b[:, 9] = 1
+    for m in range(8):
+        b[:, 1 + m] = (pkt >> m) & 1
+    return b.reshape(-1)
+
+
+def imet_bitstreams(seed: int, channels: np.ndarray, nbits: int):
+    """Per channel: idle marks, then PTU and GPS packets separated by short idle gaps.
+    Returns (bits [C, nbits], per channel list of (bit offset of the first start bit, packet bytes))."""
+    channels = np.asarray(channels, dtype=np.int64)
+    rng = np.random.Generator(np.random.Philox(key=(seed * 7907 + 29) & 0xFFFFFFFFFFFFFFFF))
+    bits = np.ones((len(channels), nbits + 2048), dtype=np.uint8)
+    frames = []
+    for ci, c in enumerate(channels):
+        pos = int(rng.integers(40, 200))
+        lst, k = [], 0
+        while pos < nbits:
+            for pkt in imet_build_packets(int(c), k):
+                ub = uart_bits(pkt)
+                bits[ci, pos: pos + len(ub)] = ub
+                if pos + len(ub) <= nbits:
+                    lst.append((pos, pkt))
+                pos += len(ub) + int(rng.integers(8, 48))
+            k += 1
+        frames.append(lst)
+    return bits[:, :nbits], frames
+
+
+def afsk_modulate(bits: np.ndarray, n_samples: int, *, seed: int = 0, snr_db: float = 30.0, fm_dev_hz: float = 3000.0,
+                  cfo_max_hz: float = 500.0, amp_range=(0.25, 1.0), device: str | torch.device = "cpu", fs: float = FS):
+    """bits (1 = mark) -> audio tones (phase-continuous 1200/2200 Hz at 1200 Bd) -> FM -> IQ [C, n_samples, 2].
+    snr_db: carrier-to-noise ratio in the full fs bandwidth."""
+    C, nbits = bits.shape
+    sps = fs / IMET_BAUD
+    assert nbits >= int(n_samples / sps) + 4
+    rng = np.random.Generator(np.random.Philox(key=(seed * 104723 + 7) & 0xFFFFFFFFFFFFFFFF))
+    cfo = rng.uniform(-cfo_max_hz, cfo_max_hz, size=C)
+    tau = rng.uniform(0.0, 1.0, size=C)
+    amp = rng.uniform(amp_range[0], amp_range[1], size=C)
+    gen = torch.Generator(device=device)
+    gen.manual_seed((seed * 31 + 3) & 0x7FFFFFFF)
+    n = torch.arange(n_samples, device=device, dtype=torch.float64)
+    out = torch.empty((C, n_samples, 2), dtype=torch.float32, device=device)
+    for c in range(C):
+        idx = torch.clamp(torch.floor(n / sps - tau[c]).to(torch.int64), 0, nbits - 1)
+        b = torch.from_numpy(bits[c].astype(np.float64)).to(device)[idx]
+        f_tone = b * IMET_MARK_HZ + (1.0 - b) * IMET_SPACE_HZ
+        audio = torch.cos(torch.cumsum(f_tone, dim=0) * (2.0 * math.pi / fs))
+        ph = torch.cumsum(fm_dev_hz * audio + cfo[c], dim=0) * (2.0 * math.pi / fs)
+        sig = amp[c] / math.sqrt(2.0 * 10.0 ** (snr_db / 10.0))
+        noise = torch.randn((n_samples, 2), generator=gen, device=device, dtype=torch.float32)
+        out[c, :, 0] = (amp[c] * torch.cos(ph)).to(torch.float32) + float(sig) * noise[:, 0]
+        out[c, :, 1] = (amp[c] * torch.sin(ph)).to(torch.float32) + float(sig) * noise[:, 1]
+    return out, cfo, tau, amp
+
+
+def make_imet_batch(n_channels: int, n_samples: int, *, seed: int = 1, snr_db: float = 30.0,
+                    device: str | torch.device = "cpu", first_channel: int = 0, **mod_kw) -> SynthBatch:
+    nbits = int(n_samples * IMET_BAUD / FS) + 16
+    channels = np.arange(first_channel, first_channel + n_channels)
+    bits, frames = imet_bitstreams(seed, channels, nbits)
+    iq, cfo, tau, amp = afsk_modulate(bits, n_samples, seed=seed + first_channel, snr_db=snr_db, device=device, **mod_kw)
+    return SynthBatch(iq=iq, frames=frames, bits=bits, cfo_hz=cfo, tau=tau, amp=amp)
 
 
 # ================================================================ wideband scene for the channelizer (config 4)
