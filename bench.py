@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--cpu-channels", type=int, default=0, help="channels of the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time spent on the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mix", action="store_true", help="BASELINE configs[2]: sonde type = (RS41, M10, DFM09)[channel % 3] (not the headline workload)")
     ap.add_argument("--stride-pad", type=int, default=0, help="experiment: extra samples between channels in HBM")
     ap.add_argument("--scatter", action="store_true", help="ingest on rank 0 and scatter IQ shards over RCCL before timing")
     args = ap.parse_args()
@@ -79,6 +80,13 @@ def main():
         torch.cuda.synchronize()
         scatter_ms = (time.perf_counter() - t0) * 1e3
         del full
+    elif args.mix:
+        order = (0, 3, 1)
+        types = np.array([order[c % 3] for c in range(C)], dtype=np.uint8)
+        iq = torch.empty((C, n, 2), dtype=torch.float32, device=dev)
+        for t in order:
+            idx = np.nonzero(types == t)[0]
+            iq[torch.from_numpy(idx).to(dev)] = synth.make_batch(int(t), len(idx), n, seed=1000 + rank + 10 * t, ebn0_db=args.ebn0 + 2.0, device=dev).iq
     else:
         iq = synth.make_rs41_batch(C, n, seed=1000 + rank, ebn0_db=args.ebn0, device=dev, first_channel=rank * C).iq
     if args.stride_pad:
@@ -87,7 +95,7 @@ def main():
         iq = padded[:, :n]
     torch.cuda.synchronize()
 
-    batch = SondeBatch(C, n, device=local_rank)
+    batch = SondeBatch(C, n, device=local_rank, types=types if args.mix else None)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -158,7 +166,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"RS41-SG x {C} channels/GPU x {n} samples (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)",
+        "config": {"workload": (f"RS41/M10/DFM09 by channel % 3 x {C} channels/GPU x {n} samples (48 kS/s)" if args.mix else
+                                f"RS41-SG x {C} channels/GPU x {n} samples (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)"),
                    "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{world}",
                    "ingest": "rccl-scatter" if scatter_ms is not None else "rank-local"},
         "frames_per_s": round(nfr_total * args.steps / dt, 1),
@@ -173,7 +182,7 @@ def main():
     if scatter_ms is not None:
         out["scatter_ms"] = round(scatter_ms, 3)
 
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.mix:
         # CPU baseline: the oracle (plain-C restatement, OpenMP over channels) on this host's cores, on a bounded
         # sample: whole passes over the same channels until >= --cpu-seconds of wall time have been spent
         import oracle_lib
