@@ -28,6 +28,28 @@ def test_crc_known_answer(oracle):
     assert synth.imet_crc(msg) == 0xE5CC
 
 
+def test_tone_demodulator_physics(oracle):
+    """A steady mark (1200 Hz) or space (2200 Hz) audio tone on the FM carrier must come out of the tone demodulator
+    as -/+ 500 Hz at 6 kS/s = -/+ 1/3 quadrant per sample (checked through the bit stream, the tap the oracle
+    exposes): alternating 25-symbol segments of the two tones give 25-bit runs, mark = slicer bit 0."""
+    n = G * 4
+    t = np.arange(n) / 48000.0
+    # the slicer centres itself on the data, so a steady tone alone has no reference: alternate the two tones instead
+    seg = 40 * 25                                  # 25 symbols per segment
+    f_inst = np.where((np.arange(n) // seg) % 2 == 0, 1200.0, 2200.0)
+    audio = np.cos(2 * np.pi * np.cumsum(f_inst) / 48000.0)
+    ph = 2 * np.pi * 3000.0 * np.cumsum(audio) / 48000.0
+    iq = np.stack([np.cos(ph), np.sin(ph)], axis=1).astype(np.float32)
+    ch = oracle.Channel(4, 0)
+    ch.feed(iq)
+    bits = ch.bits()[100:1100].astype(int)
+    runs = np.diff(np.nonzero(np.diff(bits))[0])
+    assert len(runs) >= 30 and abs(np.median(runs) - 25) <= 1          # 25-symbol runs of each tone
+    # mark (the first segment's tone, 1200 Hz) falls below the 1700 Hz mixer: negative frequency -> slicer bit 0
+    first = ch.bits()[5:15]
+    assert first.mean() < 0.5
+
+
 @pytest.mark.parametrize("snr", [30.0, 14.0])
 def test_oracle_decodes_generated_packets(oracle, snr):
     Cn, n = 4, G * 12
