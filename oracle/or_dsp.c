@@ -122,7 +122,7 @@ const OrModem *or_modem(int type)
  * each row normalised to unit DC gain.  H[p][j] = f(j - N/2 + p/P). */
 void or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS])
 {
-	const int nt = OR_NTAPS / m->decim;      /* taps in use: 16 at the decimated rate, 32 at 48 kS/s (same span in time) */
+	const int nt = OR_NT;                    /* taps in use: 16 at every internal rate (3.2 symbols at 5 samples/symbol) */
 	memset(taps, 0, sizeof(float) * OR_NPHASE * OR_NTAPS);
 	const double fc = (double)m->cutoff * m->baud / ((double)OR_FS / (m->decim * m->pre)); /* cycles per internal sample */
 	for (int p = 0; p < OR_NPHASE; p++) {
@@ -175,7 +175,7 @@ static inline float interp(const OrDemod *d, int64_t pos)
 	const int64_t n = pos >> 16;
 	const int p = (int)((pos >> 11) & (OR_NPHASE - 1));
 	/* even and odd taps accumulate separately (one v_pk_fma_f32 per tap pair on the GPU) */
-	const int nt = OR_NTAPS / d->m->decim;
+	const int nt = OR_NT;
 	float acc_e = 0.0f, acc_o = 0.0f;
 	for (int j = 0; j < nt; j += 2) {
 		acc_e = fmaf(d->taps[p][j], d->ring[(n + nt / 2 - j) & (OR_RING - 1)], acc_e);
@@ -201,7 +201,7 @@ static void push_bit(OrDemod *d, int b)
  * FIR support inside the data when a mid-tile correction moves the instants later. */
 static void run_rounds(OrDemod *d)
 {
-	const int64_t limit = (((d->n0 - 1 - (OR_NTAPS / d->m->decim) / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
+	const int64_t limit = (((d->n0 - 1 - OR_NT / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
 	float y[OR_ROUND_MAX], m[OR_ROUND_MAX];
 	int64_t K_total = (d->t_next <= limit) ? (limit - d->t_next) / d->period + 1 : 0;
 

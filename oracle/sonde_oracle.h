@@ -40,7 +40,8 @@ extern "C" {
 #define OR_FS          48000      /* decoder input rate, src/main.cpp:16 OUT_SAMPLE_RATE */
 #define OR_TILE        2048       /* samples per tile */
 #define OR_RING        4096       /* discriminator ring (floats) */
-#define OR_NTAPS       32         /* taps per polyphase branch */
+#define OR_NTAPS       32         /* row length of the polyphase table */
+#define OR_NT          16         /* taps in use per branch */
 #define OR_NPHASE      32         /* polyphase branches (1/32 sample resolution) */
 #define OR_ROUND_MAX   256        /* max symbols per timing-loop round */
 #define OR_LOOKAHEAD_MARGIN 4     /* samples of slack behind the newest sample */

@@ -49,7 +49,7 @@ static void make_taps(int type, float *out /* [32][32] */)
 {
 	const double PI = 3.14159265358979323846;
 	const double fc = (double)k_modems[type].cutoff * k_modems[type].baud / ((double)SD_FS / modem_div(type));
-	const int nt = SD_NTAPS / k_modems[type].decim;    // taps in use: 16 at the decimated rate, 32 at 48 kS/s
+	const int nt = SD_NT;                              // taps in use
 	memset(out, 0, sizeof(float) * SD_NPHASE * SD_NTAPS);
 	for (int p = 0; p < SD_NPHASE; p++) {
 		double h[SD_NTAPS], sum = 0.0;

@@ -77,7 +77,7 @@ __device__ __forceinline__ void store_one(DemodLds &s, int b, uint32_t i, float 
 // ascending (SPEC 3.2): one v_pk_fma_f32 per tap pair.  The tap rows are stored pair-swapped
 // (T[2i] = H[2i+1], T[2i+1] = H[2i]) so that they line up with the (d[x], d[x+1]) pairs.
 // rel = pos relative to A[0], Q16.
-template <int NT>   // taps in use: 32 at 48 kS/s, 16 at the decimated rate (same span in time)
+template <int NT>   // taps in use
 __device__ __forceinline__ float interp(const float *A, const float *B, const float *taps, uint32_t rel)
 {
 	const uint32_t top = (rel >> 16) + NT / 2;                          // buffer index of d for j = 0
@@ -223,13 +223,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (t < K) {
 			const int64_t base = (n0 - IT - SD_LH) << 16;
 			const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)t * (uint32_t)period;
-			if (dec2) {
-				y = interp<SD_NTAPS / 2>(s.A[b], s.B[b], s.taps, rel);
-				m = interp<SD_NTAPS / 2>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
-			} else {
-				y = interp<SD_NTAPS>(s.A[b], s.B[b], s.taps, rel);
-				m = interp<SD_NTAPS>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
-			}
+			y = interp<SD_NT>(s.A[b], s.B[b], s.taps, rel);
+			m = interp<SD_NT>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
 		}
 		const float yprev = __shfl_up(y, 1, 64);
 		const bool act = t < K;
@@ -352,7 +347,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				if (lead) {
 					if (pendK >= 0) round_back(pendK, par ^ 1);       // the previous round's update
 					if (r == 0) {
-						const int64_t limit = (((n0 - 1 - (SD_NTAPS / md.decim) / 2 - SD_MARGIN) << 16) | 0xFFFF);
+						const int64_t limit = (((n0 - 1 - SD_NT / 2 - SD_MARGIN) << 16) | 0xFFFF);
 						K_total = (st.t_next <= limit) ? (int)((uint32_t)(limit - st.t_next) / (uint32_t)st.period) + 1 : 0;
 					}
 					K = K_total > SD_ROUND_MAX ? SD_ROUND_MAX : K_total;

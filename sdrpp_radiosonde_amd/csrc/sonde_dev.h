@@ -9,7 +9,8 @@
 #define SD_FS         48000
 #define SD_TILE       2048        // samples per tile
 #define SD_RING       4096        // discriminator ring, floats (LDS)
-#define SD_NTAPS      32
+#define SD_NTAPS      32          // row length of the polyphase tap table
+#define SD_NT         16          // taps in use per row, at every internal rate (SPEC 3.2)
 #define SD_NPHASE     32
 #define SD_TAPS_LD    36          // padded leading dimension of the tap table in LDS (16-B aligned rows)
 #define SD_ROUND_MAX  256         // = workgroup size of the demod kernel
