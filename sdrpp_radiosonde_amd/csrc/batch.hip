@@ -290,6 +290,9 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	if (!b || !samples) return fail("sonde_batch_submit: null argument");
 	if (n_samples == 0 || n_samples % b->granule || n_samples > b->max_samples) return fail("sonde_batch_submit: n_samples must be a multiple of SONDE_TILE (16384 with iMet channels) and <= max_samples");
 	if (channel_stride < n_samples) return fail("sonde_batch_submit: channel_stride < n_samples");
+	// the kernels read 16 bytes per lane: every channel row must start on a 16-byte boundary
+	if (((uintptr_t)samples & 15u) || channel_stride % (b->input_kind == SONDE_INPUT_IQ ? 2 : 4))
+		return fail("sonde_batch_submit: samples must be 16-byte aligned and channel_stride a multiple of 2 (IQ) / 4 (real) samples");
 	HIPCHK(hipSetDevice(b->device));
 	hipStream_t stream = (hipStream_t)stream_;
 	const int n_tiles = (int)(n_samples / SONDE_TILE);

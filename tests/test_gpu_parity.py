@@ -164,3 +164,10 @@ def test_argument_errors_are_loud():
         b.submit(x[:, :1000].contiguous())                        # not a multiple of the tile
     with pytest.raises(Exception):
         b.submit(x[:1, : TILE * 4].contiguous())                  # wrong channel count
+    y = torch.zeros((2, TILE * 4 + 1, 2), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(Exception):
+        b.submit(y[:, : TILE * 4])                                # odd channel stride: rows not 16-byte aligned
+    with pytest.raises(Exception):
+        b.submit(y[:, 1: TILE * 4 + 1])                           # base pointer off by one sample (8 bytes)
+    b.submit(torch.zeros((2, TILE * 4, 2), dtype=torch.float32, device="cuda:0"))   # and a valid one still works
+    assert b.sync() == 0
