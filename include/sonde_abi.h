@@ -129,6 +129,11 @@ int  sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_sample
 long sonde_batch_sync(SondeBatch *b);
 /* Copy the last submit's frames to host memory, ordered by (channel, bitpos).  Returns count copied. */
 long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap);
+/* The decoded telemetry of the last submit as SondeData fragments (what the reference's per-channel X_decode loops
+ * would have returned, decoder.hpp:61), in (channel, time) order, with the channel each belongs to.  The engine keeps
+ * one stateful parser per channel.  Call repeatedly until it returns 0; fragments not fetched before the next
+ * submit's poll are kept and delivered first.  Returns the number written (<= cap) or a negative error. */
+long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t cap);
 /* Average device time (ms) of the demod and of the framer kernel over the submits since the previous
  * call of this function (at most the last 128), from HIP events recorded on the submit stream around
  * each launch.  Synchronises. */

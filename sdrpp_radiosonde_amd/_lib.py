@@ -48,7 +48,7 @@ class SondeBatchConfig(C.Structure):
 ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
     "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_kernel_ms", "sonde_batch_read_bits",
-    "sonde_batch_nbits", "sonde_batch_read_state", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
+    "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
     "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh",
     "sonde_last_error", "sonde_version", "sonde_hbm_read_probe", "sonde_dewpt", "sonde_altitude_to_pressure",
     "sonde_gpx_open", "sonde_gpx_close", "sonde_gpx_start_track", "sonde_gpx_stop_track", "sonde_gpx_add_point",
@@ -92,6 +92,8 @@ def load() -> C.CDLL:
                                          C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.sonde_get_taps.argtypes = [C.c_int, vp]
     L.sonde_parse_frame.argtypes = [vp, C.POINTER(SondeData), C.c_int]
+    L.sonde_batch_poll.argtypes = [vp, C.POINTER(SondeData), C.POINTER(C.c_uint32), C.c_size_t]
+    L.sonde_batch_poll.restype = C.c_long
     L.sonde_parser_create.argtypes = [C.c_int]
     L.sonde_parser_create.restype = vp
     L.sonde_parser_feed.argtypes = [vp, vp, C.POINTER(SondeData), C.c_int]

@@ -80,6 +80,20 @@ class SondeBatch:
             out = out[:got]
         return out
 
+    def poll(self, cap: int = 4096):
+        """SondeData fragments of the last submit with their channels: list of (channel, SondeData)."""
+        out = (_lib.SondeData * cap)()
+        chan = (C.c_uint32 * cap)()
+        res = []
+        while True:
+            n = self._chk(self.L.sonde_batch_poll(self.h, out, chan, cap))
+            if n == 0:
+                return res
+            for i in range(n):
+                d = _lib.SondeData()
+                C.memmove(C.byref(d), C.byref(out[i]), C.sizeof(d))
+                res.append((int(chan[i]), d))
+
     def kernel_ms(self):
         a, b = C.c_float(), C.c_float()
         self._chk(self.L.sonde_batch_kernel_ms(self.h, C.byref(a), C.byref(b)))

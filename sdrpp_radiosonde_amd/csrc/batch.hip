@@ -15,6 +15,9 @@
 #include "../../include/sonde_abi.h"
 
 #include "launch.h"
+#include "parse.h"
+#include <deque>
+#include <memory>
 
 static thread_local std::string g_err;
 static int fail(const char *what, hipError_t e = hipSuccess)
@@ -122,6 +125,10 @@ struct SondeBatch {
 	std::vector<uint32_t> h_counts;
 	std::vector<SondeFrame> h_slots;
 	long n_frames = 0;
+	// sonde_batch_poll: per-channel parsers (created on first use), fragments waiting to be fetched
+	std::vector<std::unique_ptr<SondeParser>> parsers;
+	std::deque<std::pair<uint32_t, SondeData>> frags;
+	bool polled = true;                    // the last submit's frames have been parsed
 };
 
 static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
@@ -339,6 +346,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	b->last_stream = stream;
 	b->pending = true;
 	b->have_counts = false;
+	b->polled = false;
 	return 0;
 }
 
@@ -409,6 +417,37 @@ extern "C" long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap)
 		hipError_t e = hipMemcpy(out + k, b->d_frames + (size_t)c * b->max_frames, take * sizeof(SondeFrame), hipMemcpyDeviceToHost);
 		if (e != hipSuccess) return fail("hipMemcpy frames", e);
 		k += take;
+	}
+	return (long)k;
+}
+
+extern "C" long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t cap)
+{
+	if (!b || !out || !channel) return fail("sonde_batch_poll: null argument");
+	if (!b->polled) {
+		const long n = sonde_batch_sync(b);
+		if (n < 0) return n;
+		std::vector<SondeFrame> fr((size_t)n);
+		const long got = n ? sonde_batch_frames(b, fr.data(), (size_t)n) : 0;
+		if (got < 0) return got;
+		if (b->parsers.empty()) b->parsers.resize(b->n_channels);
+		std::vector<SondeData> v;
+		for (long i = 0; i < got; i++) {
+			const uint32_t c = fr[(size_t)i].channel;
+			if (c >= b->n_channels) continue;
+			if (!b->parsers[c]) b->parsers[c].reset(new SondeParser((int)b->types[c]));
+			v.clear();
+			b->parsers[c]->feed(fr[(size_t)i], v);
+			for (const SondeData &d : v) b->frags.emplace_back(c, d);
+		}
+		b->polled = true;
+	}
+	size_t k = 0;
+	while (k < cap && !b->frags.empty()) {
+		channel[k] = b->frags.front().first;
+		out[k] = b->frags.front().second;
+		b->frags.pop_front();
+		k++;
 	}
 	return (long)k;
 }
