@@ -33,6 +33,33 @@ struct FullData {
 	std::string auxData;
 };
 
+// One fragment into the sticky aggregate, field group by field group (decoder.hpp:64-106), then the pressure
+// fall-back (decoder.hpp:108-110).  Returns whether the caller's callback is due (decoder.hpp:112).
+inline bool merge_fragment(FullData &m, const SondeData &f)
+{
+	if (f.fields & DATA_SEQ) m.seq = f.seq;
+	if (f.fields & DATA_POS) { m.lat = f.lat; m.lon = f.lon; m.alt = f.alt; }
+	if (f.fields & DATA_SPEED) { m.spd = f.speed; m.hdg = f.heading; m.climb = f.climb; }
+	if (f.fields & DATA_TIME) m.time = f.time;
+	if (f.fields & DATA_PTU) {
+		m.calib_percent = f.calib_percent;
+		m.calibrated = f.calib_percent >= 100.0f;
+		m.temp = f.temp;
+		m.rh = f.rh;
+		m.pressure = f.pressure;
+		m.dewpt = sonde_dewpt(f.temp, f.rh);
+	}
+	if (f.fields & DATA_SERIAL) m.serial = f.serial;
+	if (f.fields & DATA_SHUTDOWN) m.burstkill = f.shutdown;
+	if (f.fields & DATA_OZONE) {
+		char tmp[64];
+		snprintf(tmp, sizeof(tmp), "O3=%.2fmPa", (double)f.o3_mpa);
+		m.auxData = tmp;
+	}
+	if (m.pressure <= 0) m.pressure = sonde_altitude_to_pressure(m.alt);
+	return f.fields != 0;
+}
+
 template <typename T, T *(*decoder_init)(int), void (*decoder_deinit)(T *),
           ParserStatus (*decoder_get)(T *, SondeData *, const float *, size_t)>
 class Decoder {
@@ -66,9 +93,7 @@ public:
 		int fired = 0;
 		SondeData frag;
 		while (decoder_get(m_dec, &frag, buf, (size_t)count) != PROCEED) {
-			merge(frag);
-			if (m_data.pressure <= 0) m_data.pressure = sonde_altitude_to_pressure(m_data.alt);
-			if (frag.fields) {
+			if (merge_fragment(m_data, frag)) {
 				if (m_cb) m_cb(&m_data, m_ctx);
 				fired++;
 			}
@@ -79,33 +104,67 @@ public:
 	const FullData &data() const { return m_data; }
 
 private:
-	void merge(const SondeData &f)
-	{
-		if (f.fields & DATA_SEQ) m_data.seq = f.seq;
-		if (f.fields & DATA_POS) { m_data.lat = f.lat; m_data.lon = f.lon; m_data.alt = f.alt; }
-		if (f.fields & DATA_SPEED) { m_data.spd = f.speed; m_data.hdg = f.heading; m_data.climb = f.climb; }
-		if (f.fields & DATA_TIME) m_data.time = f.time;
-		if (f.fields & DATA_PTU) {
-			m_data.calib_percent = f.calib_percent;
-			m_data.calibrated = f.calib_percent >= 100.0f;
-			m_data.temp = f.temp;
-			m_data.rh = f.rh;
-			m_data.pressure = f.pressure;
-			m_data.dewpt = sonde_dewpt(f.temp, f.rh);
-		}
-		if (f.fields & DATA_SERIAL) m_data.serial = f.serial;
-		if (f.fields & DATA_SHUTDOWN) m_data.burstkill = f.shutdown;
-		if (f.fields & DATA_OZONE) {
-			char tmp[64];
-			snprintf(tmp, sizeof(tmp), "O3=%.2fmPa", (double)f.o3_mpa);
-			m_data.auxData = tmp;
-		}
-	}
-
 	T *m_dec = nullptr;
 	Callback m_cb = nullptr;
 	void *m_ctx = nullptr;
 	FullData m_data;
+};
+
+// The same for many channels at once, on top of the batch API: one sticky aggregate per channel, the callback gets
+// the channel index as well.  What a host with N narrowband channels on the GPU runs instead of N Decoder<> blocks.
+class BatchDecoder {
+public:
+	typedef void (*Callback)(uint32_t channel, FullData *data, void *ctx);
+
+	BatchDecoder() = default;
+	BatchDecoder(const BatchDecoder &) = delete;
+	BatchDecoder &operator=(const BatchDecoder &) = delete;
+	~BatchDecoder() { deinit(); }
+
+	bool init(const SondeBatchConfig &cfg, Callback cb, void *ctx)
+	{
+		deinit();
+		m_cb = cb;
+		m_ctx = ctx;
+		if (sonde_batch_create(&cfg, &m_batch) != 0) return false;
+		m_data = new FullData[cfg.n_channels];
+		return true;
+	}
+
+	void deinit()
+	{
+		if (m_batch) sonde_batch_destroy(m_batch);
+		m_batch = nullptr;
+		delete[] m_data;
+		m_data = nullptr;
+	}
+
+	// n_samples more samples of every channel (device pointer, channel-major).  Returns the callbacks made, < 0 on error.
+	long process(const void *d_samples, size_t n_samples, size_t channel_stride, void *stream = nullptr)
+	{
+		if (sonde_batch_submit(m_batch, d_samples, n_samples, channel_stride, stream) != 0) return -1;
+		long fired = 0, k;
+		SondeData frag[64];
+		uint32_t chan[64];
+		while ((k = sonde_batch_poll(m_batch, frag, chan, 64)) > 0) {
+			for (long i = 0; i < k; i++) {
+				if (merge_fragment(m_data[chan[i]], frag[i])) {
+					if (m_cb) m_cb(chan[i], &m_data[chan[i]], m_ctx);
+					fired++;
+				}
+			}
+		}
+		return k < 0 ? k : fired;
+	}
+
+	const FullData &data(uint32_t channel) const { return m_data[channel]; }
+	SondeBatch *batch() { return m_batch; }
+
+private:
+	SondeBatch *m_batch = nullptr;
+	FullData *m_data = nullptr;
+	Callback m_cb = nullptr;
+	void *m_ctx = nullptr;
 };
 
 }  // namespace sonde

@@ -85,3 +85,41 @@ def test_unimplemented_sondes_always_proceed():
         assert dec
         assert getattr(L, f"{name}_decode")(dec, C.byref(sd), buf.ctypes.data_as(C.c_void_p), 4096) == _lib.PROCEED
         getattr(L, f"{name}_decoder_deinit")(dec)
+
+
+def test_batch_decoder_cpp(tmp_path, oracle):
+    """sonde::BatchDecoder: the multi-channel counterpart of radiosonde::Decoder<> on top of sonde_batch_poll --
+    one sticky aggregate per channel, dew point and ISA pressure as decoder.hpp:84-110, callback per fragment."""
+    import os
+    import re
+    import subprocess
+    from sdrpp_radiosonde_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "batch_decoder_test")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "batch_decoder_test.cpp"), "-o", exe,
+                           "-L", libdir, "-l:libsonde_mi355.so", f"-Wl,-rpath,{libdir}"])
+    Cn, n = 3, 2048 * 96 * 5                      # ~20 s: enough frames for the calibration fragments 3..7 -> PTU
+    sb = synth.make_rs41_batch(Cn, n, seed=808, ebn0_db=30.0)
+    path = str(tmp_path / "iq.bin")
+    sb.iq.numpy().tofile(path)
+    out = subprocess.check_output([exe, path, str(Cn), str(n), "5"], text=True)
+    assert "ERROR" not in out, out[-2000:]
+    cbs = [l for l in out.splitlines() if l.startswith("CB ")]
+    done = [l for l in out.splitlines() if l.startswith("DONE")][0]
+    assert int(re.search(r"fired=(\d+)", done).group(1)) == len(cbs) >= 3 * 30 * Cn
+    last = {}
+    for l in cbs:
+        last[int(re.search(r"ch=(\d+)", l).group(1))] = l
+    L = oracle.lib()
+    for c in range(Cn):
+        l = last[c]
+        assert re.search(r"serial=(\S+)", l).group(1) == "S%07d" % c
+        temp, rh = float(re.search(r"temp=(\S+)", l).group(1)), float(re.search(r"rh=(\S+)", l).group(1))
+        alt = float(re.search(r" alt=(\S+)", l).group(1))
+        assert -60 < temp < 20 and 0 < rh <= 100                       # PTU arrived (calibration complete enough)
+        # RS41-SG carries no pressure: the aggregate holds the ISA value for the altitude at the time of the fall-back
+        assert float.fromhex(re.search(r"pressure=(\S+)", l).group(1)) > 0
+        dew = float.fromhex(re.search(r"dewpt=(\S+)", l).group(1))
+        assert abs(dew - float(L.or_dewpt(np.float32(temp), np.float32(rh)))) < 0.05 and alt > 900
