@@ -198,3 +198,36 @@ def test_poll_returns_the_fragments_of_every_channel(oracle):
         want = [int(f["data"][59]) | (int(f["data"][60]) << 8) for f in frs if f["channel"] == c and (f["nerr"] >= 0).all()]
         assert seqs[c] == want and len(want) >= 5
     assert kinds.get(_lib.DATA_TIME, 0) == kinds[_lib.DATA_SEQ | _lib.DATA_SERIAL] == kinds[_lib.DATA_POS | _lib.DATA_SPEED]
+
+
+def test_random_finite_garbage_matches_oracle(oracle):
+    """The arithmetic contract holds for any finite input whose products stay finite (|I|, |Q| < 1e18; NaN/Inf and
+    overflowing magnitudes are outside it): samples with log-uniform magnitudes over 36 decades, random
+    signs, exact zeros of both signs and denormals must give the oracle's bits and timing state."""
+    C_, n = 8, TILE * 24
+    rng = np.random.default_rng(2025)
+    mag = 10.0 ** rng.uniform(-18, 18, size=(C_, n, 2))
+    x = (mag * rng.choice([-1.0, 1.0], size=mag.shape)).astype(np.float32)
+    kind = rng.integers(0, 40, size=mag.shape)
+    x[kind == 0] = 0.0
+    x[kind == 1] = -0.0
+    x[kind == 2] = np.float32(1e-42)                 # denormal
+    x[kind == 3] = np.float32(-3e-45)
+    x[3] *= (np.abs(x[3]) < 1e3)                     # a channel that is mostly exact zeros with spikes
+    x[4, :, 1] = 0.0                                 # purely real samples: cross = +/-0 everywhere
+    x[5, :, 0] = -0.0
+    assert np.isfinite(x).all()
+    b = SondeBatch(C_, n)
+    b.submit(_dev(torch.from_numpy(x)))
+    got = b.frames()
+    chs = _oracle_channels(oracle, x)
+    ref = np.concatenate([ch.frames() for ch in chs])
+    assert got.tobytes() == ref.tobytes()
+    for c, ch in enumerate(chs):
+        rb = ch.bits()
+        assert b.nbits(c) == len(rb), c
+        assert np.array_equal(b.read_bits(c, 0, len(rb)), rb), c
+        st, rs = b.state(c), ch.state()
+        assert (st["t_next"], st["period"]) == (rs["t_next"], rs["period"]), c
+        for k in ("bias", "amp"):
+            assert np.float32(st[k]).tobytes() == np.float32(rs[k]).tobytes(), (c, k)
