@@ -162,6 +162,8 @@ void sonde_parser_destroy(SondeParserHandle *p);
  * counts f between the reference counts f1 < f2, calibration words from the sonde's table. */
 float sonde_rs41_temp(uint32_t f, uint32_t f1, uint32_t f2, float rf1, float rf2, const float co[3], const float cal[3]);
 float sonde_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float temp);
+/* DFM thermistor: measurement channel 0 against the reference channels 3 and 4 (already converted from 24-bit floats) */
+float sonde_dfm_temp(float f, float f1, float f2);
 
 /* ------------------------------------------------------------------ wideband front-end (BASELINE config 4)
  * 10 MS/s complex IQ -> 512-bin polyphase channelizer (19531.25 Hz spacing, 40 kS/s per bin) -> per-bin FM

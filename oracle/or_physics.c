@@ -73,3 +73,14 @@ float or_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float T)
 	if (T < -273.0f) rh = -1.0f;
 	return rh;
 }
+
+/* DFM thermistor temperature (public DFM-09 decoder formula, [RECALL]) */
+float or_dfm_temp(float f, float f1, float f2)
+{
+	const float B0 = 3260.0f, T0 = 25.0f + 273.15f, R0 = 5.0e3f, Rf = 220.0e3f;
+	if (f * f1 * f2 == 0.0f) return -273.15f;
+	const float g = f2 / Rf;
+	const float R = (f - f1) / g;
+	if (!(R > 0.0f)) return -273.15f;
+	return 1.0f / (1.0f / T0 + 1.0f / B0 * logf(R / R0)) - 273.15f;
+}

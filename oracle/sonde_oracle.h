@@ -153,6 +153,7 @@ float or_dewpt(float temp, float rh);
 float or_altitude_to_pressure(float alt);
 float or_rs41_temp(uint32_t f, uint32_t f1, uint32_t f2, float rf1, float rf2, const float *co, const float *cal);
 float or_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float T);
+float or_dfm_temp(float f, float f1, float f2);
 
 #ifdef __cplusplus
 }

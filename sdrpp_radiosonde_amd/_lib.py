@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
     "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_kernel_ms", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
-    "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh",
+    "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp",
     "sonde_last_error", "sonde_version", "sonde_hbm_read_probe", "sonde_dewpt", "sonde_altitude_to_pressure",
     "sonde_gpx_open", "sonde_gpx_close", "sonde_gpx_start_track", "sonde_gpx_stop_track", "sonde_gpx_add_point",
     "sonde_ptu_open", "sonde_ptu_close", "sonde_ptu_add_point",
@@ -104,6 +104,8 @@ def load() -> C.CDLL:
     L.sonde_rs41_temp.restype = C.c_float
     L.sonde_rs41_rh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
     L.sonde_rs41_rh.restype = C.c_float
+    L.sonde_dfm_temp.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.sonde_dfm_temp.restype = C.c_float
     L.sonde_dewpt.restype = C.c_float
     L.sonde_dewpt.argtypes = [C.c_float, C.c_float]
     L.sonde_altitude_to_pressure.restype = C.c_float

@@ -168,9 +168,41 @@ static long long days_from_civil(int y, int m, int d)
 // Each DAT block = 48 payload bits + sub-packet id nibble (ids per public DFM notes):
 //   0 frame counter, 1 UTC ms of minute, 2 lat (1e-7 deg) + ground speed (cm/s), 3 lon + heading (0.01 deg),
 //   4 altitude (cm) + climb (cm/s), 8 date/time.
+// DFM temperature (public DFM-09 decoders' formula, [RECALL]): the CONF block carries one measurement channel per
+// frame as a 24-bit float (20-bit mantissa / 2^exponent); channel 0 is the NTC thermistor, 3 and 4 the references.
+extern "C" float sonde_dfm_temp(float f, float f1, float f2)
+{
+	const float B0 = 3260.0f, T0 = 25.0f + 273.15f, R0 = 5.0e3f, Rf = 220.0e3f;
+	if (f * f1 * f2 == 0.0f) return -273.15f;
+	const float g = f2 / Rf;
+	const float R = (f - f1) / g;
+	if (!(R > 0.0f)) return -273.15f;
+	return 1.0f / (1.0f / T0 + 1.0f / B0 * logf(R / R0)) - 273.15f;
+}
+
 void SondeParser::feed_dfm(const SondeFrame &f, std::vector<SondeData> &out)
 {
 	if (f.len != 33 || f.nerr[1] != 0) return;       // a codeword with a detected double error poisons the frame
+	{	// CONF block: id nibble + 24-bit float
+		const int id = f.data[0] >> 4;
+		uint32_t v = 0;
+		for (int k = 1; k < 7; k++) v = (v << 4) | (uint32_t)(f.data[k] >> 4);
+		if (id <= 4) {
+			m_dfm_meas[id] = (float)(v & 0xFFFFFu) / (float)(1u << ((v >> 20) & 0xFu));
+			m_dfm_meas_mask |= 1u << id;
+		}
+		if (id == 0 && (m_dfm_meas_mask & 0x19u) == 0x19u) {
+			const float T = sonde_dfm_temp(m_dfm_meas[0], m_dfm_meas[3], m_dfm_meas[4]);
+			if (T > -270.0f) {
+				SondeData sd;
+				memset(&sd, 0, sizeof(sd));
+				sd.fields = DATA_PTU;
+				sd.temp = T;
+				sd.calib_percent = 100.0f;
+				out.push_back(sd);
+			}
+		}
+	}
 	for (int blk = 0; blk < 2; blk++) {
 		const uint8_t *cw = f.data + 7 + 13 * blk;
 		unsigned long long pay = 0;

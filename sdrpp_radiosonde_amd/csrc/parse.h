@@ -22,6 +22,8 @@ private:
 	double m_dfm_lat = 0, m_dfm_lon = 0, m_dfm_spd = 0, m_dfm_hdg = 0;
 	long long m_dfm_date = -1;        // seconds since epoch of the date+hh:mm part, -1 unknown
 	int m_dfm_have = 0;               // bit0 lat, bit1 lon
+	float m_dfm_meas[5] = {};         // CONF measurement channels 0..4
+	unsigned m_dfm_meas_mask = 0;
 };
 
 uint16_t sonde_crc16_ccitt(const uint8_t *p, size_t n);

@@ -367,6 +367,28 @@ def hamming84_encode(nib: np.ndarray) -> np.ndarray:
     return ((c0 << 7) | (c1 << 6) | (c2 << 5) | (c3 << 4) | (c4 << 3) | (c5 << 2) | (c6 << 1) | c7).astype(np.uint8)
 
 
+def dfm_true_temp(channel_ids, frame_idx):
+    return 12.0 - 0.03 * np.asarray(frame_idx, dtype=np.float64) - 0.01 * (np.asarray(channel_ids) % 50)
+
+
+DFM_F1, DFM_F2 = 1000.0, 45000.0          # reference channel readings (f1: offset, f2: gain reference, Rf = 220k)
+
+
+def dfm_meas_counts(T):
+    """Thermistor channel reading that sonde_dfm_temp maps back to T (deg C), with the fixed reference readings."""
+    B0, T0, R0, Rf = 3260.0, 25.0 + 273.15, 5.0e3, 220.0e3
+    R = R0 * np.exp(B0 * (1.0 / (np.asarray(T) + 273.15) - 1.0 / T0))
+    return DFM_F1 + R * (DFM_F2 / Rf), DFM_F1, DFM_F2
+
+
+def dfm_fl24(val):
+    """Encode positive values as mantissa(20 bits) / 2^exp(4 bits), the largest exponent that keeps the mantissa in range."""
+    val = np.asarray(val, dtype=np.float64)
+    e = np.clip(np.floor(np.log2((2 ** 20 - 1) / np.maximum(val, 1e-9))), 0, 15).astype(np.int64)
+    m = np.minimum(np.round(val * 2.0 ** e), 2 ** 20 - 1).astype(np.int64)
+    return (e << 20) | m
+
+
 def dfm_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray):
     """Returns (codewords [F,33] uint8, air bits [F,280])."""
     ch = np.asarray(channel_ids, dtype=np.int64)
@@ -376,6 +398,11 @@ def dfm_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray):
     # CONF: 7 nibbles: channel id nibble + 6 nibbles of (pseudo) sensor data
     nib[:, 0] = fi % 7
     conf = (seed * 2654435761 + ch * 40503 + fi * 9973) & 0xFFFFFF
+    # measurement channels as 24-bit floats (20-bit mantissa / 2^exponent): 0 = thermistor, 3 and 4 = references
+    f0, f3, f4 = dfm_meas_counts(dfm_true_temp(ch, fi))
+    conf = np.where(fi % 7 == 0, dfm_fl24(f0), conf)
+    conf = np.where(fi % 7 == 3, dfm_fl24(np.full(F, f3)), conf)
+    conf = np.where(fi % 7 == 4, dfm_fl24(np.full(F, f4)), conf)
     for k in range(6):
         nib[:, 1 + k] = (conf >> (4 * (5 - k))) & 0xF
     # DAT1/DAT2: 6 bytes + id nibble; ids cycle 0,1 | 2,3 | 4,8

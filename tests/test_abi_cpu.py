@@ -141,3 +141,34 @@ def test_rs41_conversions_equal_oracle_bit_for_bit(lib):
         a = np.float32(lib.sonde_rs41_rh(f, f1, f2, 45.0, T))
         b = np.float32(O.or_rs41_rh(f, f1, f2, 45.0, T))
         assert a.tobytes() == b.tobytes() and (0.0 <= a <= 100.0)
+
+
+def test_dfm_temperature_through_the_parser(lib):
+    """DFM: the CONF block delivers one measurement channel per frame (24-bit floats); temperature fragments start
+    once channels 0, 3 and 4 have been seen and match what the generator encoded; product == oracle bit for bit."""
+    import oracle_lib
+    from sdrpp_radiosonde_amd import synth
+    O = oracle_lib.lib()
+    nfr = 30
+    cw, _ = synth.dfm_build_frames(5, np.full(nfr, 9), np.arange(nfr))
+    Tt = synth.dfm_true_temp(np.full(nfr, 9), np.arange(nfr))
+    h = lib.sonde_parser_create(1)
+    out = (_lib.SondeData * 8)()
+    got = {}
+    for k in range(nfr):
+        f = _lib.SondeFrame()
+        f.type, f.len = 1, 33
+        C.memmove(f.data, cw[k].ctypes.data, 33)
+        n = lib.sonde_parser_feed(h, C.byref(f), out, 8)
+        for i in range(n):
+            if out[i].fields & _lib.DATA_PTU:
+                got[k] = out[i].temp
+    lib.sonde_parser_destroy(h)
+    assert sorted(got) == [7, 14, 21, 28]                      # CONF id 0 comes every 7th frame; the first one lacks refs
+    for k, T in got.items():
+        assert abs(T - Tt[k]) < 0.05, (k, T, Tt[k])
+    rng = np.random.default_rng(1)
+    for _ in range(500):
+        f1 = float(rng.uniform(500, 2000)); f2 = float(rng.uniform(30000, 60000)); f = f1 + float(rng.uniform(-10, 4e5))
+        a, b = np.float32(lib.sonde_dfm_temp(f, f1, f2)), np.float32(O.or_dfm_temp(f, f1, f2))
+        assert a.tobytes() == b.tobytes()
