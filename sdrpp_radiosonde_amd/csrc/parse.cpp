@@ -92,6 +92,11 @@ void SondeParser::feed_rs41(const SondeFrame &f, std::vector<SondeData> &out)
 			if (body[23] < 51) {
 				memcpy(m_calib + 16 * body[23], body + 24, 16);
 				m_calib_mask |= 1ull << body[23];
+				// burst-kill countdown: calibration word 0x316 (seconds, 0xFFFF = timer not armed) [RECALL: public RS41 notes]
+				if (body[23] == 0x31 && rd_u16(m_calib + 0x316) != 0xFFFFu) {
+					sd.fields |= DATA_SHUTDOWN;
+					sd.shutdown = (int)rd_u16(m_calib + 0x316);
+				}
 			}
 			break;
 		case 0x7C: { // GPS info: week, milliseconds of week

@@ -121,6 +121,8 @@ def rs41_calibration_memory(channel: int) -> np.ndarray:
     putf(0x4D, RS41_CO1); putf(0x59, RS41_CALT1)
     putf(0x75, [RS41_CALH0, 0.0])
     putf(0x125, RS41_CO1); putf(0x131, RS41_CALT1)
+    kill = 0xFFFF if channel % 2 == 0 else 3600 + channel          # burst-kill countdown (s); 0xFFFF = not armed
+    mem[0x316], mem[0x317] = kill & 0xFF, kill >> 8
     return mem
 
 

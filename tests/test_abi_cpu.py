@@ -98,13 +98,14 @@ def test_rs41_ptu_through_the_stateful_parser(lib):
     Tt, RHt = synth.rs41_true_ptu(np.full(nfr, 42), np.arange(nfr))
     h = lib.sonde_parser_create(0)
     out = (_lib.SondeData * 8)()
-    first_ptu, pct = None, []
+    first_ptu, pct, kills = None, [], []
     for k in range(nfr):
         f = _lib.SondeFrame()
         f.type, f.len = 0, 320
         C.memmove(f.data, frames[k].ctypes.data, 320)
         n = lib.sonde_parser_feed(h, C.byref(f), out, 8)
         ptu = [out[i] for i in range(n) if out[i].fields & _lib.DATA_PTU]
+        kills += [(k, out[i].shutdown) for i in range(n) if out[i].fields & _lib.DATA_SHUTDOWN]
         if ptu:
             if first_ptu is None:
                 first_ptu = k
@@ -113,6 +114,19 @@ def test_rs41_ptu_through_the_stateful_parser(lib):
             assert ptu[0].pressure == 0.0                      # RS41-SG: the adaptor falls back to the ISA model
             pct.append(ptu[0].calib_percent)
     lib.sonde_parser_destroy(h)
+    # channel 42 is even: burst-kill timer not armed -> no shutdown fragment; an odd channel reports its countdown
+    assert kills == []
+    fr43 = synth.rs41_build_frames(3, np.full(nfr, 43), np.arange(nfr))
+    h2 = lib.sonde_parser_create(0)
+    k43 = []
+    for k in range(nfr):
+        f = _lib.SondeFrame()
+        f.type, f.len = 0, 320
+        C.memmove(f.data, fr43[k].ctypes.data, 320)
+        n = lib.sonde_parser_feed(h2, C.byref(f), out, 8)
+        k43 += [(k, out[i].shutdown) for i in range(n) if out[i].fields & _lib.DATA_SHUTDOWN]
+    lib.sonde_parser_destroy(h2)
+    assert k43 == [((0x31 - 1000 % 51) % 51, 3643), ((0x31 - 1000 % 51) % 51 + 51, 3643)]
     # sequence numbers start at 1000 -> fragment index 1000 % 51 = 31; fragments 3..7 are complete 28 frames later
     assert first_ptu == (7 - 1000 % 51) % 51
     assert pct == sorted(pct) and abs(pct[-1] - 100.0) < 1e-3
