@@ -67,8 +67,14 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C sdrpp_radiosonde_amd/csrc` "
-                           "(or __graft_entry__.build()); there is no CPU fallback")
+        # a fresh checkout: build the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU); there is no
+        # CPU fallback -- if this fails, so does everything that needs the library
+        import subprocess
+        csrc = os.path.join(os.path.dirname(LIB_PATH), "csrc")
+        try:
+            subprocess.check_call(["make", "-s", "-C", csrc])
+        except (OSError, subprocess.CalledProcessError) as e:
+            raise RuntimeError(f"{LIB_PATH} is missing and `make -C {csrc}` failed ({e}); there is no CPU fallback") from e
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.sonde_hbm_read_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
