@@ -29,8 +29,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--ramp-ms", type=float, default=250.0,
+                    help="untimed submits for this long before the warmup steps: the GPU idles at 157 MHz and needs ~0.1 s of load "
+                         "to reach its 2.35 GHz working clock; a 3-step warmup (1 ms) measures the ramp, not the kernel")
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--tiles", type=int, default=96, help="2048-sample tiles per channel per step (96 = 4.096 s)")
     ap.add_argument("--ebn0", type=float, default=14.0)
@@ -104,6 +107,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_r = time.perf_counter()
+    while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:       # clock ramp (untimed, see --ramp-ms)
+        for _ in range(32):
+            batch.submit(iq, stream)
+        batch.sync()
     for _ in range(args.warmup):
         batch.submit(iq, stream)
     nfr_step = batch.sync()
@@ -160,6 +168,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "ramp_ms": args.ramp_ms,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
