@@ -186,7 +186,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "achievable_read": round(achievable, 1), "frac_of_achievable": round(achieved / achievable, 4),
-                     "algorithmic_bytes": alg_bytes, "kernel": "sd_demod_kernel<true, false>"},
+                     "algorithmic_bytes": alg_bytes, "kernel": "sd_demod_kernel<true, false, 4>"},
     }
     if scatter_ms is not None:
         out["scatter_ms"] = round(scatter_ms, 3)

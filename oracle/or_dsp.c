@@ -98,7 +98,7 @@ void or_discriminate(const float *iq, size_t n, float *d, float *last)
 /* ---- modem table.  Baud rates: SURVEY.md Appendix B [RECALL]; VFO bandwidths in
  * /root/reference/src/main.hpp:44-52 bound them from above. ---- */
 static const OrModem g_modems[OR_NTYPES] = {
-	{ OR_RS41,   4800.0, 0, 0.65f, 2, 1 },  /* RS41: 4800 Bd GFSK, NRZ */
+	{ OR_RS41,   4800.0, 0, 0.65f, 4, 1 },  /* RS41: 4800 Bd GFSK, NRZ; 12 kS/s internally (the reference's VFO is 10 kHz wide, main.hpp:45) */
 	{ OR_DFM09,  5000.0, 0, 0.65f, 2, 1 },  /* DFM: 2500 bit/s Manchester => 5000 chips/s */
 	{ OR_IMS100, 4800.0, 0, 0.65f, 2, 1 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
 	{ OR_M10,    9600.0, 0, 0.65f, 1, 1 },  /* M10/M20: 9600 chips/s Manchester: stays at 48 kS/s (5 samples/chip) */
@@ -122,7 +122,7 @@ const OrModem *or_modem(int type)
  * each row normalised to unit DC gain.  H[p][j] = f(j - N/2 + p/P). */
 void or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS])
 {
-	const int nt = OR_NT;                    /* taps in use: 16 at every internal rate (3.2 symbols at 5 samples/symbol) */
+	const int nt = OR_NT(m);                 /* taps in use: 3.2 symbols */
 	memset(taps, 0, sizeof(float) * OR_NPHASE * OR_NTAPS);
 	const double fc = (double)m->cutoff * m->baud / ((double)OR_FS / (m->decim * m->pre)); /* cycles per internal sample */
 	for (int p = 0; p < OR_NPHASE; p++) {
@@ -175,7 +175,7 @@ static inline float interp(const OrDemod *d, int64_t pos)
 	const int64_t n = pos >> 16;
 	const int p = (int)((pos >> 11) & (OR_NPHASE - 1));
 	/* even and odd taps accumulate separately (one v_pk_fma_f32 per tap pair on the GPU) */
-	const int nt = OR_NT;
+	const int nt = OR_NT(d->m);
 	float acc_e = 0.0f, acc_o = 0.0f;
 	for (int j = 0; j < nt; j += 2) {
 		acc_e = fmaf(d->taps[p][j], d->ring[(n + nt / 2 - j) & (OR_RING - 1)], acc_e);
@@ -201,7 +201,7 @@ static void push_bit(OrDemod *d, int b)
  * FIR support inside the data when a mid-tile correction moves the instants later. */
 static void run_rounds(OrDemod *d)
 {
-	const int64_t limit = (((d->n0 - 1 - OR_NT / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
+	const int64_t limit = (((d->n0 - 1 - OR_NT(d->m) / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
 	float y[OR_ROUND_MAX], m[OR_ROUND_MAX];
 	int64_t K_total = (d->t_next <= limit) ? (limit - d->t_next) / d->period + 1 : 0;
 
@@ -308,9 +308,9 @@ static void afsk_front(OrDemod *d, const float *src, size_t n_in, int is_iq, flo
 }
 
 /* One 2048-sample input tile at a time.  Stage K0 (SPEC 3.0): sondes whose symbol rate leaves room
- * (decim = 2: RS41, DFM, iMS-100) are first decimated 2:1 by a two-sample boxcar -- z[m] = x[2m] + x[2m+1]
- * on IQ, 0.5*(d[2m] + d[2m+1]) on real discriminator input -- so that the discriminator and everything
- * behind it run at 24 kS/s.  This is the reference's own ordering (the VFO hands dsp::demod::FM a stream
+ * are first decimated by a boxcar -- 4:1 for RS41 (z[m] = (x[4m] + x[4m+1]) + (x[4m+2] + x[4m+3]), 12 kS/s behind it),
+ * 2:1 for DFM and iMS-100 (z[m] = x[2m] + x[2m+1], 24 kS/s); real discriminator input is averaged the same way --
+ * so that the discriminator and everything behind it run at the lower rate.  This is the reference's own ordering (the VFO hands dsp::demod::FM a stream
  * at the channel bandwidth, 10 kS/s for RS41: /root/reference/src/main.cpp:55-57, src/main.hpp:45),
  * halves the arithmetic per input sample and lowers the FM threshold by narrowing the pre-detection
  * noise bandwidth.  M10 (9600 chips/s) stays at 48 kS/s. */
@@ -334,7 +334,13 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 	for (size_t off = 0; off + OR_TILE <= n; off += OR_TILE) {
 		if (is_iq) {
 			const float *x = src + 2 * off;
-			if (dec == 2) {
+			if (dec == 4) {
+				for (int m = 0; m < it; m++) {
+					z[2 * m] = (x[8 * m] + x[8 * m + 2]) + (x[8 * m + 4] + x[8 * m + 6]);
+					z[2 * m + 1] = (x[8 * m + 1] + x[8 * m + 3]) + (x[8 * m + 5] + x[8 * m + 7]);
+				}
+				or_discriminate(z, (size_t)it, tile, d->iq_last);
+			} else if (dec == 2) {
 				for (int m = 0; m < it; m++) {
 					z[2 * m] = x[4 * m] + x[4 * m + 2];
 					z[2 * m + 1] = x[4 * m + 1] + x[4 * m + 3];
@@ -345,7 +351,9 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 			}
 		} else {
 			const float *x = src + off;
-			if (dec == 2) {
+			if (dec == 4) {
+				for (int m = 0; m < it; m++) tile[m] = ((x[4 * m] + x[4 * m + 1]) + (x[4 * m + 2] + x[4 * m + 3])) * 0.25f;
+			} else if (dec == 2) {
 				for (int m = 0; m < it; m++) tile[m] = (x[2 * m] + x[2 * m + 1]) * 0.5f;
 			} else {
 				memcpy(tile, x, sizeof(float) * (size_t)it);

@@ -41,7 +41,7 @@ extern "C" {
 #define OR_TILE        2048       /* samples per tile */
 #define OR_RING        4096       /* discriminator ring (floats) */
 #define OR_NTAPS       32         /* row length of the polyphase table */
-#define OR_NT          16         /* taps in use per branch */
+#define OR_NT(m)       ((m)->decim == 4 ? 8 : 16)   /* taps in use per branch: 3.2 symbols (2.5 or 5 samples per symbol) */
 #define OR_NPHASE      32         /* polyphase branches (1/32 sample resolution) */
 #define OR_ROUND_MAX   256        /* max symbols per timing-loop round */
 #define OR_LOOKAHEAD_MARGIN 4     /* samples of slack behind the newest sample */
@@ -55,7 +55,7 @@ typedef struct {
 	double baud;        /* on-air symbol (chip) rate */
 	int    period0;     /* Q16 (internal-rate) samples per symbol = rint(65536*(FS/decim)/baud) */
 	float  cutoff;      /* low-pass cutoff, in units of baud */
-	int    decim;       /* 2: IQ is decimated 2:1 before the discriminator (internal rate 24 kS/s); 1: not */
+	int    decim;       /* IQ is decimated decim:1 (boxcar) before the discriminator: 4 RS41 (12 kS/s), 2 DFM / iMS-100 (24 kS/s), 1 M10 */
 	int    pre;         /* 8: AFSK sonde, the tone demodulator in front delivers FS/8 samples (SPEC 3.6); else 1 */
 } OrModem;
 

@@ -36,7 +36,7 @@ extern "C" const char *sonde_version(void) { return "sonde_mi355 0.1 (gfx950)"; 
 // bound them from above.
 struct ModemDef { double baud; float cutoff; int decim; int pre; };   // pre = 8: AFSK tone demodulator in front (SPEC 3.6)
 static const ModemDef k_modems[SONDE_NTYPES] = {
-	{ 4800.0, 0.65f, 2, 1 },   // RS41   4800 Bd GFSK NRZ; IQ decimated 2:1 before the discriminator (SPEC 3.0)
+	{ 4800.0, 0.65f, 4, 1 },   // RS41   4800 Bd GFSK NRZ; IQ decimated 4:1 before the discriminator: 12 kS/s (SPEC 3.0)
 	{ 5000.0, 0.65f, 2, 1 },   // DFM    2500 bit/s Manchester -> 5000 chips/s
 	{ 4800.0, 0.65f, 2, 1 },   // iMS100 2400 bit/s biphase    -> 4800 chips/s
 	{ 9600.0, 0.65f, 1, 1 },   // M10    9600 chips/s Manchester: stays at 48 kS/s (5 samples per chip)
@@ -52,7 +52,7 @@ static void make_taps(int type, float *out /* [32][32] */)
 {
 	const double PI = 3.14159265358979323846;
 	const double fc = (double)k_modems[type].cutoff * k_modems[type].baud / ((double)SD_FS / modem_div(type));
-	const int nt = SD_NT;                              // taps in use
+	const int nt = SD_NT(k_modems[type].decim);        // taps in use
 	memset(out, 0, sizeof(float) * SD_NPHASE * SD_NTAPS);
 	for (int p = 0; p < SD_NPHASE; p++) {
 		double h[SD_NTAPS], sum = 0.0;
@@ -113,8 +113,13 @@ struct SondeBatch {
 	// AFSK sondes (iMet): tone-demodulator state, mixer table, 6 kS/s scratch rows; the other channels' list for kernel A
 	SdAfskState *d_astates = nullptr;
 	float *d_wtab = nullptr, *d_afq = nullptr;
-	uint32_t *d_nonafsk = nullptr;
-	uint32_t n_nonafsk = 0;
+	// kernel A runs once per decimation class (1, 2, 4) of the non-AFSK channels: one class in the batch = one plain
+	// launch over all channels; several = one launch per class over its channel list
+	uint32_t *d_cls[3] = {};
+	uint32_t n_cls[3] = {};
+	int n_classes = 0, only_class = 0;
+	hipStream_t aux[3] = {};               // side streams so that the per-class launches of a mixed batch overlap
+	hipEvent_t ev_fork = nullptr, ev_join[3] = {};
 	uint32_t granule = SONDE_TILE;         // submit sizes must be a multiple of this
 
 	static const int kEvSlots = 128;       // submits timed between two sonde_batch_kernel_ms() calls
@@ -140,7 +145,9 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	if (b->pending) (void)hipStreamSynchronize(b->last_stream);
 	(void)hipFree(b->d_states); (void)hipFree(b->d_fstates); (void)hipFree(b->d_hist); (void)hipFree(b->d_bitring);
 	(void)hipFree(b->d_frames); (void)hipFree(b->d_counts); (void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
-	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); (void)hipFree(b->d_nonafsk);
+	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
+	for (int k = 0; k < 3; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
+	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
 	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfmulk); (void)hipFree(b->d_g64); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
@@ -206,16 +213,25 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
-	std::vector<uint32_t> nonafsk;
+	std::vector<uint32_t> cls[3];               // index: 0 -> decim 1, 1 -> decim 2, 2 -> decim 4
+	for (uint32_t c = 0; c < b->n_channels; c++) {
+		if (b->types[c] == SONDE_IMET4) continue;
+		const int d = k_modems[b->types[c]].decim;
+		cls[d == 4 ? 2 : d - 1].push_back(c);
+	}
+	for (int k = 0; k < 3; k++) {
+		b->n_cls[k] = (uint32_t)cls[k].size();
+		if (b->n_cls[k]) { b->n_classes++; b->only_class = k == 2 ? 4 : k + 1; }
+	}
+	const bool need_lists = n_afsk != 0 || b->n_classes > 1;
+	if (need_lists)
+		for (int k = 0; k < 3; k++) if (b->n_cls[k]) ALLOC(b->d_cls[k], cls[k].size() * sizeof(uint32_t));
 	if (n_afsk) {
 		if (cfg->max_samples % (SONDE_TILE * SD_AF_DEC)) { sonde_batch_destroy(b); return fail("sonde_batch_create: with iMet channels max_samples must be a multiple of 16384"); }
 		b->granule = SONDE_TILE * SD_AF_DEC;
 		ALLOC(b->d_astates, C * sizeof(SdAfskState));
 		ALLOC(b->d_wtab, SD_AF_PER * 2 * sizeof(float));
 		ALLOC(b->d_afq, n_afsk * (size_t)(cfg->max_samples / SD_AF_DEC) * sizeof(float));
-		for (uint32_t c = 0; c < b->n_channels; c++) if (b->types[c] != SONDE_IMET4) nonafsk.push_back(c);
-		b->n_nonafsk = (uint32_t)nonafsk.size();
-		if (b->n_nonafsk) ALLOC(b->d_nonafsk, nonafsk.size() * sizeof(uint32_t));
 	}
 #undef ALLOC
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { sonde_batch_destroy(b); return fail(#x, e_); } } while (0)
@@ -232,6 +248,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		modems[t].pmax = p0 + (p0 >> 8);
 		modems[t].decim = k_modems[t].decim;
 		modems[t].itile = SD_TILE / k_modems[t].decim;      // AFSK: kernel A sees the 6 kS/s stream as plain real input
+		modems[t].nt = SD_NT(k_modems[t].decim);
 		modems[t].rounds = ((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 > SD_ROUND_MAX) ? 2 : 1;
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -280,12 +297,20 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		sonde_get_afsk_table(wtab);
 		CHK(hipMemcpy(b->d_wtab, wtab, sizeof(wtab), hipMemcpyHostToDevice));
 		CHK(hipMemset(b->d_astates, 0, C * sizeof(SdAfskState)));
-		if (b->n_nonafsk) CHK(hipMemcpy(b->d_nonafsk, nonafsk.data(), nonafsk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
+	for (int k = 0; k < 3; k++)
+		if (b->d_cls[k]) CHK(hipMemcpy(b->d_cls[k], cls[k].data(), cls[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty())
 			CHK(hipMemcpy(b->d_chlist[t], b->chlist[t].data(), b->chlist[t].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) CHK(hipEventCreate(&b->ev[i]));
+	if (need_lists) {
+		CHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+		for (int k = 0; k < 3; k++) {
+			CHK(hipStreamCreateWithFlags(&b->aux[k], hipStreamNonBlocking));
+			CHK(hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming));
+		}
+	}
 #undef CHK
 	b->h_counts.assign(C, 0);
 	*out = b;
@@ -306,20 +331,32 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	HIPCHK(hipEventRecord(ev[0], stream));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
-	if (!n_afsk) {
-		sd_launch_demod(b->input_kind == SONDE_INPUT_IQ, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
+	const bool iq = b->input_kind == SONDE_INPUT_IQ;
+	if (!n_afsk && b->n_classes == 1) {
+		sd_launch_demod(iq, b->only_class, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems);
 	} else {
-		// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows
-		// (one kernel-A tile = 2048 scratch samples = 16384 input samples); everything else as usual
-		if (b->n_nonafsk)
-			sd_launch_demod(b->input_kind == SONDE_INPUT_IQ, b->n_nonafsk, stream, (const float *)samples, channel_stride, n_tiles,
-				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_nonafsk, false);
-		const size_t nq = n_samples / SD_AF_DEC;
-		sd_launch_afsk(b->input_kind == SONDE_INPUT_IQ, (uint32_t)n_afsk, stream, (const float *)samples, channel_stride, n_tiles,
-			b->d_chlist[SONDE_IMET4], b->d_astates, b->d_wtab, b->d_afq, nq);
-		sd_launch_demod(false, (uint32_t)n_afsk, stream, b->d_afq, nq, (int)(nq / SONDE_TILE),
-			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[SONDE_IMET4], true);
+		// fork: the class launches are independent (disjoint channels), let them share the GPU
+		HIPCHK(hipEventRecord(b->ev_fork, stream));
+		int used = 0;
+		for (int k = 0; k < 3; k++) {
+			if (!b->n_cls[k]) continue;
+			hipStream_t sk = used == 0 ? stream : b->aux[k];
+			if (sk != stream) HIPCHK(hipStreamWaitEvent(sk, b->ev_fork, 0));
+			sd_launch_demod(iq, k == 2 ? 4 : k + 1, b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
+				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_cls[k], false);
+			if (sk != stream) { HIPCHK(hipEventRecord(b->ev_join[k], sk)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[k], 0)); }
+			used++;
+		}
+		if (n_afsk) {
+			// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows
+			// (one kernel-A tile = 2048 scratch samples = 16384 input samples)
+			const size_t nq = n_samples / SD_AF_DEC;
+			sd_launch_afsk(iq, (uint32_t)n_afsk, stream, (const float *)samples, channel_stride, n_tiles,
+				b->d_chlist[SONDE_IMET4], b->d_astates, b->d_wtab, b->d_afq, nq);
+			sd_launch_demod(false, 1, (uint32_t)n_afsk, stream, b->d_afq, nq, (int)(nq / SONDE_TILE),
+				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[SONDE_IMET4], true);
+		}
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], stream));

@@ -103,7 +103,10 @@ __device__ __forceinline__ float interp(const float *A, const float *B, const fl
 // latency-bound chain (loop update -> FIR reads -> reduction).  Running them as different waves of the
 // same workgroup doubles the waves per SIMD and lets the hardware overlap them; the only hand-over is
 // the double-buffered LDS tile, one s_barrier per tile (two for sondes with > 256 symbols per tile).
-template <bool IS_IQ, bool LIST>      // LIST: work on the channels of `chlist` (mixed batches with AFSK sondes); the plain instantiation ignores it
+// LIST: work on the channels of `chlist` (mixed batches); the plain instantiation ignores it.  DEC: the decimation
+// factor of every channel of this launch (the host launches once per class), so that the three discriminator
+// variants do not share one register allocation.
+template <bool IS_IQ, bool LIST, int DEC>
 __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const SdModem md = modems[st.type];
 	const int rounds = md.rounds;          // sub-phases (= barriers) per tile: 1, or 2 for M10
 	const int IT = md.itile;               // internal samples per input tile: 1024 after 2:1 decimation, else 2048
-	const bool dec2 = md.decim == 2;
+	constexpr bool dec2 = DEC == 2, dec4 = DEC == 4;
 	const float *taps_g = taps_all + (size_t)st.type * SD_NPHASE * SD_NTAPS;
 	for (int i = tid; i < SD_NPHASE * SD_NTAPS; i += SD_WGT)
 		s.taps[(i >> 5) * SD_TAPS_LD + ((i & 31) ^ 1)] = taps_g[i];     // pair-swapped rows, see interp()
@@ -149,7 +152,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
 	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)row * ch_stride);
 	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
-	float4 pa, pb;                         // the float4 (two input samples) just before the wave's first one
+	float4 pa, pb, qa, qb;                 // the float4s (two input samples each) just before the wave's first one: -1 (pa, pb), -2 (qa, qb)
+	qa = qb = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
 	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);
 	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
 	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
@@ -157,25 +161,57 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const int kw = wave & 3;
 	auto f4_index = [&](int r) { return SD_WG / 4 * (NLD * kw + r) + lane; };      // float4 index inside the tile
 
-	auto load_tile = [&](int tile, float4 (&v)[NLD], float4 &pv) {
+	auto load_tile = [&](int tile, float4 (&v)[NLD], float4 &pv, float4 &pw) {
 #pragma unroll
 		for (int r = 0; r < NLD; r++) {                    // read-once data: streaming (nontemporal) loads
 			const sd_f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const sd_f32x4 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
 			v[r] = make_float4(q.x, q.y, q.z, q.w);
 		}
 		if (IS_IQ) {
-			// the float4 just before this wave's first one: a wave-uniform address, so a scalar load (no VGPRs,
-			// not counted by vmcnt); the very first one of the stream stands for the carried sample instead.
+			// the two float4s just before this wave's first one: wave-uniform addresses, so scalar loads (no VGPRs,
+			// not counted by vmcnt); at the very start of the stream they stand for the carried (decimated) sample.
 			// -0.0f is the additive identity for every float (+0 and -0 included), so k1_tile needs no case split
 			const long f4 = (long)tile * TILE_F4 + SD_WG / 4 * NLD * kw;
-			if (f4 > 0) pv = src[f4 - 1];
-			else pv = dec2 ? make_float4(st.iq_last[0], st.iq_last[1], -0.0f, -0.0f) : make_float4(0.0f, 0.0f, st.iq_last[0], st.iq_last[1]);
+			const float4 nz = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
+			if (f4 > 0) {
+				pv = src[f4 - 1];
+				if (dec4) pw = src[f4 - 2];
+			} else {
+				pv = (dec2 || dec4) ? make_float4(st.iq_last[0], st.iq_last[1], -0.0f, -0.0f) : make_float4(0.0f, 0.0f, st.iq_last[0], st.iq_last[1]);
+				pw = nz;
+			}
 		}
 	};
 	// K0+K1: (2:1 boxcar decimation,) d[n] = atan2q(z[n] * conj(z[n-1])), straight into buffer b
-	auto k1_tile = [&](int b, const float4 (&v)[NLD], const float4 &pv) {
+	auto k1_tile = [&](int b, const float4 (&v)[NLD], const float4 &pv, const float4 &pw) {
 		// lane 0's predecessor (decimated) sample; after each load: lane 63's last sample
-		float cx = dec2 ? pv.x + pv.z : pv.z, cy = dec2 ? pv.y + pv.w : pv.w;
+		float cx = dec4 ? (pw.x + pw.z) + (pv.x + pv.z) : (dec2 ? pv.x + pv.z : pv.z);
+		float cy = dec4 ? (pw.y + pw.w) + (pv.y + pv.w) : (dec2 ? pv.y + pv.w : pv.w);
+		if (IS_IQ && dec4) {
+			// 4:1: a decimated sample spans two adjacent float4s, which the coalesced loads put into adjacent LANES.
+			// The per-float4 partial sums of two loads go through a wave-private LDS scratch (128 float2) and come back
+			// as one 16-byte read per lane: lane l gets the partials of float4s 2l and 2l+1, i.e. decimated sample l of
+			// the 64 this pair of loads holds.  (The scratch sits in the part of A[0] a 512-sample tile never uses.)
+			float2 *scr = reinterpret_cast<float2 *>(&s.A[0][1024]) + 128 * kw;
+#pragma unroll
+			for (int g = 0; g < NLD / 2; g++) {
+				scr[lane] = make_float2(v[2 * g].x + v[2 * g].z, v[2 * g].y + v[2 * g].w);
+				scr[64 + lane] = make_float2(v[2 * g + 1].x + v[2 * g + 1].z, v[2 * g + 1].y + v[2 * g + 1].w);
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				const float4 q = *reinterpret_cast<const float4 *>(&scr[2 * lane]);
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				const float zx = q.x + q.z, zy = q.y + q.w;
+				float px = __shfl_up(zx, 1, 64), py = __shfl_up(zy, 1, 64);
+				if (lane == 0) { px = cx; py = cy; }
+				store_one(s, b, (uint32_t)(128 * kw + 64 * g + lane), sd_disc(zx, zy, px, py));
+				cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zx), 63));
+				cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zy), 63));
+			}
+			last_iq = make_float2(cx, cy);
+			return;
+		}
 #pragma unroll
 		for (int r = 0; r < NLD; r++) {
 			const uint32_t fi = (uint32_t)f4_index(r);
@@ -197,6 +233,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 					cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[r].z), 63));
 					cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[r].w), 63));
 				}
+			} else if (dec4) {
+				// real input, 4:1: one float4 = one decimated sample
+				store_one(s, b, fi, ((v[r].x + v[r].y) + (v[r].z + v[r].w)) * 0.25f);
 			} else if (dec2) {
 				// real input: average pairs, 4 inputs -> 2 consecutive decimated samples
 				store_pair(s, b, 2u * fi, (v[r].x + v[r].y) * 0.5f, (v[r].z + v[r].w) * 0.5f);
@@ -223,8 +262,13 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (t < K) {
 			const int64_t base = (n0 - IT - SD_LH) << 16;
 			const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)t * (uint32_t)period;
-			y = interp<SD_NT>(s.A[b], s.B[b], s.taps, rel);
-			m = interp<SD_NT>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+			if (dec4) {                                       // 2.5 samples per symbol: 8 taps = 3.2 symbols
+				y = interp<8>(s.A[b], s.B[b], s.taps, rel);
+				m = interp<8>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+			} else {
+				y = interp<16>(s.A[b], s.B[b], s.taps, rel);
+				m = interp<16>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+			}
 		}
 		const float yprev = __shfl_up(y, 1, 64);
 		const bool act = t < K;
@@ -307,10 +351,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// ---- the two roles run separate loops (so that neither carries the other's live registers) with the
 	// same number of s_barriers: one after the prologue, then `rounds` per tile.  is_k is wave-uniform.
 	if (is_k) {
-		load_tile(0, va, pa);
-		if (n_tiles > 1) load_tile(1, vb, pb);
-		k1_tile(0, va, pa);
-		if (n_tiles > 2) load_tile(2, va, pa);
+		load_tile(0, va, pa, qa);
+		if (n_tiles > 1) load_tile(1, vb, pb, qb);
+		k1_tile(0, va, pa, qa);
+		if (n_tiles > 2) load_tile(2, va, pa, qa);
 		__syncthreads();
 		// phase `tile`: tile+1 goes from registers into the other LDS buffer, tile+3 is requested from HBM
 		// (two phases of latency budget); the loop is unrolled by two so the register sets are static
@@ -318,16 +362,16 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			if (tile + 1 < n_tiles) {
 				if (t < SD_LH) s.A[1][t] = s.A[0][IT + t];            // history roll into the other buffer
 				else if (t < 2 * SD_LH - 1) s.B[1][t - SD_LH] = s.B[0][IT + t - SD_LH];
-				k1_tile(1, vb, pb);
-				if (tile + 3 < n_tiles) load_tile(tile + 3, vb, pb);
+				k1_tile(1, vb, pb, qb);
+				if (tile + 3 < n_tiles) load_tile(tile + 3, vb, pb, qb);
 			}
 			for (int r = 0; r < rounds; r++) __syncthreads();
 			if (tile + 1 >= n_tiles) break;
 			if (tile + 2 < n_tiles) {
 				if (t < SD_LH) s.A[0][t] = s.A[1][IT + t];
 				else if (t < 2 * SD_LH - 1) s.B[0][t - SD_LH] = s.B[1][IT + t - SD_LH];
-				k1_tile(0, va, pa);
-				if (tile + 4 < n_tiles) load_tile(tile + 4, va, pa);
+				k1_tile(0, va, pa, qa);
+				if (tile + 4 < n_tiles) load_tile(tile + 4, va, pa, qa);
 			}
 			for (int r = 0; r < rounds; r++) __syncthreads();
 		}
@@ -347,7 +391,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				if (lead) {
 					if (pendK >= 0) round_back(pendK, par ^ 1);       // the previous round's update
 					if (r == 0) {
-						const int64_t limit = (((n0 - 1 - SD_NT / 2 - SD_MARGIN) << 16) | 0xFFFF);
+						const int64_t limit = (((n0 - 1 - md.nt / 2 - SD_MARGIN) << 16) | 0xFFFF);
 						K_total = (st.t_next <= limit) ? (int)((uint32_t)(limit - st.t_next) / (uint32_t)st.period) + 1 : 0;
 					}
 					K = K_total > SD_ROUND_MAX ? SD_ROUND_MAX : K_total;
@@ -384,7 +428,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	}
 }
 
-void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
+void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in)
@@ -392,9 +436,14 @@ void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
 	const dim3 g(n_channels), blk(SD_WGT);
 	const int ci = compact_in ? 1 : 0;
 #define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci
-	if (is_iq && !chlist) hipLaunchKernelGGL((sd_demod_kernel<true, false>), g, blk, 0, stream, SD_DEMOD_ARGS);
-	else if (is_iq) hipLaunchKernelGGL((sd_demod_kernel<true, true>), g, blk, 0, stream, SD_DEMOD_ARGS);
-	else if (!chlist) hipLaunchKernelGGL((sd_demod_kernel<false, false>), g, blk, 0, stream, SD_DEMOD_ARGS);
-	else hipLaunchKernelGGL((sd_demod_kernel<false, true>), g, blk, 0, stream, SD_DEMOD_ARGS);
+#define SD_DEMOD_LAUNCH(IQ, LS) do { \
+		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 4>), g, blk, 0, stream, SD_DEMOD_ARGS); \
+		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 2>), g, blk, 0, stream, SD_DEMOD_ARGS); \
+		else hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 1>), g, blk, 0, stream, SD_DEMOD_ARGS); } while (0)
+	if (is_iq && !chlist) SD_DEMOD_LAUNCH(true, false);
+	else if (is_iq) SD_DEMOD_LAUNCH(true, true);
+	else if (!chlist) SD_DEMOD_LAUNCH(false, false);
+	else SD_DEMOD_LAUNCH(false, true);
+#undef SD_DEMOD_LAUNCH
 #undef SD_DEMOD_ARGS
 }

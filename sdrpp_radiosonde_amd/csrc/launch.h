@@ -6,7 +6,8 @@
 
 // chlist: null = channels 0..n_channels-1 read their own row of `in`; else block i works on channel chlist[i] and reads
 // row chlist[i] (compact_in = false: the caller's buffer) or row i (compact_in = true: a per-list scratch buffer)
-void sd_launch_demod(bool is_iq, uint32_t n_channels, hipStream_t stream,
+// decim: the decimation factor (1, 2, 4) of EVERY channel this launch works on
+void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist = nullptr, bool compact_in = false);

@@ -10,7 +10,7 @@
 #define SD_TILE       2048        // samples per tile
 #define SD_RING       4096        // discriminator ring, floats (LDS)
 #define SD_NTAPS      32          // row length of the polyphase tap table
-#define SD_NT         16          // taps in use per row, at every internal rate (SPEC 3.2)
+#define SD_NT(decim)  ((decim) == 4 ? 8 : 16)   // taps in use per row: 3.2 symbols (SPEC 3.2)
 #define SD_NPHASE     32
 #define SD_TAPS_LD    36          // padded leading dimension of the tap table in LDS (16-B aligned rows)
 #define SD_ROUND_MAX  256         // = workgroup size of the demod kernel
@@ -24,8 +24,9 @@ struct SdModem {            // per sonde type, built on the host
 	float   ki;             // integral gain
 	int32_t pmin, pmax;     // period clamp
 	int32_t rounds;         // timing-loop rounds per tile: 1, or 2 when a tile can hold > 256 symbols (M10)
-	int32_t decim;          // 2: IQ decimated 2:1 before the discriminator (internal rate 24 kS/s), 1: not (SPEC 3.0)
+	int32_t decim;          // IQ boxcar-decimated decim:1 before the discriminator: 4 RS41 (12 kS/s), 2 DFM / iMS-100, 1 M10 (SPEC 3.0)
 	int32_t itile;          // internal samples per 2048-sample input tile = 2048 / decim
+	int32_t nt;             // taps in use per polyphase row: 3.2 symbols = 8 (2.5 samples per symbol) or 16 (5)
 };
 
 #define SD_AF_DEC 8        // AFSK tone demodulator (SPEC 3.6): 48 kS/s -> 6 kS/s

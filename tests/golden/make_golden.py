@@ -20,7 +20,7 @@ import oracle_lib  # noqa: E402
 
 C, TILES = 3, 34
 n = 2048 * TILES
-sb = synth.make_rs41_batch(C, n, seed=2024, ebn0_db=13.0, amp_range=(0.5, 0.9))
+sb = synth.make_rs41_batch(C, n, seed=2024, ebn0_db=11.0, amp_range=(0.5, 0.9))
 q = np.clip(np.round(sb.iq.numpy() * 100.0), -127, 127).astype(np.int8)       # 8-bit capture
 iq = q.astype(np.float32) / np.float32(100.0)
 chs, bits, states = [], [], []

@@ -92,10 +92,12 @@ def test_real_input_equals_oracle(oracle):
     chs = _oracle_channels(oracle, d, is_iq=False)
     ref = np.concatenate([ch.frames() for ch in chs])
     assert len(ref) >= C and got.tobytes() == ref.tobytes()
-    # and identical to the IQ path (discriminator inside the kernel)
+    # the IQ path (decimation before the discriminator) is a different signal path: same frames, positions within a bit
     b2 = SondeBatch(C, n)
     b2.submit(_dev(sb.iq))
-    assert b2.frames().tobytes() == got.tobytes()
+    got2 = b2.frames()
+    assert len(got2) == len(got) and np.array_equal(got2["data"], got["data"]) and np.array_equal(got2["nerr"], got["nerr"])
+    assert np.abs(got2["bitpos"].astype(np.int64) - got["bitpos"].astype(np.int64)).max() <= 2
 
 
 def test_inverted_polarity_and_extended_frames(oracle):

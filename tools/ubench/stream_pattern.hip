@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void sweep(const f4 *src, size_t n16, float *s
 
 // one workgroup per channel; LOADERS of the WG's waves read, each step = STEP_F4 float4 per channel
 // DEPTH register sets in flight; BAR: s_barrier per step; NT: nontemporal
-template <int WG, int LOADERS, int DEPTH, bool BAR, bool NT>
+template <int WG, int LOADERS, int DEPTH, bool BAR, bool NT, bool PAIR = false>
 __global__ __launch_bounds__(WG) void streams(const f4 *src, size_t ch_f4, int steps, float *sink)
 {
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(WG) void streams(const f4 *src, size_t ch_f4, int s
 		for (int d = 0; d < DEPTH; d++)
 #pragma unroll
 			for (int r = 0; r < NLD; r++) {
-				const f4 *a = p + (size_t)d * STEP_F4 + 64 * (NLD * kw + r) + lane;
+				const f4 *a = PAIR ? p + (size_t)d * STEP_F4 + 64 * NLD * kw + 128 * (r >> 1) + 2 * lane + (r & 1)
+				                   : p + (size_t)d * STEP_F4 + 64 * (NLD * kw + r) + lane;
 				v[d][r] = NT ? __builtin_nontemporal_load(a) : *a;
 			}
 		for (int s = 0; s < steps; s += DEPTH) {
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(WG) void streams(const f4 *src, size_t ch_f4, int s
 				if (s + d + DEPTH < steps) {
 #pragma unroll
 					for (int r = 0; r < NLD; r++) {
-						const f4 *a = p + (size_t)(s + d + DEPTH) * STEP_F4 + 64 * (NLD * kw + r) + lane;
+						const f4 *a = PAIR ? p + (size_t)(s + d + DEPTH) * STEP_F4 + 64 * NLD * kw + 128 * (r >> 1) + 2 * lane + (r & 1)
+						                   : p + (size_t)(s + d + DEPTH) * STEP_F4 + 64 * (NLD * kw + r) + lane;
 						v[d][r] = NT ? __builtin_nontemporal_load(a) : *a;
 					}
 				}
@@ -93,6 +95,9 @@ int main()
 	rep("streams wg384 load4 depth3 bar nt", timeit([&] { streams<384, 4, 3, true, true><<<C, 384>>>(buf, ch_f4, steps, sink); }));
 	rep("streams wg384 load4 depth4 bar nt", timeit([&] { streams<384, 4, 4, true, true><<<C, 384>>>(buf, ch_f4, steps, sink); }));
 	rep("streams wg512 load4 depth3 bar nt", timeit([&] { streams<512, 4, 3, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
+	rep("streams wg512 load4 depth2 bar nt PAIR", timeit([&] { streams<512, 4, 2, true, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
+	rep("streams wg512 load4 depth2 bar    PAIR", timeit([&] { streams<512, 4, 2, true, false, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
+	rep("streams wg512 load4 depth2 bar nt (again)", timeit([&] { streams<512, 4, 2, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
 	rep("streams wg512 load2 depth2 bar nt", timeit([&] { streams<512, 2, 2, true, true><<<C, 512>>>(buf, ch_f4, steps, sink); }));
 	return 0;
 }
