@@ -205,8 +205,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_counts, C * sizeof(uint32_t));
 	ALLOC(b->d_taps, (size_t)SONDE_NTYPES * SD_NPHASE * SD_NTAPS * sizeof(float));
 	ALLOC(b->d_modems, SONDE_NTYPES * sizeof(SdModem));
-	ALLOC(b->d_gfexp, 512);
-	ALLOC(b->d_gflog, 256);
+	ALLOC(b->d_gfexp, 2304);      // zero-absorbing antilog table of the RS decoder (GF_EXP2 in framer_kernel.hip)
+	ALLOC(b->d_gflog, 512);       // 256 x u16 logarithms, log 0 = 768
 	ALLOC(b->d_gfmulk, 24 * 256);
 	ALLOC(b->d_g64, 192);
 	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
@@ -261,8 +261,14 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		for (int i = 0; i < 255; i++) { gexp[i] = (uint8_t)x; glog[x] = (uint8_t)i; x <<= 1; if (x & 0x100) x ^= 0x11D; }
 		for (int i = 255; i < 512; i++) gexp[i] = gexp[i - 255];
 	}
-	CHK(hipMemcpy(b->d_gfexp, gexp, 512, hipMemcpyHostToDevice));
-	CHK(hipMemcpy(b->d_gflog, glog, 256, hipMemcpyHostToDevice));
+	{	// log domain without zero tests: log 0 = 768 (above any sum of valid logs), antilog periodic below 768, zero above
+		std::vector<uint8_t> e2(2304, 0);
+		for (int i = 0; i < 768; i++) e2[i] = gexp[i % 255];
+		uint16_t l2[256];
+		for (int v = 0; v < 256; v++) l2[v] = v ? (uint16_t)glog[v] : (uint16_t)768;
+		CHK(hipMemcpy(b->d_gfexp, e2.data(), e2.size(), hipMemcpyHostToDevice));
+		CHK(hipMemcpy(b->d_gflog, l2, sizeof(l2), hipMemcpyHostToDevice));
+	}
 	{	// mulk[j][v] = v * alpha^j for the 24 syndrome roots
 		std::vector<uint8_t> mulk(24 * 256);
 		for (int j = 0; j < 24; j++)

@@ -26,7 +26,7 @@
 // on-air RS41 header 10 B6 CA 11 22 96 12 F8, LSB-first bit order => little-endian u64
 #define RS41_SYNC64 0xF812962211CAB610ull
 
-__constant__ uint8_t c_rs41_mask[64] = {
+__constant__ __attribute__((aligned(4))) uint8_t c_rs41_mask[64] = {
 	0x96, 0x83, 0x3E, 0x51, 0xB1, 0x49, 0x08, 0x98, 0x32, 0x05, 0x59, 0x0E, 0xF9, 0x44, 0xC6, 0x26,
 	0x21, 0x60, 0xC2, 0xEA, 0x79, 0x5D, 0x6D, 0xA1, 0x54, 0x69, 0x47, 0x0C, 0xDC, 0xE8, 0x5C, 0xF1,
 	0xF7, 0x76, 0x82, 0x7F, 0x07, 0x99, 0xA2, 0x2C, 0x93, 0x7C, 0x30, 0x63, 0xF5, 0x10, 0x2E, 0x61,
@@ -45,11 +45,11 @@ __constant__ uint8_t c_rs41_mask[64] = {
 #define GF_EXP2  (3 * GF_LZ)
 struct FramerTabs {                // shared by the waves of a workgroup
 	uint8_t  mulk[RS_R * 256];     // mulk[j][v] = v * alpha^j : one dependent lookup per Horner step
-	uint8_t  exp2[GF_EXP2];        // alpha^(i mod 255) for i < GF_LZ, 0 above
-	uint16_t log2[256];            // log2[0] = GF_LZ
+	alignas(16) uint8_t  exp2[GF_EXP2];        // alpha^(i mod 255) for i < GF_LZ, 0 above
+	alignas(16) uint16_t log2[256];            // log2[0] = GF_LZ
 };
 struct FramerLds {                 // one per wave (= per frame)
-	uint8_t frame[SONDE_FRAME_MAX];
+	alignas(4) uint8_t frame[SONDE_FRAME_MAX];
 	alignas(4) uint8_t cw[2][256];
 	uint16_t logS[2][RS_R];        // logarithms of the syndromes
 	uint8_t  lam[2][RS_R + 2];
@@ -395,8 +395,11 @@ __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 		const uint4 *src = reinterpret_cast<const uint4 *>(gf_mulk);
 		uint4 *dst = reinterpret_cast<uint4 *>(tabs.mulk);
 		for (int i = tid; i < RS_R * 256 / 16; i += 64 * B2_WAVES) dst[i] = src[i];
-		for (int i = tid; i < GF_EXP2; i += 64 * B2_WAVES) tabs.exp2[i] = i < GF_LZ ? gf_exp[i % 255] : (uint8_t)0;
-		tabs.log2[tid] = tid ? (uint16_t)gf_log[tid] : (uint16_t)GF_LZ;          // 256 threads, 256 entries
+		// antilog (zero-absorbing, GF_EXP2 bytes) and log (256 x u16) tables as the host laid them out: plain copies
+		const uint4 *se = reinterpret_cast<const uint4 *>(gf_exp);
+		uint4 *de = reinterpret_cast<uint4 *>(tabs.exp2);
+		for (int i = tid; i < GF_EXP2 / 16; i += 64 * B2_WAVES) de[i] = se[i];
+		if (tid < 512 / 16) reinterpret_cast<uint4 *>(tabs.log2)[tid] = reinterpret_cast<const uint4 *>(gf_log)[tid];
 	}
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
@@ -409,9 +412,19 @@ __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 	const SdFrameDesc d = descs[(size_t)ch * max_frames + k];
 	const int flen = d.flen;
 	const uint8_t xinv = d.inv ? 0xFF : 0x00;
-	// K5: extract + de-whiten
-	for (int i = lane; i < flen; i += 64)
-		s.frame[i] = (uint8_t)(byte_at(ring, mask, d.fstart + 8 * (uint64_t)i) ^ xinv ^ c_rs41_mask[i & 63]);
+	// K5: extract + de-whiten, four bytes per lane and step (the frame lengths are even, the word past the end
+	// is written whole and never read beyond flen)
+	{
+		const uint32_t winv = d.inv ? 0xFFFFFFFFu : 0u;
+		const uint32_t *mask32 = reinterpret_cast<const uint32_t *>(c_rs41_mask);
+		uint32_t *frame32 = reinterpret_cast<uint32_t *>(s.frame);
+		for (int i = lane; 4 * i < flen; i += 64) {
+			const uint64_t p = d.fstart + 32ull * (uint64_t)i;
+			const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+			const uint64_t lo = (uint64_t)ring[w & mask] | ((uint64_t)ring[(w + 1) & mask] << 32);
+			frame32[i] = (uint32_t)(lo >> sh) ^ winv ^ mask32[i & 15];
+		}
+	}
 	WAVE_SYNC();
 	// K6: de-interleave into two shortened codewords
 	const int msglen = (flen - 56) / 2;
@@ -445,9 +458,9 @@ __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 		fr->bitpos = d.fstart;
 	}
 	for (int i = lane; i < SONDE_FRAME_MAX / 4; i += 64) {
-		const int b = 4 * i;
-		uint32_t wd = 0;
-		for (int q = 0; q < 4; q++) wd |= (uint32_t)(b + q < flen ? s.frame[b + q] : 0) << (8 * q);
+		const int rem = flen - 4 * i;                            // bytes of this word inside the frame
+		uint32_t wd = rem > 0 ? reinterpret_cast<const uint32_t *>(s.frame)[i] : 0u;
+		if (rem > 0 && rem < 4) wd &= (1u << (8 * rem)) - 1u;
 		reinterpret_cast<uint32_t *>(fr->data)[i] = wd;
 	}
 }
