@@ -248,3 +248,24 @@ def test_oracle_decodes_other_sondes(oracle, stype, ebn0):
     assert exact >= (sent - C if ebn0 > 20 else 0.5 * sent)
     if ebn0 < 20 and stype != 3:
         assert (fr["nerr"][:, 0] > 0).any()       # Hamming / BCH corrections happen
+
+
+@pytest.mark.parametrize("ppm,cfo", [(100.0, 500.0), (-100.0, 500.0), (0.0, 2000.0), (200.0, 1500.0)])
+def test_tracking_range_clock_and_carrier_offsets(oracle, ppm, cfo):
+    """The timing loop must follow a sonde whose symbol clock is off by +-100..200 ppm (its period clamp is +-0.39 %)
+    and the slicer a carrier offset of a few kHz (a DC term behind the discriminator): every frame still decodes."""
+    C, n = 4, 2048 * 96
+    baud = 4800.0 * (1.0 + ppm * 1e-6)
+    nbits = int(n * baud / 48000.0) + 16
+    bits, frames = synth.rs41_bitstreams(31, np.arange(C), nbits)
+    iq, *_ = synth.gfsk_modulate(bits, n, baud, seed=31, ebn0_db=20.0, cfo_max_hz=cfo)
+    fr = oracle.batch_run(0, iq.numpy(), nthreads=4)
+    sent = sum(len(f) for f in frames)
+    good = sum(1 for f in fr if (f["nerr"] >= 0).all() and
+               any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in frames[f["channel"]]))
+    assert good >= sent - C, (good, sent)
+    for c in range(C):
+        ch = oracle.Channel(0, c)
+        ch.feed(iq.numpy()[c])
+        want = 163840.0 / (1.0 + ppm * 1e-6)
+        assert abs(ch.state()["period"] - want) < 40, (ch.state()["period"], want)     # the loop found the clock
