@@ -109,7 +109,12 @@ typedef struct {
 	uint32_t       max_samples;      /* largest samples-per-channel of one submit (multiple of SONDE_TILE) */
 	int32_t        input_kind;       /* SONDE_INPUT_IQ or SONDE_INPUT_REAL */
 	int32_t        device;           /* HIP device ordinal */
+	uint32_t       flags;            /* SONDE_FLAG_*; 0 = defaults */
 } SondeBatchConfig;
+
+/* RS41 channels: decimate IQ 2:1 instead of 4:1 before the discriminator (24 kS/s internally): tolerates +-5 kHz of carrier
+ * offset instead of +-1 kHz, at about 2 dB of sensitivity and twice the discriminator arithmetic.  IQ input only. */
+#define SONDE_FLAG_RS41_WIDE 1u
 
 typedef struct SondeBatch SondeBatch;
 

@@ -97,7 +97,7 @@ void or_discriminate(const float *iq, size_t n, float *d, float *last)
 
 /* ---- modem table.  Baud rates: SURVEY.md Appendix B [RECALL]; VFO bandwidths in
  * /root/reference/src/main.hpp:44-52 bound them from above. ---- */
-static const OrModem g_modems[OR_NTYPES] = {
+static OrModem g_modems[OR_NTYPES] = {
 	{ OR_RS41,   4800.0, 0, 0.65f, 4, 1 },  /* RS41: 4800 Bd GFSK, NRZ; 12 kS/s internally (the reference's VFO is 10 kHz wide, main.hpp:45) */
 	{ OR_DFM09,  5000.0, 0, 0.65f, 2, 1 },  /* DFM: 2500 bit/s Manchester => 5000 chips/s */
 	{ OR_IMS100, 4800.0, 0, 0.65f, 2, 1 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
@@ -107,6 +107,14 @@ static const OrModem g_modems[OR_NTYPES] = {
 	{ OR_MRZN1,  2400.0, 0, 0.65f, 2, 1 },
 };
 static OrModem g_modem_rt[OR_NTYPES];
+
+/* test hook for configuration flags of the product (SONDE_FLAG_RS41_WIDE: RS41 at 2:1): affects demodulators created afterwards */
+void or_modem_set_decim(int type, int decim)
+{
+	if (type < 0 || type >= OR_NTYPES) return;
+	g_modems[type].decim = decim;
+	g_modem_rt[type].period0 = 0;
+}
 
 const OrModem *or_modem(int type)
 {
@@ -246,6 +254,10 @@ static void run_rounds(OrDemod *d)
 			}
 			if (!(d->amp >= 1.0e-3f)) d->amp = 1.0e-3f;
 			d->nstat = 1;
+		} else {
+			/* one-sided round (a carrier offset larger than the deviation puts every sample on one side of the
+			 * threshold): no level estimate; move the threshold to the mean so that the next round sees both levels */
+			d->bias = ((float)(S1 + S0) * or_recip((float)K)) * (1.0f / 4096.0f);
 		}
 		float err = ((float)E * or_recip((float)K)) * (1.0f / 1024.0f);
 		err = err * or_recip(d->amp * d->amp);

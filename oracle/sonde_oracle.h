@@ -78,6 +78,7 @@ void  or_discriminate(const float *iq, size_t n, float *d, float *last);
 /* ---- stage 2: GFSK demod (sondedump gfsk.c equivalent; SPEC) ---- */
 void  or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS]);
 const OrModem *or_modem(int type);
+void  or_modem_set_decim(int type, int decim);   /* test hook: the product's SONDE_FLAG_RS41_WIDE */
 
 typedef struct OrDemod OrDemod;
 OrDemod *or_demod_new(int type);

@@ -41,7 +41,10 @@ class SondeData(C.Structure):
 
 class SondeBatchConfig(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("types", C.POINTER(C.c_uint8)), ("max_samples", C.c_uint32),
-                ("input_kind", C.c_int32), ("device", C.c_int32)]
+                ("input_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+FLAG_RS41_WIDE = 1
 
 
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them

@@ -45,14 +45,14 @@ static const ModemDef k_modems[SONDE_NTYPES] = {
 	{ 2400.0, 0.65f, 2, 1 },   // MRZ-N1  (not implemented)
 };
 
-static int modem_div(int type) { return k_modems[type].decim * k_modems[type].pre; }     // input samples per internal sample
-static int32_t modem_period0(int type) { return (int32_t)llrint(65536.0 * ((double)SD_FS / modem_div(type)) / k_modems[type].baud); }
+static int modem_div(const ModemDef *md, int type) { return md[type].decim * md[type].pre; }     // input samples per internal sample
+static int32_t modem_period0(const ModemDef *md, int type) { return (int32_t)llrint(65536.0 * ((double)SD_FS / modem_div(md, type)) / md[type].baud); }
 
-static void make_taps(int type, float *out /* [32][32] */)
+static void make_taps(const ModemDef *md, int type, float *out /* [32][32] */)
 {
 	const double PI = 3.14159265358979323846;
-	const double fc = (double)k_modems[type].cutoff * k_modems[type].baud / ((double)SD_FS / modem_div(type));
-	const int nt = SD_NT(k_modems[type].decim);        // taps in use
+	const double fc = (double)md[type].cutoff * md[type].baud / ((double)SD_FS / modem_div(md, type));
+	const int nt = SD_NT(md[type].decim);              // taps in use
 	memset(out, 0, sizeof(float) * SD_NPHASE * SD_NTAPS);
 	for (int p = 0; p < SD_NPHASE; p++) {
 		double h[SD_NTAPS], sum = 0.0;
@@ -84,7 +84,7 @@ extern "C" int sonde_get_afsk_table(float *out /* [480][2] */)
 extern "C" int sonde_get_taps(int type, float *out)
 {
 	if (type < 0 || type >= SONDE_NTYPES || !out) return fail("sonde_get_taps: bad argument");
-	make_taps(type, out);
+	make_taps(k_modems, type, out);
 	return 0;
 }
 
@@ -96,6 +96,7 @@ struct SondeBatch {
 	uint32_t type_frames[SONDE_NTYPES] = {};   // upper bound of complete frames per submit, per sonde type (B2 grid)
 	std::vector<uint8_t> types;
 	std::vector<uint32_t> chlist[SONDE_NTYPES];
+	ModemDef md[SONDE_NTYPES];             // this batch's modem table (k_modems, with the configuration flags applied)
 
 	SdChanState *d_states = nullptr;
 	SdFramerState *d_fstates = nullptr;
@@ -171,6 +172,9 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	b->max_samples = cfg->max_samples;
 	b->input_kind = cfg->input_kind;
 	b->device = cfg->device;
+	for (int t = 0; t < SONDE_NTYPES; t++) b->md[t] = k_modems[t];
+	if ((cfg->flags & SONDE_FLAG_RS41_WIDE) && cfg->input_kind == SONDE_INPUT_IQ) b->md[SONDE_RS41].decim = 2;
+	const ModemDef *md = b->md;
 	b->types.assign(cfg->n_channels, SONDE_RS41);
 	if (cfg->types) b->types.assign(cfg->types, cfg->types + cfg->n_channels);
 	uint64_t max_bits = 0;
@@ -178,8 +182,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		const int t = b->types[c];
 		if (t < 0 || t >= SONDE_NTYPES) { delete b; return fail("sonde_batch_create: bad sonde type"); }
 		b->chlist[t].push_back(c);
-		const int32_t p = modem_period0(t) - (modem_period0(t) >> 8);      // fastest symbol clock the loop allows
-		max_bits = std::max(max_bits, ((uint64_t)(cfg->max_samples / modem_div(t)) << 16) / (uint64_t)p + 2);
+		const int32_t p = modem_period0(md, t) - (modem_period0(md, t) >> 8);      // fastest symbol clock the loop allows
+		max_bits = std::max(max_bits, ((uint64_t)(cfg->max_samples / modem_div(md, t)) << 16) / (uint64_t)p + 2);
 	}
 	b->ring_words = pow2ceil((uint32_t)((max_bits + 8 * SONDE_FRAME_MAX + 1024 + 31) / 32));
 	b->max_frames = 2;
@@ -187,8 +191,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		static const uint32_t min_frame_bits[SONDE_NTYPES] = { 320 * 8, 560, 1152, 1648, 140, 1u << 30, 1u << 30 };
 		for (int t = 0; t < SONDE_NTYPES; t++) {
 			if (b->chlist[t].empty()) continue;
-			const int32_t p = modem_period0(t) - (modem_period0(t) >> 8);
-			const uint64_t bits_t = ((uint64_t)(cfg->max_samples / modem_div(t)) << 16) / (uint64_t)p + 2;
+			const int32_t p = modem_period0(md, t) - (modem_period0(md, t) >> 8);
+			const uint64_t bits_t = ((uint64_t)(cfg->max_samples / modem_div(md, t)) << 16) / (uint64_t)p + 2;
 			b->type_frames[t] = (uint32_t)(bits_t / min_frame_bits[t]) + 2;
 			b->max_frames = std::max(b->max_frames, b->type_frames[t]);
 		}
@@ -216,7 +220,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	std::vector<uint32_t> cls[3];               // index: 0 -> decim 1, 1 -> decim 2, 2 -> decim 4
 	for (uint32_t c = 0; c < b->n_channels; c++) {
 		if (b->types[c] == SONDE_IMET4) continue;
-		const int d = k_modems[b->types[c]].decim;
+		const int d = md[b->types[c]].decim;
 		cls[d == 4 ? 2 : d - 1].push_back(c);
 	}
 	for (int k = 0; k < 3; k++) {
@@ -239,16 +243,16 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	std::vector<float> taps((size_t)SONDE_NTYPES * SD_NPHASE * SD_NTAPS);
 	SdModem modems[SONDE_NTYPES];
 	for (int t = 0; t < SONDE_NTYPES; t++) {
-		make_taps(t, &taps[(size_t)t * SD_NPHASE * SD_NTAPS]);
-		const int32_t p0 = modem_period0(t);
+		make_taps(md, t, &taps[(size_t)t * SD_NPHASE * SD_NTAPS]);
+		const int32_t p0 = modem_period0(md, t);
 		modems[t].period0 = p0;
 		modems[t].kp = (float)p0 * 0.159154943f;       // half of 1/pi symbol per unit error
 		modems[t].ki = modems[t].kp * (1.0f / 4096.0f);
 		modems[t].pmin = p0 - (p0 >> 8);
 		modems[t].pmax = p0 + (p0 >> 8);
-		modems[t].decim = k_modems[t].decim;
-		modems[t].itile = SD_TILE / k_modems[t].decim;      // AFSK: kernel A sees the 6 kS/s stream as plain real input
-		modems[t].nt = SD_NT(k_modems[t].decim);
+		modems[t].decim = md[t].decim;
+		modems[t].itile = SD_TILE / md[t].decim;      // AFSK: kernel A sees the 6 kS/s stream as plain real input
+		modems[t].nt = SD_NT(md[t].decim);
 		modems[t].rounds = ((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 > SD_ROUND_MAX) ? 2 : 1;
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -333,6 +333,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			}
 			if (!(st.amp >= 1.0e-3f)) st.amp = 1.0e-3f;
 			st.nstat = 1;
+		} else {
+			// one-sided round (carrier offset larger than the deviation): no level estimate; move the threshold to the
+			// mean of the round so that the next one sees both levels (SPEC 3.2)
+			st.bias = ((float)(S1 + S0) * sd_recip((float)K)) * (1.0f / 4096.0f);
 		}
 		const f32x2 den = {(float)K, st.amp * st.amp};
 		const f32x2 rd = sd_recip2(den);

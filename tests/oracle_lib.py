@@ -87,6 +87,7 @@ def lib():
     L.or_rs41_rh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
     L.or_dfm_temp.restype = C.c_float
     L.or_dfm_temp.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.or_modem_set_decim.argtypes = [C.c_int, C.c_int]
     L.or_afsk_table.argtypes = [f32p]
     L.or_imet_crc.restype = C.c_uint16
     L.or_imet_crc.argtypes = [C.POINTER(C.c_uint8), C.c_size_t]

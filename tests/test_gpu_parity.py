@@ -233,3 +233,34 @@ def test_random_finite_garbage_matches_oracle(oracle):
         assert (st["t_next"], st["period"]) == (rs["t_next"], rs["period"]), c
         for k in ("bias", "amp"):
             assert np.float32(st[k]).tobytes() == np.float32(rs[k]).tobytes(), (c, k)
+
+
+def test_rs41_wide_mode(oracle):
+    """SONDE_FLAG_RS41_WIDE: RS41 at 2:1 instead of 4:1 (24 kS/s internally) -- bit-exact against the oracle set the same
+    way, and it decodes a carrier 4 kHz off centre, which the default (12 kS/s, like the reference's 10 kHz VFO) cannot."""
+    from sdrpp_radiosonde_amd._lib import FLAG_RS41_WIDE
+    C_, n = 6, TILE * 60
+    nbits = int(n * 4800 / 48000) + 16
+    bits, frames = synth.rs41_bitstreams(61, np.arange(C_), nbits)
+    iq, *_ = synth.gfsk_modulate(bits, n, 4800.0, seed=61, ebn0_db=20.0, cfo_max_hz=0.0)
+    t = np.arange(n) / 48000.0
+    z = (iq.numpy()[..., 0] + 1j * iq.numpy()[..., 1]) * np.exp(2j * np.pi * 4000.0 * t)[None, :]
+    x = np.ascontiguousarray(np.stack([z.real, z.imag], axis=-1).astype(np.float32))
+    narrow = SondeBatch(C_, n)
+    narrow.submit(_dev(torch.from_numpy(x)))
+    assert len(narrow.frames()) == 0                                 # 4 kHz off: outside the default path's +-1 kHz
+    wide = SondeBatch(C_, n, flags=FLAG_RS41_WIDE)
+    wide.submit(_dev(torch.from_numpy(x)))
+    got = wide.frames()
+    L = oracle.lib()
+    L.or_modem_set_decim(0, 2)
+    try:
+        ref = oracle.batch_run(0, x, nthreads=4)
+    finally:
+        L.or_modem_set_decim(0, 4)
+    assert got.tobytes() == ref.tobytes()
+    sent = sum(len(f) for f in frames)
+    good = [f for f in got if (f["nerr"] >= 0).all()]
+    assert len(good) >= sent - 2 * C_
+    for f in good:
+        assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in frames[f["channel"]])
