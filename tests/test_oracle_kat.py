@@ -269,3 +269,27 @@ def test_tracking_range_clock_and_carrier_offsets(oracle, ppm, cfo):
         ch.feed(iq.numpy()[c])
         want = 163840.0 / (1.0 + ppm * 1e-6)
         assert abs(ch.state()["period"] - want) < 40, (ch.state()["period"], want)     # the loop found the clock
+
+
+def test_robustness_modulation_index_onset_and_level(oracle):
+    """The demodulator must not care about the modulation index (0.5..1.6), about when the signal appears (noise
+    first), or about a 40 dB level step in mid-stream (FM: the level is irrelevant)."""
+    C, n = 4, 2048 * 96
+    nbits = int(n * 4800 / 48000) + 16
+    bits, frames = synth.rs41_bitstreams(71, np.arange(C), nbits)
+    sent = sum(len(f) for f in frames)
+    for h in (0.5, 1.6):
+        iq, *_ = synth.gfsk_modulate(bits, n, 4800.0, seed=71, ebn0_db=18.0, h=h)
+        fr = oracle.batch_run(0, iq.numpy(), nthreads=4)
+        assert int((fr["nerr"] >= 0).all(axis=1).sum()) >= sent - C, h
+    iq, *_ = synth.gfsk_modulate(bits, n, 4800.0, seed=71, ebn0_db=18.0)
+    x = iq.numpy().copy()
+    k = 72000
+    x[:, :k, :] = 0.1 * np.random.default_rng(1).standard_normal((C, k, 2)).astype(np.float32)
+    fr = oracle.batch_run(0, x, nthreads=4)
+    late = [f for f in fr if f["bitpos"] > k / 10 + 300 and (f["nerr"] >= 0).all()]
+    assert len(late) == sum(1 for c in range(C) for p, _ in frames[c] if p > k / 10 + 300)
+    x = iq.numpy().copy()
+    x[:, n // 2:, :] *= 0.01
+    fr = oracle.batch_run(0, x, nthreads=4)
+    assert int((fr["nerr"] >= 0).all(axis=1).sum()) >= sent - C
