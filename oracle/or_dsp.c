@@ -328,6 +328,14 @@ static void afsk_front(OrDemod *d, const float *src, size_t n_in, int is_iq, flo
  * noise bandwidth.  M10 (9600 chips/s) stays at 48 kS/s. */
 void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 {
+	{	/* one allocation per feed instead of doubling reallocs inside the symbol loop (many threads feed at once) */
+		const int32_t pmin = d->m->period0 - (d->m->period0 >> 8);
+		const uint64_t want = d->nbits + (((uint64_t)(n / (size_t)(d->m->decim * d->m->pre)) << 16) / (uint64_t)pmin) + 64;
+		if (want > d->cap) {
+			d->cap = want;
+			d->bits = realloc(d->bits, d->cap);
+		}
+	}
 	if (d->m->pre > 1) {
 		/* AFSK: one tile of the demodulator = 2048 samples behind the tone demodulator = 16384 input samples
 		 * (n must be a multiple of that) */

@@ -26,6 +26,7 @@ class SondeBatch:
         self.n_channels = int(n_channels)
         self.max_samples = int(max_samples)
         self.input_kind = input_kind
+        self.device = int(device)
         cfg = _lib.SondeBatchConfig()
         cfg.n_channels = self.n_channels
         self._types = None
@@ -61,6 +62,20 @@ class SondeBatch:
             raise SondeError("first dimension must be n_channels")
         if self.input_kind == INPUT_IQ and (len(shape) != 3 or shape[2] != 2):
             raise SondeError("IQ input must be [C, n, 2] float32")
+        if self.input_kind != INPUT_IQ and len(shape) != 2:
+            raise SondeError("real input must be [C, n] float32")
+        # the C side sees only a pointer: check what it cannot (dtype, device, inner layout)
+        dt = str(getattr(samples, "dtype", ""))
+        if not dt.endswith("float32"):
+            raise SondeError(f"samples must be float32, got {dt}")
+        dev = getattr(samples, "device", None)
+        if dev is None or getattr(dev, "type", "") != "cuda":
+            raise SondeError("samples must be a device (HIP) tensor; use submit_host() for host memory")
+        if dev.index is not None and dev.index != self.device:
+            raise SondeError(f"samples live on device {dev.index}, the batch on device {self.device}")
+        st = tuple(samples.stride())
+        if (self.input_kind == INPUT_IQ and st[1:] != (2, 1)) or (self.input_kind != INPUT_IQ and st[1] != 1):
+            raise SondeError("samples must be contiguous inside a channel (only the channel stride may be padded)")
         stride = samples.stride(0) // (2 if self.input_kind == INPUT_IQ else 1)
         self._keep = samples   # keep the device buffer alive until sync
         self._chk(self.L.sonde_batch_submit(self.h, C.c_void_p(samples.data_ptr()), n, stride, C.c_void_p(stream or 0)))

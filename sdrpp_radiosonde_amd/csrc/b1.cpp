@@ -8,6 +8,8 @@
 // fragment queue one fragment per call, then PROCEED is returned once and the next buffer is accepted.
 #include <deque>
 #include <vector>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "parse.h"
 #include "../../include/sonde_abi.h"
@@ -20,6 +22,7 @@ struct SondeB1Decoder {
 	std::deque<SondeData> frags;
 	std::vector<SondeFrame> frames;
 	bool consumed = false;
+	bool complained = false;          // a failed submit has been reported once
 	explicit SondeB1Decoder(int t) : type(t), parser(t) {}
 };
 
@@ -39,7 +42,9 @@ static SondeB1Decoder *b1_init(int type, int samplerate, bool implemented)
 		cfg.types = &t;
 		cfg.max_samples = kB1MaxSamples;
 		cfg.input_kind = SONDE_INPUT_REAL;
-		cfg.device = 0;
+		// HIP device ordinal: SONDE_B1_DEVICE (the reference's init(int samplerate) has no room for it, decoder.hpp:39)
+		const char *dv = getenv("SONDE_B1_DEVICE");
+		cfg.device = dv ? atoi(dv) : 0;
 		if (sonde_batch_create(&cfg, &d->batch) != 0) { delete d; return nullptr; }
 	}
 	return d;
@@ -62,7 +67,13 @@ static ParserStatus b1_decode(SondeB1Decoder *d, SondeData *dst, const float *sr
 		while (d->pending.size() - off >= gran) {
 			size_t n = ((d->pending.size() - off) / gran) * gran;
 			if (n > kB1MaxSamples) n = kB1MaxSamples;
-			if (sonde_batch_submit_host(d->batch, d->pending.data() + off, n, n) != 0) break;
+			if (sonde_batch_submit_host(d->batch, d->pending.data() + off, n, n) != 0) {
+				// the GPU refused the block: say so once and drop the samples (keeping them would grow `pending`
+				// without bound and answer PROCEED forever with no diagnostic)
+				if (!d->complained) { fprintf(stderr, "sonde_mi355: decoder submit failed: %s\n", sonde_last_error()); d->complained = true; }
+				off = d->pending.size();
+				break;
+			}
 			const long nf = sonde_batch_sync(d->batch);
 			if (nf > 0) {
 				d->frames.resize((size_t)nf);

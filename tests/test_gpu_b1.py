@@ -76,11 +76,12 @@ def test_dfm_and_m10_b1_fields(oracle):
         assert len(times) >= 2 and all(t > 1_400_000_000 for t in times), name
 
 
-def test_unimplemented_sondes_always_proceed():
+def test_silence_always_proceeds():
+    """All seven decoders of main.hpp:36-42: a buffer of zeros yields no fragment (decoder.hpp:61 then flushes)."""
     L = _lib.load()
     sd = _lib.SondeData()
     buf = np.zeros(4096, dtype=np.float32)
-    for name in ("imet4", "c50", "mrzn1"):
+    for name in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1"):
         dec = getattr(L, f"{name}_decoder_init")(48000)
         assert dec
         assert getattr(L, f"{name}_decode")(dec, C.byref(sd), buf.ctypes.data_as(C.c_void_p), 4096) == _lib.PROCEED
