@@ -106,7 +106,8 @@ struct SondeBatch {
 	uint32_t *d_counts = nullptr;
 	float *d_taps = nullptr;
 	SdModem *d_modems = nullptr;
-	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_gfmulk = nullptr, *d_g64 = nullptr;
+	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_g64 = nullptr;
+	uint32_t *d_gfswar = nullptr;          // byte-slice tables of the 24 syndrome multipliers alpha^(4j), framer_kernel.hip
 	void *d_descs = nullptr;
 	uint32_t *d_chlist[SONDE_NTYPES] = {};
 	void *d_stage = nullptr;
@@ -149,7 +150,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
 	for (int k = 0; k < 3; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfmulk); (void)hipFree(b->d_g64); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
+	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_g64); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	delete b;
@@ -197,7 +198,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			b->max_frames = std::max(b->max_frames, b->type_frames[t]);
 		}
 	}
-	if ((size_t)b->ring_words * 4 > 65536) { delete b; return fail("sonde_batch_create: max_samples too large for the LDS-staged bit ring (64 KB)"); }
+	// the fixed-length framers stage the whole ring in LDS next to a few static words: keep it below the 64 KB workgroup limit
+	if ((size_t)b->ring_words * 4 >= 65536) { delete b; return fail("sonde_batch_create: max_samples too large for the LDS-staged bit ring (< 64 KB)"); }
 
 	const size_t C = b->n_channels;
 #define ALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void **)&(p), (bytes)); if (e_ != hipSuccess) { sonde_batch_destroy(b); return fail("hipMalloc " #p, e_); } } while (0)
@@ -211,7 +213,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_modems, SONDE_NTYPES * sizeof(SdModem));
 	ALLOC(b->d_gfexp, 2304);      // zero-absorbing antilog table of the RS decoder (GF_EXP2 in framer_kernel.hip)
 	ALLOC(b->d_gflog, 512);       // 256 x u16 logarithms, log 0 = 768
-	ALLOC(b->d_gfmulk, 24 * 256);
+	ALLOC(b->d_gfswar, 24 * 8 * sizeof(uint32_t));
 	ALLOC(b->d_g64, 192);
 	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
 	for (int t = 0; t < SONDE_NTYPES; t++)
@@ -273,11 +275,20 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		CHK(hipMemcpy(b->d_gfexp, e2.data(), e2.size(), hipMemcpyHostToDevice));
 		CHK(hipMemcpy(b->d_gflog, l2, sizeof(l2), hipMemcpyHostToDevice));
 	}
-	{	// mulk[j][v] = v * alpha^j for the 24 syndrome roots
-		std::vector<uint8_t> mulk(24 * 256);
-		for (int j = 0; j < 24; j++)
-			for (int v = 0; v < 256; v++) mulk[256 * j + v] = v ? gexp[glog[v] + j] : 0;
-		CHK(hipMemcpy(b->d_gfmulk, mulk.data(), mulk.size(), hipMemcpyHostToDevice));
+	{	// byte-slice tables of the multipliers c_j = alpha^(4j), j = 0..23 (framer_kernel.hip gf_swar_mul):
+		// words 0,1: c*x for x = 0..7;  words 2,3: c*(x << 3);  word 4: c*(x << 6), x = 0..3;  words 5..7 unused
+		uint32_t sw[24 * 8];
+		memset(sw, 0, sizeof(sw));
+		auto mul = [&](int c, int v) -> uint32_t { return (c && v) ? gexp[glog[c] + glog[v]] : 0u; };
+		for (int j = 0; j < 24; j++) {
+			const int c = gexp[(4 * j) % 255];
+			for (int x = 0; x < 8; x++) {
+				sw[8 * j + 0 + x / 4] |= mul(c, x) << (8 * (x % 4));
+				sw[8 * j + 2 + x / 4] |= mul(c, x << 3) << (8 * (x % 4));
+				if (x < 4) sw[8 * j + 4] |= mul(c, x << 6) << (8 * x);
+			}
+		}
+		CHK(hipMemcpy(b->d_gfswar, sw, sizeof(sw), hipMemcpyHostToDevice));
 	}
 	{	// GF(2^6)/x^6+x+1 tables for BCH(63,51): exp[128] then log[64]
 		uint8_t g64[192];
@@ -342,9 +353,11 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	HIPCHK(hipEventRecord(ev[0], stream));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
 	const bool iq = b->input_kind == SONDE_INPUT_IQ;
+	// RS41 channels: the demod kernel runs the sync search itself and lists complete frames here
+	const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts, b->max_frames };
 	if (!n_afsk && b->n_classes == 1) {
 		sd_launch_demod(iq, b->only_class, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
-			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems);
+			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo);
 	} else {
 		// fork: the class launches are independent (disjoint channels), let them share the GPU
 		HIPCHK(hipEventRecord(b->ev_fork, stream));
@@ -354,7 +367,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 			hipStream_t sk = used == 0 ? stream : b->aux[k];
 			if (sk != stream) HIPCHK(hipStreamWaitEvent(sk, b->ev_fork, 0));
 			sd_launch_demod(iq, k == 2 ? 4 : k + 1, b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
-				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_cls[k], false);
+				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_cls[k], false, fo);
 			if (sk != stream) { HIPCHK(hipEventRecord(b->ev_join[k], sk)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[k], 0)); }
 			used++;
 		}
@@ -365,7 +378,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 			sd_launch_afsk(iq, (uint32_t)n_afsk, stream, (const float *)samples, channel_stride, n_tiles,
 				b->d_chlist[SONDE_IMET4], b->d_astates, b->d_wtab, b->d_afq, nq);
 			sd_launch_demod(false, 1, (uint32_t)n_afsk, stream, b->d_afq, nq, (int)(nq / SONDE_TILE),
-				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[SONDE_IMET4], true);
+				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[SONDE_IMET4], true, fo);
 		}
 	}
 	HIPCHK(hipGetLastError());
@@ -373,7 +386,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	// d_counts: zeroed at creation; every sync kernel rewrites the entry of each channel it owns on every submit
 	if (!b->chlist[SONDE_RS41].empty()) {
 		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
-			b->d_states, b->d_fstates, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfmulk, b->d_descs,
+			b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_descs,
 			b->d_frames, b->d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);
 		HIPCHK(hipGetLastError());
 	}

@@ -6,6 +6,8 @@
 //   K2  polyphase low-pass FIR, evaluated only at the timing loop's sampling instants
 //   K3  Gardner timing-error detector + PI loop filter, updated once per round (<= 256 symbols)
 //       and hard slicer -> bit ring in HBM
+//   K4  RS41 channels: frame-sync correlator over the newest bits (sd_rs41.h), on a round wave that would
+//       otherwise spin while the lead wave runs the loop filter -> frame descriptors for the FEC kernel
 // (K2/K3 stand where sondedump's gfsk_demod sits behind X_decode, /root/reference/src/decode/decoder.hpp:22,61.)
 //
 // Bit-exactness contract: compiled with -ffp-contract=off, every fused op is an
@@ -15,6 +17,8 @@
 #include "sonde_dev.h"
 
 #include "sd_math.h"
+#include "sd_rs41.h"
+#include "launch.h"
 
 typedef float sd_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -55,7 +59,8 @@ struct DemodLds {
 	float iq_last[2];
 	// what the lead round wave (wave 0) computes once per round and the other round waves pick up:
 	// the PI loop filter runs on one wave instead of four (it is ~35 % of a round wave's VALU work)
-	struct { long long t_next; int period; float bias; int K; unsigned flag; } pub;
+	struct { long long t_next; int period; float bias; int K; unsigned flag; unsigned long long wpos; } pub;
+	uint32_t mirror[SD_MIRROR_WORDS];       // the newest 2048 bits of the bit ring, for the in-kernel sync search (K4)
 };
 
 // samples (i, i+1) of a tile, i even, into buffer b
@@ -112,7 +117,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
-	const uint32_t *__restrict__ chlist, int compact_in)
+	const uint32_t *__restrict__ chlist, int compact_in,
+	SdFramerState *__restrict__ fstates, SdFrameDesc *__restrict__ descs, uint32_t *__restrict__ counts, uint32_t max_frames)
 {
 	__shared__ __attribute__((aligned(16))) DemodLds s;
 
@@ -145,7 +151,18 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0;
 		s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
 		s.pub.flag = 0;
+		s.pub.wpos = st.wpos;
 	}
+	// K4 (RS41 channels): the sync search runs in here, on round wave 3, over an LDS mirror of the newest ring words
+	const bool framing = st.type == SONDE_RS41;          // workgroup-uniform
+	if (framing && tid >= SD_WGT - SD_MIRROR_WORDS) {
+		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WGT - 1 - tid);      // the words up to and including wpos's
+		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
+	}
+	auto uniform64 = [](unsigned long long v) {            // a value all lanes hold alike, moved to scalar registers
+		return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+		       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+	};
 
 	// ================================================================ discriminator role (waves 4-7)
 	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
@@ -313,6 +330,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				const uint32_t idx = (w0 + t) & ring_mask;
 				if (t == 0 && sh) vv |= s.partial[par] & ((1u << sh) - 1u);
 				ring_g[idx] = vv;
+				s.mirror[idx & (SD_MIRROR_WORDS - 1)] = vv;
 			}
 			// whoever owns the word the next round starts in publishes it (read after a barrier)
 			if ((uint32_t)t == ((sh + (uint32_t)K) >> 5)) s.partial[par ^ 1] = vv;
@@ -379,11 +397,25 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			}
 			for (int r = 0; r < rounds; r++) __syncthreads();
 		}
+		if (IS_IQ && t == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
+		__syncthreads();                                   // (E)
 	} else {
 		// the round waves are the critical path of a tile (update -> FIR -> reduction, all dependent);
 		// the discriminator waves only have to be done by the next barrier: let the round waves win
 		// every issue arbitration (static priority, T5 in the CDNA guide)
 		if (lead) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+		// K4 state (wave 3 of an RS41 channel only; scalar registers, live in this role's loop only)
+		const bool k4 = framing && rwave == 3;
+		SdSyncRun fr = {};
+		uint64_t wp_seen = 0;                              // bits known to be in the mirror
+		SdFrameDesc *const descs_ch = descs + (size_t)ch * max_frames;
+		if (k4) {
+			const SdFramerState f0 = fstates[ch];
+			fr.rpos = uniform64(f0.rpos); fr.fstart = uniform64(f0.fstart);
+			fr.collecting = __builtin_amdgcn_readfirstlane(f0.collecting); fr.inv = __builtin_amdgcn_readfirstlane(f0.inv);
+			fr.flen = __builtin_amdgcn_readfirstlane(f0.flen);
+			wp_seen = uniform64(st.wpos);
+		}
 		__syncthreads();
 		int K_total = 0;
 		for (int tile = 0; tile < n_tiles; tile++) {
@@ -403,12 +435,17 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 					t_next = st.t_next; period = st.period; bias = st.bias;
 					if (lane == 0) {
 						s.pub.t_next = t_next; s.pub.period = period; s.pub.bias = bias; s.pub.K = K;
+						s.pub.wpos = st.wpos;                             // every bit below it is in the ring and in the mirror
 						__hip_atomic_store(&s.pub.flag, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				} else {
+					// K4 instead of spinning while the lead wave runs the loop filter: the search works on the bits the
+					// PREVIOUS publish announced (one round behind; the epilogue catches up)
+					if (k4) sd_rs41_sync_step(fr, wp_seen, s.mirror, lane, descs_ch, max_frames);
 					while (__hip_atomic_load(&s.pub.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1u)
 						__builtin_amdgcn_s_sleep(2);
 					t_next = s.pub.t_next; period = s.pub.period; bias = s.pub.bias; K = s.pub.K;
+					if (k4) wp_seen = uniform64(s.pub.wpos);
 				}
 				round_front(K, b, par);
 				pendK = K;
@@ -416,12 +453,23 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				__syncthreads();
 			}
 		}
+		// ---- epilogue of the round role: the last round's update ...
+		if (lead && pendK >= 0) round_back(pendK, (int)((seq & 1u) ^ 1u));
+		if (lead && lane == 0) s.pub.wpos = st.wpos;
+		__syncthreads();                                   // (E) matched by the discriminator role's last barrier
+		if (k4) {
+			// ... and K4's catch-up over the last rounds' bits; the search state and the number of listed frames go back to HBM
+			sd_rs41_sync_step(fr, uniform64(s.pub.wpos), s.mirror, lane, descs_ch, max_frames);
+			if (lane == 0) {
+				SdFramerState f1;
+				f1.rpos = fr.rpos; f1.fstart = fr.fstart; f1.collecting = fr.collecting; f1.inv = fr.inv; f1.flen = fr.flen; f1.pad = 0;
+				fstates[ch] = f1;
+				counts[ch] = fr.nout;
+			}
+		}
 	}
 
-	// ---- epilogue: the last round's update, then carry history and state to the next submit
-	if (is_k && IS_IQ && t == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
-	if (!is_k && lead && pendK >= 0) round_back(pendK, (int)((seq & 1u) ^ 1u));
-	__syncthreads();
+	// ---- common epilogue (after barrier E): carry history and state to the next submit
 	const int bl = (n_tiles - 1) & 1;
 	if (tid < SD_LH) hist[(size_t)ch * SD_HIST + tid] = s.A[bl][IT + tid];
 	if (tid == 0) {
@@ -435,11 +483,11 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist, bool compact_in)
+	const uint32_t *chlist, bool compact_in, const SdFramerOut &fo)
 {
 	const dim3 g(n_channels), blk(SD_WGT);
 	const int ci = compact_in ? 1 : 0;
-#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci
+#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo.fstates, (SdFrameDesc *)fo.descs, fo.counts, fo.max_frames
 #define SD_DEMOD_LAUNCH(IQ, LS) do { \
 		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 4>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 2>), g, blk, 0, stream, SD_DEMOD_ARGS); \

@@ -12,7 +12,6 @@
 #include "sonde_dev.h"
 #include "../../include/sonde_abi.h"
 
-struct SdFrameDesc { uint64_t fstart; int32_t flen; int32_t inv; };
 
 __device__ __forceinline__ uint32_t chip_at(const uint32_t *ring, uint32_t mask, uint64_t p)
 {

@@ -1,14 +1,12 @@
-// framer_kernel.hip -- kernels B1/B2: bit ring -> sync search -> de-whitening -> RS(255,231) -> frame records.
-// B1 (sd_sync_rs41_kernel): one workgroup per channel walks the new bits and lists frame starts.
-// B2 (sd_rsdec_rs41_kernel): one 64-lane wave per listed frame extracts, de-whitens and RS-decodes it,
-//     so the latency-bound GF(2^8) chains of thousands of frames overlap.
+// framer_kernel.hip -- kernel B (sd_rsdec_rs41_kernel): listed RS41 frames -> de-whitening -> RS(255,231) -> frame records.
+// The frame-sync correlator (K4) runs inside the demodulator kernel (demod_kernel.hip, sd_rs41.h), which lists the
+// complete frames of a submit as descriptors; here one 64-lane wave per listed frame extracts, de-whitens and
+// RS-decodes it, so the latency-bound GF(2^8) chains of thousands of frames overlap.
 //
-//   K4  frame-sync correlator: 64-bit window XOR sync word, popcount, both polarities; the 64
-//       candidate offsets of one step are tested one per lane and reduced with a ballot
 //   K5  XOR de-whitening with the 64-byte RS41 mask
 //   K6  RS(255,231) over GF(2^8)/0x11D, roots alpha^0..alpha^23, two interleaved codewords:
-//       syndromes one per lane (48 lanes), Berlekamp-Massey on one lane per codeword,
-//       Chien search one position per lane, Forney one error per lane
+//       syndromes one per lane (48 lanes, four byte-sliced Horner chains per lane, no table memory),
+//       Berlekamp-Massey one coefficient per lane, Chien search one position per lane, Forney one error per lane
 // (stands where sondedump's framer/correlator/rs sit behind rs41_decode,
 //  /root/reference/src/main.hpp:36, /root/reference/src/decode/decoder.hpp:61; protocol constants:
 //  SURVEY.md Appendix B.2.)  All integer/byte work: bit-exact by construction.
@@ -16,15 +14,10 @@
 #include "sonde_dev.h"
 #include "../../include/sonde_abi.h"
 
+#include "sd_rs41.h"
+
 #define RS_R 24
 #define RS_T 12
-#define RS41_SYNC_THR 6
-#define RS41_LEN_STD  320
-#define RS41_LEN_EXT  518
-#define RS41_TYPE_POS 56
-
-// on-air RS41 header 10 B6 CA 11 22 96 12 F8, LSB-first bit order => little-endian u64
-#define RS41_SYNC64 0xF812962211CAB610ull
 
 __constant__ __attribute__((aligned(4))) uint8_t c_rs41_mask[64] = {
 	0x96, 0x83, 0x3E, 0x51, 0xB1, 0x49, 0x08, 0x98, 0x32, 0x05, 0x59, 0x0E, 0xF9, 0x44, 0xC6, 0x26,
@@ -44,7 +37,6 @@ __constant__ __attribute__((aligned(4))) uint8_t c_rs41_mask[64] = {
 #define GF_LZ    768
 #define GF_EXP2  (3 * GF_LZ)
 struct FramerTabs {                // shared by the waves of a workgroup
-	uint8_t  mulk[RS_R * 256];     // mulk[j][v] = v * alpha^j : one dependent lookup per Horner step
 	alignas(16) uint8_t  exp2[GF_EXP2];        // alpha^(i mod 255) for i < GF_LZ, 0 above
 	alignas(16) uint16_t log2[256];            // log2[0] = GF_LZ
 };
@@ -72,49 +64,48 @@ __device__ __forceinline__ uint8_t byte_at(const uint32_t *ring, uint32_t mask, 
 	return (uint8_t)(lo >> sh);
 }
 
-// One syndrome S_j = r(alpha^j) of the codeword cw[0..4Q) (zero-padded, Q a multiple of 4), as four interleaved
-// Horner chains.  The kernel is bound by the CU's one LDS pipe, so the codeword is read a word at a time (one
-// ds_read_b32 per chain per four steps; the byte select folds into the xor) and only the multiplication
-// table costs one LDS access per step.
-template <int Q>
-__device__ __forceinline__ uint32_t syndrome4(const FramerTabs &tb, const uint8_t *cw, int j)
+// Byte-sliced multiplication by a per-lane constant c in GF(2^8): v -> v*c is GF(2)-linear, so
+//   v*c = Ta[v & 7] ^ Tb[(v >> 3) & 7] ^ Tc[v >> 6]   with Ta[x] = c*x, Tb[x] = c*(x << 3), Tc[x] = c*(x << 6),
+// and v_perm_b32 looks all four bytes of a register up in an 8-entry byte table (two registers) at once: four
+// independent Horner chains advance with 2 shifts, 3 ands, 3 perms and 2 xors and no memory access at all
+// (the LDS byte-table form cost one conflicting LDS read per multiplication: 65 % of the kernel's LDS cycles
+// were bank conflicts, profiles/r1_v16_counters.csv).
+struct GfSwar { uint32_t a_lo, a_hi, b_lo, b_hi, c; };       // the 20 table bytes of one multiplier
+
+__device__ __forceinline__ uint32_t gf_swar_mul(uint32_t s, const GfSwar &t)
 {
-	static_assert(Q % 4 == 0, "chain length must be a whole number of words");
-	const uint8_t *mj = tb.mulk + 256 * j;      // mj[v] = v * alpha^j
+	const uint32_t ia = s & 0x07070707u;
+	const uint32_t ib = (s >> 3) & 0x07070707u;
+	const uint32_t ic = (s >> 6) & 0x03030303u;
+	// v_perm_b32: selector bytes 0..3 pick bytes of the SECOND source, 4..7 of the first
+	return __builtin_amdgcn_perm(t.a_hi, t.a_lo, ia) ^ __builtin_amdgcn_perm(t.b_hi, t.b_lo, ib) ^ __builtin_amdgcn_perm(t.c, t.c, ic);
+}
+
+// One syndrome S_j = r(alpha^j) of the codeword cw[0..4W) (zero-padded).  Chain k (byte k of the state) runs over
+// the positions 4m + k with the multiplier alpha^(4j), so one aligned word of the codeword feeds all four chains
+// (a broadcast LDS read: the lanes of a codeword share the address); then S = U0 + a^j U1 + a^2j U2 + a^3j U3.
+__device__ __forceinline__ uint32_t syndrome_swar(const FramerTabs &tb, const uint8_t *cw, int W, int j, const GfSwar &t)
+{
 	const uint32_t *cww = reinterpret_cast<const uint32_t *>(cw);
-	uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll 1
-	for (int w = Q / 4 - 1; w >= 0; w--) {
-		const uint32_t w0 = cww[w], w1 = cww[Q / 4 + w], w2 = cww[2 * (Q / 4) + w], w3 = cww[3 * (Q / 4) + w];
-#pragma unroll
-		for (int b = 3; b >= 0; b--) {
-			p0 = (uint32_t)mj[p0] ^ ((w0 >> (8 * b)) & 0xFFu);
-			p1 = (uint32_t)mj[p1] ^ ((w1 >> (8 * b)) & 0xFFu);
-			p2 = (uint32_t)mj[p2] ^ ((w2 >> (8 * b)) & 0xFFu);
-			p3 = (uint32_t)mj[p3] ^ ((w3 >> (8 * b)) & 0xFFu);
-		}
-	}
-	const uint32_t la = (uint32_t)(j * Q) % 255u;          // log of A = alpha^(j*Q)
-	uint32_t syn = (uint32_t)tb.exp2[tb.log2[p3] + la] ^ p2;
-	syn = (uint32_t)tb.exp2[tb.log2[syn] + la] ^ p1;
-	syn = (uint32_t)tb.exp2[tb.log2[syn] + la] ^ p0;
+	uint32_t u = 0;
+#pragma unroll 4
+	for (int w = W - 1; w >= 0; w--) u = gf_swar_mul(u, t) ^ cww[w];
+	uint32_t syn = u & 0xFFu;
+	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[(u >> 8) & 0xFFu] + (uint32_t)j];
+	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[(u >> 16) & 0xFFu] + 2u * (uint32_t)j];
+	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[u >> 24] + 3u * (uint32_t)j];
 	return syn;
 }
 
 // Decode both codewords held in s.cw[c][0..n) (zero-padded to 256).  Wave-synchronous; 64 lanes.
-__device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int lane)
+__device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int lane, const GfSwar &swar)
 {
-	// ---- syndromes: lane = 24*c + j, Horner from the highest position down
+	// ---- syndromes: lane = 24*c + j, byte-sliced Horner from the highest position down (the codeword buffer is
+	// zero-padded to 256 bytes, so the last word may be read whole)
 	uint32_t syn = 0;
 	if (lane < 2 * RS_R) {
 		const int c = lane / RS_R, j = lane % RS_R;
-		// Horner in four independent quarter-chains (4x shorter dependent LDS-lookup chain), then
-		// S = ((S3*A + S2)*A + S1)*A + S0 with A = alpha^(j*q): same field element as one long chain.
-		// The codeword buffer is zero-padded to 256 and 4q <= 256, so no chain needs a bounds test; each
-		// chain keeps "table base + value" in one register, so a step is two LDS byte reads and one
-		// xor-add.  The two RS41 frame lengths get their own instantiation (constant chain offsets).
-		if (n == RS_R + (RS41_LEN_STD - 56) / 2) syn = syndrome4<((RS_R + (RS41_LEN_STD - 56) / 2 + 15) / 16) * 4>(tb, s.cw[c], j);
-		else syn = syndrome4<64>(tb, s.cw[c], j);
+		syn = syndrome_swar(tb, s.cw[c], (n + 3) >> 2, j, swar);
 		s.logS[c][j] = tb.log2[syn];
 	}
 	const unsigned long long nzm = __ballot(syn != 0);
@@ -259,142 +250,29 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 	}
 }
 
-struct SdFrameDesc {            // one frame located by B1, decoded by B2
-	uint64_t fstart;            // absolute bit index of the first sync bit
-	int32_t  flen;              // bytes
-	int32_t  inv;               // polarity
-};
-
-#define RS41_SYNC_LO 0x11CAB610u
-#define RS41_SYNC_HI 0xF8129622u
-
-// ---------------------------------------------------------------- B1: sync search
-// One 256-thread workgroup per channel.  The channel's bit ring is staged in LDS; a search step covers the 2048
-// bit positions of 64 ring words, thread t testing the 8 positions  8*(t&3) .. 8*(t&3)+7  of word t>>2, so that
-// position order = thread order and "the earliest hit wins" is: lowest wave with a hit, lowest lane in it,
-// lowest offset in that lane.  The frame bookkeeping that follows a hit is replicated in every thread (the
-// state is tiny), so all control flow is workgroup-uniform and one s_barrier per search step is enough
-// (the per-wave results are double-buffered by step parity).
-#define B1_WAVES 4
-__global__ __launch_bounds__(64 * B1_WAVES) void sd_sync_rs41_kernel(
-	const SdChanState *__restrict__ states, SdFramerState *__restrict__ fstates,
-	const uint32_t *__restrict__ bitring, uint32_t ring_words,
-	SdFrameDesc *__restrict__ descs, uint32_t *__restrict__ counts, uint32_t max_frames,
-	const uint32_t *__restrict__ chlist)
-{
-	extern __shared__ __attribute__((aligned(16))) uint32_t s_ring[];   // the channel's whole bit ring
-	__shared__ int s_hit[2][B1_WAVES];       // [step parity][wave]: (bit offset inside the 2048-block) << 8 | hd, or -1
-	const int tid = threadIdx.x;
-	const int lane = tid & 63, wave = tid >> 6;
-	const uint32_t ch = chlist ? chlist[blockIdx.x] : blockIdx.x;
-	const uint32_t mask = ring_words - 1;
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(bitring + (size_t)ch * ring_words);
-		uint4 *dst = reinterpret_cast<uint4 *>(s_ring);
-		for (uint32_t i = tid; i < ring_words / 4; i += 64 * B1_WAVES) dst[i] = src[i];
-	}
-	const uint64_t wpos = states[ch].wpos;
-	SdFramerState fs = fstates[ch];
-	uint32_t nout = 0;
-	int par = 0;
-	__syncthreads();
-
-	for (;;) {
-		if (!fs.collecting) {
-			bool found = false;
-			while (fs.rpos + 64 <= wpos) {
-				const uint64_t blk = fs.rpos & ~31ull;
-				const uint64_t pos0 = blk + 32ull * (uint64_t)(tid >> 2);
-				const uint32_t wi = (uint32_t)(pos0 >> 5);
-				const uint32_t w0 = s_ring[wi & mask], w1 = s_ring[(wi + 1) & mask], w2 = s_ring[(wi + 2) & mask];
-				// valid offsets s: pos0+s >= rpos and pos0+s+64 <= wpos
-				const int s_lo = pos0 >= fs.rpos ? 0 : (int)(fs.rpos - pos0);
-				const int64_t room = (int64_t)(wpos - 64) - (int64_t)pos0;
-				const int s_hi = room < 0 ? -1 : (room > 31 ? 31 : (int)room);
-				const int sub = 8 * (tid & 3);
-				int first = 64, hd_first = 0;
-#pragma unroll
-				for (int q = 7; q >= 0; q--) {
-					const int sft = sub + q;
-					const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sft);
-					const uint32_t c = __popc(lo ^ RS41_SYNC_LO);
-					// necessary condition on the low half: c <= THR or c >= 32-THR
-					if ((uint32_t)(c - (RS41_SYNC_THR + 1)) >= (uint32_t)(32 - 2 * RS41_SYNC_THR - 1) && sft >= s_lo && sft <= s_hi) {
-						const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sft);
-						const int hd = (int)c + __popc(hi ^ RS41_SYNC_HI);
-						if (hd <= RS41_SYNC_THR || hd >= 64 - RS41_SYNC_THR) { first = sft; hd_first = hd; }
-					}
-				}
-				const unsigned long long hm = __ballot(first < 64);
-				if (lane == 0) s_hit[par][wave] = -1;
-				if (hm) {
-					const int fl = __ffsll((long long)hm) - 1;
-					if (lane == fl) s_hit[par][wave] = ((32 * (tid >> 2) + first) << 8) | hd_first;
-				}
-				__syncthreads();
-				int hit = -1;
-#pragma unroll
-				for (int w = B1_WAVES - 1; w >= 0; w--) {
-					const int hw = s_hit[par][w];
-					if (hw >= 0) hit = hw;
-				}
-				par ^= 1;
-				if (hit >= 0) {
-					fs.fstart = blk + (uint64_t)(hit >> 8);
-					fs.inv = (hit & 0xFF) >= 64 - RS41_SYNC_THR;
-					fs.collecting = 1;
-					found = true;
-					break;
-				}
-				uint64_t next = blk + 32ull * 64ull;
-				if (next > wpos - 63) next = wpos - 63;
-				fs.rpos = next;
-			}
-			if (!found) break;
-		}
-		if (wpos < fs.fstart + 8 * (RS41_TYPE_POS + 1)) break;
-		const uint8_t xinv = fs.inv ? 0xFF : 0x00;
-		const uint8_t tb = (uint8_t)(byte_at(s_ring, mask, fs.fstart + 8 * RS41_TYPE_POS) ^ xinv ^ c_rs41_mask[RS41_TYPE_POS & 63]);
-		const bool ext = __popc(tb ^ 0xF0u) < __popc(tb ^ 0x0Fu);
-		const int flen = ext ? RS41_LEN_EXT : RS41_LEN_STD;
-		if (wpos < fs.fstart + 8 * (uint64_t)flen) break;
-		if (nout < max_frames && tid == 0) {
-			SdFrameDesc d;
-			d.fstart = fs.fstart; d.flen = flen; d.inv = fs.inv;
-			descs[(size_t)ch * max_frames + nout] = d;
-		}
-		nout++;
-		fs.rpos = fs.fstart + 8 * (uint64_t)flen;
-		fs.collecting = 0;
-	}
-	if (tid == 0) {
-		fstates[ch] = fs;
-		counts[ch] = nout;
-	}
-}
-
-// ---------------------------------------------------------------- B2: per-frame de-whitening + RS
-// 256 threads = 4 waves = 4 frames per workgroup: the 7 KB of GF tables are staged once per
+// ---------------------------------------------------------------- kernel B: per-frame de-whitening + RS
+// 256 threads = 4 waves = 4 frames per workgroup: the 2.8 KB of GF tables are staged once per
 // workgroup, each wave then works alone on its own frame (wave-scope synchronisation only), so that
 // all frames of a step are resident at once and their latency-bound GF(2^8) chains overlap.
 #define B2_WAVES 4
 static_assert(64 * B2_WAVES == 256, "the table staging below writes one log2 entry per thread");
 __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 	const uint32_t *__restrict__ bitring, uint32_t ring_words,
-	const uint8_t *__restrict__ gf_exp, const uint8_t *__restrict__ gf_log, const uint8_t *__restrict__ gf_mulk,
+	const uint8_t *__restrict__ gf_exp, const uint8_t *__restrict__ gf_log, const uint32_t *__restrict__ gf_swar /* [24][8] */,
 	const SdFrameDesc *__restrict__ descs, const uint32_t *__restrict__ counts, uint32_t max_frames,
 	SondeFrame *__restrict__ frames, const uint32_t *__restrict__ chlist)
 {
 	__shared__ __attribute__((aligned(16))) FramerTabs tabs;
 	__shared__ __attribute__((aligned(16))) FramerLds wl[B2_WAVES];
-	const uint32_t ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
+	const uint32_t ch = chlist ? chlist[blockIdx.x] : blockIdx.x;
 	const uint32_t nfr = min(counts[ch], max_frames);
-	if (B2_WAVES * blockIdx.x >= nfr) return;                  // whole workgroup has nothing to do
+	if (B2_WAVES * blockIdx.y >= nfr) return;                  // whole workgroup has nothing to do
+	GfSwar swar;
 	{
 		const int tid = threadIdx.x;
-		const uint4 *src = reinterpret_cast<const uint4 *>(gf_mulk);
-		uint4 *dst = reinterpret_cast<uint4 *>(tabs.mulk);
-		for (int i = tid; i < RS_R * 256 / 16; i += 64 * B2_WAVES) dst[i] = src[i];
+		// this lane's multiplier alpha^(4j) as byte-slice tables (lane = 24 c + j of its wave)
+		const uint32_t *sw = gf_swar + 8 * ((tid & 63) % RS_R);
+		swar.a_lo = sw[0]; swar.a_hi = sw[1]; swar.b_lo = sw[2]; swar.b_hi = sw[3]; swar.c = sw[4];
 		// antilog (zero-absorbing, GF_EXP2 bytes) and log (256 x u16) tables as the host laid them out: plain copies
 		const uint4 *se = reinterpret_cast<const uint4 *>(gf_exp);
 		uint4 *de = reinterpret_cast<uint4 *>(tabs.exp2);
@@ -404,7 +282,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const int w = threadIdx.x >> 6;
-	const uint32_t k = B2_WAVES * blockIdx.x + (uint32_t)w;
+	const uint32_t k = B2_WAVES * blockIdx.y + (uint32_t)w;
 	if (k >= nfr) return;
 	FramerLds &s = wl[w];
 	const uint32_t *ring = bitring + (size_t)ch * ring_words;
@@ -437,7 +315,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 		s.cw[c][kk] = v;
 	}
 	WAVE_SYNC();
-	rs255_decode_pair(tabs, s, n, lane);
+	rs255_decode_pair(tabs, s, n, lane, swar);
 	for (int c = 0; c < 2; c++) {
 		if (s.status[c] > 0) {
 			for (int kk = lane; kk < n; kk += 64) {
@@ -465,13 +343,11 @@ __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 	}
 }
 
-void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,
-	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
-	const uint8_t *gf_exp, const uint8_t *gf_log, const uint8_t *gf_mulk, void *descs,
-	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist)
+void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream, const uint32_t *bitring, uint32_t ring_words,
+	const uint8_t *gf_exp, const uint8_t *gf_log, const uint32_t *gf_swar, const void *descs,
+	SondeFrame *frames, const uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist)
 {
-	hipLaunchKernelGGL(sd_sync_rs41_kernel, dim3(n_list), dim3(64 * B1_WAVES), ring_words * sizeof(uint32_t), stream,
-		states, fstates, bitring, ring_words, (SdFrameDesc *)descs, counts, max_frames, chlist);
-	hipLaunchKernelGGL(sd_rsdec_rs41_kernel, dim3((grid_frames + B2_WAVES - 1) / B2_WAVES, n_list), dim3(64 * B2_WAVES), 0, stream,
-		bitring, ring_words, gf_exp, gf_log, gf_mulk, (const SdFrameDesc *)descs, counts, max_frames, frames, chlist);
+	// channels on grid.x (no 65535 limit), frame groups on grid.y
+	hipLaunchKernelGGL(sd_rsdec_rs41_kernel, dim3(n_list, (grid_frames + B2_WAVES - 1) / B2_WAVES), dim3(64 * B2_WAVES), 0, stream,
+		bitring, ring_words, gf_exp, gf_log, gf_swar, (const SdFrameDesc *)descs, counts, max_frames, frames, chlist);
 }

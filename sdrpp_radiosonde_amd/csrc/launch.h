@@ -7,10 +7,12 @@
 // chlist: null = channels 0..n_channels-1 read their own row of `in`; else block i works on channel chlist[i] and reads
 // row chlist[i] (compact_in = false: the caller's buffer) or row i (compact_in = true: a per-list scratch buffer)
 // decim: the decimation factor (1, 2, 4) of EVERY channel this launch works on
+// where the in-kernel sync search of the RS41 channels (sd_rs41.h) keeps its state and lists the complete frames
+struct SdFramerOut { SdFramerState *fstates; void *descs; uint32_t *counts; uint32_t max_frames; };
 void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist = nullptr, bool compact_in = false);
+	const uint32_t *chlist, bool compact_in, const SdFramerOut &fo);
 
 void sd_launch_afsk(bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
 	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride);
@@ -18,10 +20,9 @@ void sd_launch_framer_imet(uint32_t n_list, hipStream_t stream, const SdChanStat
 	const uint32_t *bitring, uint32_t ring_words, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist);
 
 #define SD_DESC_BYTES 16   // sizeof(SdFrameDesc)
-void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream,
-	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
-	const uint8_t *gf_exp, const uint8_t *gf_log, const uint8_t *gf_mulk, void *descs,
-	SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist);
+void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream, const uint32_t *bitring, uint32_t ring_words,
+	const uint8_t *gf_exp, const uint8_t *gf_log, const uint32_t *gf_swar, const void *descs,
+	SondeFrame *frames, const uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist);
 
 void sd_launch_framer_other(int type, uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,

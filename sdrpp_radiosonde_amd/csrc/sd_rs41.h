@@ -1,0 +1,85 @@
+// sd_rs41.h -- RS41 framing constants and the frame-sync correlator (K4) that runs INSIDE
+// the demodulator kernel: one round wave advances the channel's sync-search state machine once per tile over the
+// newest bits, which the lead wave mirrors in LDS while it appends them to the bit ring in HBM.  Complete frames
+// are listed as descriptors for the FEC kernel (framer_kernel.hip).  This replaces a separate sync-search kernel
+// (12.8 us per step plus a launch boundary in round 1).
+//
+// It stands where sondedump's framer/correlator sits behind rs41_decode (/root/reference/src/main.hpp:36,
+// /root/reference/src/decode/decoder.hpp:61).  Search semantics (SPEC 3.3, oracle/or_fec.c rs41_run): positions
+// are tried in ascending order from `rpos`; the 64-bit window is compared with the on-air header, Hamming distance
+// <= 6 (>= 58: inverted polarity) starts a frame; its length follows from the de-whitened type byte 56; once the
+// last bit of the frame has arrived it is listed and the search resumes right behind it.  All integer work.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sonde_dev.h"
+
+#define RS41_SYNC_THR 6
+#define RS41_LEN_STD  320
+#define RS41_LEN_EXT  518
+#define RS41_TYPE_POS 56
+#define RS41_TYPE_MASK 0x78u        // whitening mask byte 56
+
+// on-air RS41 header 10 B6 CA 11 22 96 12 F8, LSB-first bit order => little-endian words
+#define RS41_SYNC_LO 0x11CAB610u
+#define RS41_SYNC_HI 0xF8129622u
+
+struct SdSyncRun {                  // the wave-uniform working copy of SdFramerState + the frames listed so far
+	uint64_t rpos, fstart;
+	int32_t collecting, inv, flen;
+	uint32_t nout;
+};
+
+// Advance the state machine over the bits [.., wp) of the channel.  `mirror` holds the ring words of the newest
+// SD_MIRROR_WORDS * 32 bits (word w of the stream at mirror[w % SD_MIRROR_WORDS]); the caller guarantees that the
+// search never trails wp by more than that (it is called at least once per tile).  Wave-synchronous, 64 lanes,
+// all control flow wave-uniform.
+__device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &fs, uint64_t wp, const uint32_t *mirror, int lane,
+	SdFrameDesc *__restrict__ descs_ch, uint32_t max_frames)
+{
+	for (;;) {
+		if (!fs.collecting) {
+			bool found = false;
+			while (fs.rpos + 64 <= wp) {
+				const uint64_t pos = fs.rpos + (uint64_t)lane;
+				const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)pos & 31u;
+				const uint32_t w0 = mirror[wi & (SD_MIRROR_WORDS - 1)], w1 = mirror[(wi + 1) & (SD_MIRROR_WORDS - 1)],
+				               w2 = mirror[(wi + 2) & (SD_MIRROR_WORDS - 1)];
+				const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+				const int hd = __popc(lo ^ RS41_SYNC_LO) + __popc(hi ^ RS41_SYNC_HI);
+				const bool hit = pos + 64 <= wp && (hd <= RS41_SYNC_THR || hd >= 64 - RS41_SYNC_THR);
+				const unsigned long long hm = __ballot(hit);
+				if (hm) {
+					const int fl = __ffsll((long long)hm) - 1;            // the earliest position wins
+					fs.fstart = fs.rpos + (uint64_t)fl;
+					fs.inv = __builtin_amdgcn_readlane(hd, fl) >= 64 - RS41_SYNC_THR;
+					fs.collecting = 1;
+					fs.flen = 0;
+					found = true;
+					break;
+				}
+				uint64_t next = fs.rpos + 64;
+				if (next > wp - 63) next = wp - 63;                       // first position whose window is not complete yet
+				fs.rpos = next;
+			}
+			if (!found) return;
+		}
+		if (!fs.flen) {
+			if (wp < fs.fstart + 8 * (RS41_TYPE_POS + 1)) return;
+			const uint64_t p = fs.fstart + 8 * RS41_TYPE_POS;
+			const uint32_t wi = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+			const uint32_t raw = __builtin_amdgcn_alignbit(mirror[(wi + 1) & (SD_MIRROR_WORDS - 1)], mirror[wi & (SD_MIRROR_WORDS - 1)], sh);
+			const uint32_t tb = (raw ^ (fs.inv ? 0xFFu : 0u) ^ RS41_TYPE_MASK) & 0xFFu;
+			fs.flen = (__popc(tb ^ 0xF0u) < __popc(tb ^ 0x0Fu)) ? RS41_LEN_EXT : RS41_LEN_STD;
+		}
+		if (wp < fs.fstart + 8 * (uint64_t)fs.flen) return;
+		if (fs.nout < max_frames && lane == 0) {
+			SdFrameDesc d;
+			d.fstart = fs.fstart; d.flen = fs.flen; d.inv = fs.inv;
+			descs_ch[fs.nout] = d;
+		}
+		fs.nout++;
+		fs.rpos = fs.fstart + 8 * (uint64_t)fs.flen;
+		fs.collecting = 0;
+		fs.flen = 0;
+	}
+}

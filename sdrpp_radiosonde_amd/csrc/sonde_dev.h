@@ -54,9 +54,19 @@ struct SdChanState {        // demodulator state, one per channel (64 B)
 };
 
 struct SdFramerState {      // framer state, one per channel (32 B)
-	uint64_t rpos;
-	uint64_t fstart;
+	uint64_t rpos;          // the sync search resumes at this absolute bit index
+	uint64_t fstart;        // collecting: absolute bit index of the first sync bit
 	int32_t  collecting;
 	int32_t  inv;
-	int32_t  pad[2];
+	int32_t  flen;          // RS41 (framed inside the demod kernel): frame length in bytes once the type byte has arrived, else 0
+	int32_t  pad;
 };
+
+struct SdFrameDesc {        // one complete frame located by the sync search, decoded by the FEC kernel
+	uint64_t fstart;        // absolute bit index of the first sync bit
+	int32_t  flen;          // bytes (RS41) or chips (the fixed-length framers)
+	int32_t  inv;           // polarity
+};
+
+// newest bits of a channel's bit ring kept in LDS by the demod kernel for its in-kernel sync search
+#define SD_MIRROR_WORDS 64
