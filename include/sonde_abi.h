@@ -115,6 +115,9 @@ typedef struct {
 /* RS41 channels: decimate IQ 2:1 instead of 4:1 before the discriminator (24 kS/s internally): tolerates +-5 kHz of carrier
  * offset instead of +-1 kHz, at about 2 dB of sensitivity and twice the discriminator arithmetic.  IQ input only. */
 #define SONDE_FLAG_RS41_WIDE 1u
+/* RS41 channels: run the Reed-Solomon stage as a kernel of its own behind the demodulator instead of in the demodulator
+ * kernel's epilogue (one launch more per submit; same frames).  Kept for A/B measurements. */
+#define SONDE_FLAG_SPLIT_FEC 2u
 
 typedef struct SondeBatch SondeBatch;
 

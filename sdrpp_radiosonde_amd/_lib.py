@@ -45,6 +45,7 @@ class SondeBatchConfig(C.Structure):
 
 
 FLAG_RS41_WIDE = 1
+FLAG_SPLIT_FEC = 2
 
 
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them

@@ -107,6 +107,8 @@ struct SondeBatch {
 	float *d_taps = nullptr;
 	SdModem *d_modems = nullptr;
 	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_g64 = nullptr;
+	uint32_t fuse_fec = 1;                 // RS41 FEC in the demod kernel's epilogue (default) or as its own kernel (SONDE_FLAG_SPLIT_FEC)
+	SdFramerOut *d_fo = nullptr;           // where the demod kernel's in-kernel sync search keeps its state (device copy)
 	uint32_t *d_gfswar = nullptr;          // byte-slice tables of the 24 syndrome multipliers alpha^(4j), framer_kernel.hip
 	void *d_descs = nullptr;
 	uint32_t *d_chlist[SONDE_NTYPES] = {};
@@ -150,7 +152,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
 	for (int k = 0; k < 3; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_g64); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
+	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_fo); (void)hipFree(b->d_g64); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	delete b;
@@ -214,6 +216,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_gfexp, 2304);      // zero-absorbing antilog table of the RS decoder (GF_EXP2 in framer_kernel.hip)
 	ALLOC(b->d_gflog, 512);       // 256 x u16 logarithms, log 0 = 768
 	ALLOC(b->d_gfswar, 24 * 8 * sizeof(uint32_t));
+	ALLOC(b->d_fo, sizeof(SdFramerOut));
 	ALLOC(b->d_g64, 192);
 	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
 	for (int t = 0; t < SONDE_NTYPES; t++)
@@ -298,6 +301,11 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		for (int i = 63; i < 128; i++) g64[i] = g64[i - 63];
 		CHK(hipMemcpy(b->d_g64, g64, sizeof(g64), hipMemcpyHostToDevice));
 	}
+	{
+		b->fuse_fec = (cfg->flags & SONDE_FLAG_SPLIT_FEC) ? 0u : 1u;
+		const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts, b->max_frames, b->fuse_fec, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_frames };
+		CHK(hipMemcpy(b->d_fo, &fo, sizeof(fo), hipMemcpyHostToDevice));
+	}
 	// initial channel state
 	std::vector<SdChanState> st(C);
 	for (size_t c = 0; c < C; c++) {
@@ -353,8 +361,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	HIPCHK(hipEventRecord(ev[0], stream));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
 	const bool iq = b->input_kind == SONDE_INPUT_IQ;
-	// RS41 channels: the demod kernel runs the sync search itself and lists complete frames here
-	const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts, b->max_frames };
+	const SdFramerOut *fo = b->d_fo;    // RS41 channels: the demod kernel runs the sync search itself and lists complete frames there
 	if (!n_afsk && b->n_classes == 1) {
 		sd_launch_demod(iq, b->only_class, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo);
@@ -384,7 +391,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], stream));
 	// d_counts: zeroed at creation; every sync kernel rewrites the entry of each channel it owns on every submit
-	if (!b->chlist[SONDE_RS41].empty()) {
+	if (!b->chlist[SONDE_RS41].empty() && !b->fuse_fec) {
 		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
 			b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_descs,
 			b->d_frames, b->d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);

@@ -7,7 +7,10 @@
 //   K3  Gardner timing-error detector + PI loop filter, updated once per round (<= 256 symbols)
 //       and hard slicer -> bit ring in HBM
 //   K4  RS41 channels: frame-sync correlator over the newest bits (sd_rs41.h), on a round wave that would
-//       otherwise spin while the lead wave runs the loop filter -> frame descriptors for the FEC kernel
+//       otherwise spin while the lead wave runs the loop filter -> frame descriptors
+//   K5/K6  RS41 channels, epilogue: the frames completed in this submit are de-whitened and RS(255,231)-decoded
+//       by the eight waves of the workgroup, one frame per wave (sd_rsdec.h) -> frame records in HBM.
+//       One launch per step instead of three (round 1: sync 12.8 us + FEC 38.2 us + two launch boundaries).
 // (K2/K3 stand where sondedump's gfsk_demod sits behind X_decode, /root/reference/src/decode/decoder.hpp:22,61.)
 //
 // Bit-exactness contract: compiled with -ffp-contract=off, every fused op is an
@@ -18,6 +21,7 @@
 
 #include "sd_math.h"
 #include "sd_rs41.h"
+#include "sd_rsdec.h"
 #include "launch.h"
 
 typedef float sd_f32x4 __attribute__((ext_vector_type(4)));
@@ -61,6 +65,7 @@ struct DemodLds {
 	// the PI loop filter runs on one wave instead of four (it is ~35 % of a round wave's VALU work)
 	struct { long long t_next; int period; float bias; int K; unsigned flag; unsigned long long wpos; } pub;
 	uint32_t mirror[SD_MIRROR_WORDS];       // the newest 2048 bits of the bit ring, for the in-kernel sync search (K4)
+	SdSyncRun k4;                           // K4's state between steps (wave 3 only)
 };
 
 // samples (i, i+1) of a tile, i even, into buffer b
@@ -103,6 +108,15 @@ __device__ __forceinline__ float interp(const float *A, const float *B, const fl
 	return acc.y + acc.x;
 }
 
+// FEC epilogue (RS41 channels): the GF tables sit, for the whole launch, behind the part of B[1] that a decimated
+// tile uses (decimation 4 or 2: <= 64 + 1024 + 4 floats of 2116), the per-wave work areas alias the tile buffers,
+// which are dead by then.
+#define SD_EPI_TAB_OFF 1100                 // floats into B[1]
+struct EpiTabs { FramerTabs tabs; alignas(16) uint32_t swar[RS_R * 8]; };
+static_assert(SD_LH + SD_TILE / 2 + 4 <= SD_EPI_TAB_OFF, "the tables must stay clear of a 2:1 tile");
+static_assert(sizeof(EpiTabs) <= (SD_BUF - SD_EPI_TAB_OFF) * sizeof(float), "GF tables do not fit behind the tile");
+static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "per-wave FEC work areas do not fit into the tile buffers");
+
 // ---------------------------------------------------------------- the kernel
 // Wave specialisation: the discriminator (K1) is pure per-sample ALU work, the rounds (K2/K3) are a
 // latency-bound chain (loop update -> FIR reads -> reduction).  Running them as different waves of the
@@ -117,8 +131,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
-	const uint32_t *__restrict__ chlist, int compact_in,
-	SdFramerState *__restrict__ fstates, SdFrameDesc *__restrict__ descs, uint32_t *__restrict__ counts, uint32_t max_frames)
+	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo)
 {
 	__shared__ __attribute__((aligned(16))) DemodLds s;
 
@@ -159,10 +172,16 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WGT - 1 - tid);      // the words up to and including wpos's
 		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
 	}
-	auto uniform64 = [](unsigned long long v) {            // a value all lanes hold alike, moved to scalar registers
-		return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-		       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-	};
+
+	const bool fec_here = DEC != 1 && framing && fo->fuse_fec != 0;     // workgroup-uniform
+	EpiTabs &et = *reinterpret_cast<EpiTabs *>(&s.B[1][SD_EPI_TAB_OFF]);
+	if (fec_here) {
+		// GF(2^8) tables for the epilogue: one 16-byte global load per thread now, hidden behind the first tile's loads
+		if (tid < GF_EXP2 / 16) reinterpret_cast<uint4 *>(et.tabs.exp2)[tid] = reinterpret_cast<const uint4 *>(fo->gf_exp)[tid];
+		else if (tid < GF_EXP2 / 16 + 512 / 16) reinterpret_cast<uint4 *>(et.tabs.log2)[tid - GF_EXP2 / 16] = reinterpret_cast<const uint4 *>(fo->gf_log)[tid - GF_EXP2 / 16];
+		else if (tid < GF_EXP2 / 16 + 512 / 16 + RS_R * 8 * 4 / 16)
+			reinterpret_cast<uint4 *>(et.swar)[tid - (GF_EXP2 / 16 + 512 / 16)] = reinterpret_cast<const uint4 *>(fo->gf_swar)[tid - (GF_EXP2 / 16 + 512 / 16)];
+	}
 
 	// ================================================================ discriminator role (waves 4-7)
 	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
@@ -404,17 +423,13 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		// the discriminator waves only have to be done by the next barrier: let the round waves win
 		// every issue arbitration (static priority, T5 in the CDNA guide)
 		if (lead) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
-		// K4 state (wave 3 of an RS41 channel only; scalar registers, live in this role's loop only)
+		// K4 (wave 3 of an RS41 channel only): its state sits in LDS between steps, the output pointers in a
+		// descriptor in HBM -- scalar registers are the scarce resource of this kernel
 		const bool k4 = framing && rwave == 3;
-		SdSyncRun fr = {};
-		uint64_t wp_seen = 0;                              // bits known to be in the mirror
-		SdFrameDesc *const descs_ch = descs + (size_t)ch * max_frames;
-		if (k4) {
-			const SdFramerState f0 = fstates[ch];
-			fr.rpos = uniform64(f0.rpos); fr.fstart = uniform64(f0.fstart);
-			fr.collecting = __builtin_amdgcn_readfirstlane(f0.collecting); fr.inv = __builtin_amdgcn_readfirstlane(f0.inv);
-			fr.flen = __builtin_amdgcn_readfirstlane(f0.flen);
-			wp_seen = uniform64(st.wpos);
+		if (k4 && lane == 0) {
+			const SdFramerState f0 = fo->fstates[ch];
+			s.k4.rpos = f0.rpos; s.k4.fstart = f0.fstart; s.k4.collecting = f0.collecting; s.k4.inv = f0.inv; s.k4.flen = f0.flen;
+			s.k4.nout = 0; s.k4.wp_seen = st.wpos;
 		}
 		__syncthreads();
 		int K_total = 0;
@@ -441,11 +456,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				} else {
 					// K4 instead of spinning while the lead wave runs the loop filter: the search works on the bits the
 					// PREVIOUS publish announced (one round behind; the epilogue catches up)
-					if (k4) sd_rs41_sync_step(fr, wp_seen, s.mirror, lane, descs_ch, max_frames);
+					if (k4) sd_rs41_sync_step(s.k4, sd_uniform64(s.k4.wp_seen), s.mirror, lane,
+						(SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames, fo->max_frames);
 					while (__hip_atomic_load(&s.pub.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1u)
 						__builtin_amdgcn_s_sleep(2);
 					t_next = s.pub.t_next; period = s.pub.period; bias = s.pub.bias; K = s.pub.K;
-					if (k4) wp_seen = uniform64(s.pub.wpos);
+					if (k4 && lane == 0) s.k4.wp_seen = s.pub.wpos;
 				}
 				round_front(K, b, par);
 				pendK = K;
@@ -459,12 +475,13 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		__syncthreads();                                   // (E) matched by the discriminator role's last barrier
 		if (k4) {
 			// ... and K4's catch-up over the last rounds' bits; the search state and the number of listed frames go back to HBM
-			sd_rs41_sync_step(fr, uniform64(s.pub.wpos), s.mirror, lane, descs_ch, max_frames);
+			sd_rs41_sync_step(s.k4, sd_uniform64(s.pub.wpos), s.mirror, lane,
+				(SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames, fo->max_frames);
 			if (lane == 0) {
 				SdFramerState f1;
-				f1.rpos = fr.rpos; f1.fstart = fr.fstart; f1.collecting = fr.collecting; f1.inv = fr.inv; f1.flen = fr.flen; f1.pad = 0;
-				fstates[ch] = f1;
-				counts[ch] = fr.nout;
+				f1.rpos = s.k4.rpos; f1.fstart = s.k4.fstart; f1.collecting = s.k4.collecting; f1.inv = s.k4.inv; f1.flen = s.k4.flen; f1.pad = 0;
+				fo->fstates[ch] = f1;
+				fo->counts[ch] = s.k4.nout;
 			}
 		}
 	}
@@ -478,16 +495,41 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		st.yprev = 0.0f;
 		states[ch] = st;
 	}
+
+	// ---- K5/K6 (RS41 channels): the frames K4 listed in this submit, one per wave
+	if (fec_here) {
+		__syncthreads();           // (F) K4's catch-up is done (nout in LDS, descriptors in HBM); the tile buffers are dead
+		const uint32_t max_frames = fo->max_frames;
+		const uint32_t nfr = min((uint32_t)__builtin_amdgcn_readfirstlane((int)s.k4.nout), max_frames);
+		if ((uint32_t)wave < nfr) {
+			FramerLds &wl = reinterpret_cast<FramerLds *>(&s.A[0][0])[wave];
+			GfSwar swar;
+			const uint32_t *sw = et.swar + 8 * (lane % RS_R);
+			swar.a_lo = sw[0]; swar.a_hi = sw[1]; swar.b_lo = sw[2]; swar.b_hi = sw[3]; swar.c = sw[4];
+			const unsigned long long *dg = reinterpret_cast<const unsigned long long *>((const SdFrameDesc *)fo->descs + (size_t)ch * max_frames);
+			SondeFrame *fout = fo->frames + (size_t)ch * max_frames;
+			for (uint32_t k = (uint32_t)wave; k < nfr; k += SD_WGT / 64) {
+				// the descriptor was stored by wave 3 of this workgroup a moment ago: agent-scope loads (L2), like the ring words
+				const unsigned long long d0 = __hip_atomic_load(dg + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const unsigned long long d1 = __hip_atomic_load(dg + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				SdFrameDesc d;
+				d.fstart = sd_uniform64(d0);
+				d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);
+				d.inv = __builtin_amdgcn_readfirstlane((int)(d1 >> 32));
+				sd_rs41_decode_frame<true>(et.tabs, wl, swar, ring_g, ring_mask, d, fout + k, ch, lane);
+			}
+		}
+	}
 }
 
 void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist, bool compact_in, const SdFramerOut &fo)
+	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */)
 {
 	const dim3 g(n_channels), blk(SD_WGT);
 	const int ci = compact_in ? 1 : 0;
-#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo.fstates, (SdFrameDesc *)fo.descs, fo.counts, fo.max_frames
+#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo
 #define SD_DEMOD_LAUNCH(IQ, LS) do { \
 		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 4>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 2>), g, blk, 0, stream, SD_DEMOD_ARGS); \

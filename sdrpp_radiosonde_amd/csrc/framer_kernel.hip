@@ -1,261 +1,16 @@
-// framer_kernel.hip -- kernel B (sd_rsdec_rs41_kernel): listed RS41 frames -> de-whitening -> RS(255,231) -> frame records.
-// The frame-sync correlator (K4) runs inside the demodulator kernel (demod_kernel.hip, sd_rs41.h), which lists the
-// complete frames of a submit as descriptors; here one 64-lane wave per listed frame extracts, de-whitens and
-// RS-decodes it, so the latency-bound GF(2^8) chains of thousands of frames overlap.
-//
-//   K5  XOR de-whitening with the 64-byte RS41 mask
-//   K6  RS(255,231) over GF(2^8)/0x11D, roots alpha^0..alpha^23, two interleaved codewords:
-//       syndromes one per lane (48 lanes, four byte-sliced Horner chains per lane, no table memory),
-//       Berlekamp-Massey one coefficient per lane, Chien search one position per lane, Forney one error per lane
-// (stands where sondedump's framer/correlator/rs sit behind rs41_decode,
-//  /root/reference/src/main.hpp:36, /root/reference/src/decode/decoder.hpp:61; protocol constants:
-//  SURVEY.md Appendix B.2.)  All integer/byte work: bit-exact by construction.
+// framer_kernel.hip -- stand-alone FEC kernel (sd_rsdec_rs41_kernel): listed RS41 frames -> de-whitening -> RS(255,231) ->
+// frame records, one 64-lane wave per frame (sd_rsdec.h).  The frame-sync correlator (K4) runs inside the demodulator
+// kernel, which lists the complete frames of a submit as descriptors; by default that kernel also runs the FEC in its
+// epilogue (SONDE_FLAG_SPLIT_FEC selects this kernel instead: A/B measurements).
 #include <hip/hip_runtime.h>
 #include "sonde_dev.h"
-#include "../../include/sonde_abi.h"
+#include "sd_rsdec.h"
+#include "launch.h"
 
-#include "sd_rs41.h"
-
-#define RS_R 24
-#define RS_T 12
-
-__constant__ __attribute__((aligned(4))) uint8_t c_rs41_mask[64] = {
-	0x96, 0x83, 0x3E, 0x51, 0xB1, 0x49, 0x08, 0x98, 0x32, 0x05, 0x59, 0x0E, 0xF9, 0x44, 0xC6, 0x26,
-	0x21, 0x60, 0xC2, 0xEA, 0x79, 0x5D, 0x6D, 0xA1, 0x54, 0x69, 0x47, 0x0C, 0xDC, 0xE8, 0x5C, 0xF1,
-	0xF7, 0x76, 0x82, 0x7F, 0x07, 0x99, 0xA2, 0x2C, 0x93, 0x7C, 0x30, 0x63, 0xF5, 0x10, 0x2E, 0x61,
-	0xD0, 0xBC, 0xB4, 0xB6, 0x06, 0xAA, 0xF4, 0x23, 0x78, 0x6E, 0x3B, 0xAE, 0xBF, 0x7B, 0x4C, 0xC1,
-};
-
-// wave-scope ordering of LDS traffic: DS operations of one wave execute in order, so lanes of the same
-// wave see each other's LDS writes once the compiler is kept from reordering across this point
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-
-// GF(2^8) arithmetic in the log domain without zero tests: log of 0 is GF_LZ, larger than any sum of valid
-// logarithms (<= 254 + 509), and the antilog table is periodic below GF_LZ and zero from there on, so a product
-// with a zero factor reads a zero.  The kernel is bound by the CU's LDS pipe, so a product is one table read once
-// the logarithms of its factors are at hand.
-#define GF_LZ    768
-#define GF_EXP2  (3 * GF_LZ)
-struct FramerTabs {                // shared by the waves of a workgroup
-	alignas(16) uint8_t  exp2[GF_EXP2];        // alpha^(i mod 255) for i < GF_LZ, 0 above
-	alignas(16) uint16_t log2[256];            // log2[0] = GF_LZ
-};
-struct FramerLds {                 // one per wave (= per frame)
-	alignas(4) uint8_t frame[SONDE_FRAME_MAX];
-	alignas(4) uint8_t cw[2][256];
-	uint16_t logS[2][RS_R];        // logarithms of the syndromes
-	uint8_t  lam[2][RS_R + 2];
-	uint16_t loglam[2][RS_R + 2];
-	uint16_t logom[2][RS_R];
-	int     pos[2][RS_T];
-	int     L[2];
-	int     status[2];     // 0 clean, >0 errors to fix, -1 fail
-};
-
-__device__ __forceinline__ uint32_t gmul(const FramerTabs &s, uint32_t a, uint32_t b)
-{
-	return s.exp2[(uint32_t)s.log2[a] + (uint32_t)s.log2[b]];
-}
-
-__device__ __forceinline__ uint8_t byte_at(const uint32_t *ring, uint32_t mask, uint64_t p)
-{
-	const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
-	const uint64_t lo = (uint64_t)ring[w & mask] | ((uint64_t)ring[(w + 1) & mask] << 32);
-	return (uint8_t)(lo >> sh);
-}
-
-// Byte-sliced multiplication by a per-lane constant c in GF(2^8): v -> v*c is GF(2)-linear, so
-//   v*c = Ta[v & 7] ^ Tb[(v >> 3) & 7] ^ Tc[v >> 6]   with Ta[x] = c*x, Tb[x] = c*(x << 3), Tc[x] = c*(x << 6),
-// and v_perm_b32 looks all four bytes of a register up in an 8-entry byte table (two registers) at once: four
-// independent Horner chains advance with 2 shifts, 3 ands, 3 perms and 2 xors and no memory access at all
-// (the LDS byte-table form cost one conflicting LDS read per multiplication: 65 % of the kernel's LDS cycles
-// were bank conflicts, profiles/r1_v16_counters.csv).
-struct GfSwar { uint32_t a_lo, a_hi, b_lo, b_hi, c; };       // the 20 table bytes of one multiplier
-
-__device__ __forceinline__ uint32_t gf_swar_mul(uint32_t s, const GfSwar &t)
-{
-	const uint32_t ia = s & 0x07070707u;
-	const uint32_t ib = (s >> 3) & 0x07070707u;
-	const uint32_t ic = (s >> 6) & 0x03030303u;
-	// v_perm_b32: selector bytes 0..3 pick bytes of the SECOND source, 4..7 of the first
-	return __builtin_amdgcn_perm(t.a_hi, t.a_lo, ia) ^ __builtin_amdgcn_perm(t.b_hi, t.b_lo, ib) ^ __builtin_amdgcn_perm(t.c, t.c, ic);
-}
-
-// One syndrome S_j = r(alpha^j) of the codeword cw[0..4W) (zero-padded).  Chain k (byte k of the state) runs over
-// the positions 4m + k with the multiplier alpha^(4j), so one aligned word of the codeword feeds all four chains
-// (a broadcast LDS read: the lanes of a codeword share the address); then S = U0 + a^j U1 + a^2j U2 + a^3j U3.
-__device__ __forceinline__ uint32_t syndrome_swar(const FramerTabs &tb, const uint8_t *cw, int W, int j, const GfSwar &t)
-{
-	const uint32_t *cww = reinterpret_cast<const uint32_t *>(cw);
-	uint32_t u = 0;
-#pragma unroll 4
-	for (int w = W - 1; w >= 0; w--) u = gf_swar_mul(u, t) ^ cww[w];
-	uint32_t syn = u & 0xFFu;
-	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[(u >> 8) & 0xFFu] + (uint32_t)j];
-	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[(u >> 16) & 0xFFu] + 2u * (uint32_t)j];
-	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[u >> 24] + 3u * (uint32_t)j];
-	return syn;
-}
-
-// Decode both codewords held in s.cw[c][0..n) (zero-padded to 256).  Wave-synchronous; 64 lanes.
-__device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int lane, const GfSwar &swar)
-{
-	// ---- syndromes: lane = 24*c + j, byte-sliced Horner from the highest position down (the codeword buffer is
-	// zero-padded to 256 bytes, so the last word may be read whole)
-	uint32_t syn = 0;
-	if (lane < 2 * RS_R) {
-		const int c = lane / RS_R, j = lane % RS_R;
-		syn = syndrome_swar(tb, s.cw[c], (n + 3) >> 2, j, swar);
-		s.logS[c][j] = tb.log2[syn];
-	}
-	const unsigned long long nzm = __ballot(syn != 0);
-	if (lane < 2) {
-		const bool nz = (nzm >> (RS_R * lane)) & 0xFFFFFFull;
-		s.status[lane] = nz ? 1 : 0;
-		s.L[lane] = 0;
-	}
-	WAVE_SYNC();
-	if (nzm == 0ull) return;                    // both codewords clean (wave-uniform): nothing to correct
-
-	// ---- Berlekamp-Massey, one coefficient per lane: half-wave h handles codeword h, lane idx = lane&31 holds
-	// lam[idx] and (the logarithm of) Bp[idx] where Bp = x^m * B.  Same recurrence as the sequential form (delta,
-	// then lam -= delta/b * x^m B, length change iff 2L <= r), so the same Lambda comes out.  Log domain: the
-	// discrepancy term is one antilog read, the update one more, plus the logarithm of the new coefficient.
-	{
-		const int h = lane >> 5, idx = lane & 31;
-		const bool live = s.status[h] > 0;
-		uint32_t lam = (idx == 0) ? 1u : 0u;
-		uint32_t loglam = (idx == 0) ? 0u : (uint32_t)GF_LZ;
-		uint32_t logBp = (idx == 1) ? 0u : (uint32_t)GF_LZ;
-		int L = 0;
-		uint32_t logbb = 0;                                     // b = 1
-#pragma unroll 1
-		for (int r = 0; r < RS_R; r++) {
-			const uint32_t ls = (live && idx <= r && idx <= L) ? (uint32_t)s.logS[h][r - idx] : (uint32_t)GF_LZ;
-			int t = tb.exp2[loglam + ls];
-			// xor-reduce over the 32 lanes of this half (two DPP rows)
-			t ^= __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true);
-			t ^= __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xF, 0xF, true);
-			t ^= __builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, true);
-			t ^= __builtin_amdgcn_update_dpp(0, t, 0x140, 0xF, 0xF, true);
-			t ^= __builtin_amdgcn_update_dpp(0, t, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1 and 3
-			const int d0 = __builtin_amdgcn_readlane(t, 31), d1 = __builtin_amdgcn_readlane(t, 63);
-			const uint32_t delta = (uint32_t)(h ? d1 : d0);
-			const uint32_t logd = tb.log2[delta];
-			// lam -= (delta / b) * Bp ; with delta = 0 the index lands in the zero part of the table
-			const uint32_t upd = tb.exp2[logd + 255u - logbb + logBp];
-			const bool change = delta != 0u && 2 * L <= r;
-			const uint32_t loglam_old = loglam;
-			lam ^= upd;
-			loglam = tb.log2[lam];
-			int up = __shfl_up((int)(change ? loglam_old : logBp), 1, 32);
-			if (idx == 0) up = GF_LZ;
-			logBp = (uint32_t)up;
-			if (change) { L = r + 1 - L; logbb = logd; }
-		}
-		if (idx < RS_R + 2) { s.lam[h][idx] = (uint8_t)lam; s.loglam[h][idx] = (uint16_t)loglam; }
-		const unsigned long long nzl = __ballot(lam != 0);
-		const uint32_t halfmask = (uint32_t)(h ? (nzl >> 32) : nzl);
-		const int deg = halfmask ? 31 - __clz(halfmask) : 0;
-		if (idx == 0 && live) {
-			s.L[h] = L;
-			if (L > RS_T || deg != L) s.status[h] = -1;
-		}
-	}
-	WAVE_SYNC();
-
-	for (int c = 0; c < 2; c++) {
-		if (s.status[c] <= 0) continue;          // wave-uniform
-		const int L = s.L[c];
-		// ---- Chien search over the n positions of the shortened codeword, position i = lane + 64*it.
-		// Lambda has degree L, hence at most L roots among the 255 candidates: "L roots inside [0, n)" is the
-		// same condition as "L roots in all and none in the padding" (SPEC 3.3).  Term k at position i is
-		// lam[k] * alpha^(-i*k): its logarithm advances by (255 - i) mod 255 per k.
-		const int nit = (n + 63) >> 6;
-		uint32_t v[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, st[4];
-#pragma unroll
-		for (int it = 0; it < 4; it++) { const uint32_t i = (uint32_t)(lane + 64 * it); st[it] = i ? 255u - i : 0u; }
-#pragma unroll 1
-		for (int k = 0; k <= L; k++) {
-			const uint32_t ll = s.loglam[c][k];
-#pragma unroll
-			for (int it = 0; it < 4; it++) {
-				if (it < nit) {
-					v[it] ^= tb.exp2[ll + e[it]];
-					e[it] += st[it];
-					if (e[it] >= 255u) e[it] -= 255u;
-				}
-			}
-		}
-		int npos = 0;
-#pragma unroll
-		for (int it = 0; it < 4; it++) {
-			if (it < nit) {
-				const int i = lane + 64 * it;
-				const bool root = i < n && v[it] == 0u;
-				const unsigned long long rm = __ballot(root);
-				if (root) {
-					const int idx = npos + __popcll(rm & ((1ull << lane) - 1ull));
-					if (idx < RS_T) s.pos[c][idx] = i;
-				}
-				npos += __popcll(rm);
-			}
-		}
-		if (npos != L) {
-			if (lane == 0) s.status[c] = -1;
-			WAVE_SYNC();
-			continue;
-		}
-		// ---- omega = S*lam mod x^24
-		if (lane < RS_R) {
-			uint32_t om = 0;
-#pragma unroll 1
-			for (int k = 0; k <= lane && k <= L; k++) om ^= tb.exp2[(uint32_t)s.loglam[c][k] + (uint32_t)s.logS[c][lane - k]];
-			s.logom[c][lane] = tb.log2[om];
-		}
-		WAVE_SYNC();
-		// ---- Forney: e = X * omega(X^-1) / lam'(X^-1)
-		bool bad = false;
-		uint32_t ev = 0;
-		int p = 0;
-		if (lane < npos) {
-			p = s.pos[c][lane];
-			const uint32_t xi = p ? 255u - (uint32_t)p : 0u;
-			uint32_t num = 0, den = 0, ex = 0;
-#pragma unroll 1
-			for (int k = 0; k < RS_R; k++) {
-				num ^= tb.exp2[(uint32_t)s.logom[c][k] + ex];
-				ex += xi;
-				if (ex >= 255u) ex -= 255u;
-			}
-			uint32_t xi2 = 2u * xi;
-			if (xi2 >= 255u) xi2 -= 255u;
-			ex = 0;
-#pragma unroll 1
-			for (int k = 1; k <= L; k += 2) {
-				den ^= tb.exp2[(uint32_t)s.loglam[c][k] + ex];
-				ex += xi2;
-				if (ex >= 255u) ex -= 255u;
-			}
-			if (!den) bad = true;
-			else ev = tb.exp2[(uint32_t)p + (uint32_t)tb.log2[num] + 255u - (uint32_t)tb.log2[den]];
-		}
-		if (__ballot(bad) != 0ull) {
-			if (lane == 0) s.status[c] = -1;
-		} else {
-			if (lane < npos) s.cw[c][p] ^= (uint8_t)ev;
-			if (lane == 0) s.status[c] = npos;
-		}
-		WAVE_SYNC();
-	}
-}
-
-// ---------------------------------------------------------------- kernel B: per-frame de-whitening + RS
 // 256 threads = 4 waves = 4 frames per workgroup: the 2.8 KB of GF tables are staged once per
 // workgroup, each wave then works alone on its own frame (wave-scope synchronisation only), so that
 // all frames of a step are resident at once and their latency-bound GF(2^8) chains overlap.
 #define B2_WAVES 4
-static_assert(64 * B2_WAVES == 256, "the table staging below writes one log2 entry per thread");
 __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 	const uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const uint8_t *__restrict__ gf_exp, const uint8_t *__restrict__ gf_log, const uint32_t *__restrict__ gf_swar /* [24][8] */,
@@ -284,63 +39,8 @@ __global__ __launch_bounds__(64 * B2_WAVES) void sd_rsdec_rs41_kernel(
 	const int w = threadIdx.x >> 6;
 	const uint32_t k = B2_WAVES * blockIdx.y + (uint32_t)w;
 	if (k >= nfr) return;
-	FramerLds &s = wl[w];
-	const uint32_t *ring = bitring + (size_t)ch * ring_words;
-	const uint32_t mask = ring_words - 1;
-	const SdFrameDesc d = descs[(size_t)ch * max_frames + k];
-	const int flen = d.flen;
-	const uint8_t xinv = d.inv ? 0xFF : 0x00;
-	// K5: extract + de-whiten, four bytes per lane and step (the frame lengths are even, the word past the end
-	// is written whole and never read beyond flen)
-	{
-		const uint32_t winv = d.inv ? 0xFFFFFFFFu : 0u;
-		const uint32_t *mask32 = reinterpret_cast<const uint32_t *>(c_rs41_mask);
-		uint32_t *frame32 = reinterpret_cast<uint32_t *>(s.frame);
-		for (int i = lane; 4 * i < flen; i += 64) {
-			const uint64_t p = d.fstart + 32ull * (uint64_t)i;
-			const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
-			const uint64_t lo = (uint64_t)ring[w & mask] | ((uint64_t)ring[(w + 1) & mask] << 32);
-			frame32[i] = (uint32_t)(lo >> sh) ^ winv ^ mask32[i & 15];
-		}
-	}
-	WAVE_SYNC();
-	// K6: de-interleave into two shortened codewords
-	const int msglen = (flen - 56) / 2;
-	const int n = RS_R + msglen;
-	for (int i = lane; i < 2 * 256; i += 64) {
-		const int c = i >> 8, kk = i & 255;
-		uint8_t v = 0;
-		if (kk < RS_R) v = s.frame[8 + RS_R * c + kk];
-		else if (kk < n) v = s.frame[56 + 2 * (kk - RS_R) + c];
-		s.cw[c][kk] = v;
-	}
-	WAVE_SYNC();
-	rs255_decode_pair(tabs, s, n, lane, swar);
-	for (int c = 0; c < 2; c++) {
-		if (s.status[c] > 0) {
-			for (int kk = lane; kk < n; kk += 64) {
-				if (kk < RS_R) s.frame[8 + RS_R * c + kk] = s.cw[c][kk];
-				else s.frame[56 + 2 * (kk - RS_R) + c] = s.cw[c][kk];
-			}
-		}
-	}
-	WAVE_SYNC();
-	SondeFrame *fr = frames + (size_t)ch * max_frames + k;
-	if (lane == 0) {
-		fr->channel = ch;
-		fr->type = SONDE_RS41;
-		fr->len = flen;
-		fr->nerr[0] = s.status[0];
-		fr->nerr[1] = s.status[1];
-		fr->flags = d.inv ? 1u : 0u;
-		fr->bitpos = d.fstart;
-	}
-	for (int i = lane; i < SONDE_FRAME_MAX / 4; i += 64) {
-		const int rem = flen - 4 * i;                            // bytes of this word inside the frame
-		uint32_t wd = rem > 0 ? reinterpret_cast<const uint32_t *>(s.frame)[i] : 0u;
-		if (rem > 0 && rem < 4) wd &= (1u << (8 * rem)) - 1u;
-		reinterpret_cast<uint32_t *>(fr->data)[i] = wd;
-	}
+	sd_rs41_decode_frame<false>(tabs, wl[w], swar, bitring + (size_t)ch * ring_words, ring_words - 1,
+		descs[(size_t)ch * max_frames + k], frames + (size_t)ch * max_frames + k, ch, lane);
 }
 
 void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream, const uint32_t *bitring, uint32_t ring_words,

@@ -8,11 +8,17 @@
 // row chlist[i] (compact_in = false: the caller's buffer) or row i (compact_in = true: a per-list scratch buffer)
 // decim: the decimation factor (1, 2, 4) of EVERY channel this launch works on
 // where the in-kernel sync search of the RS41 channels (sd_rs41.h) keeps its state and lists the complete frames
-struct SdFramerOut { SdFramerState *fstates; void *descs; uint32_t *counts; uint32_t max_frames; };
+// and, for the FEC epilogue of the same kernel (sd_rsdec.h), the GF(2^8) tables and the frame slots
+struct SdFramerOut {
+	SdFramerState *fstates; void *descs; uint32_t *counts; uint32_t max_frames;
+	uint32_t fuse_fec;                      // 1: the demod kernel decodes the listed frames in its epilogue; 0: sd_rsdec_rs41_kernel does
+	const uint8_t *gf_exp, *gf_log; const uint32_t *gf_swar;
+	SondeFrame *frames;
+};
 void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist, bool compact_in, const SdFramerOut &fo);
+	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */);
 
 void sd_launch_afsk(bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
 	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride);

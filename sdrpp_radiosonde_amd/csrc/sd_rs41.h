@@ -23,19 +23,34 @@
 #define RS41_SYNC_LO 0x11CAB610u
 #define RS41_SYNC_HI 0xF8129622u
 
-struct SdSyncRun {                  // the wave-uniform working copy of SdFramerState + the frames listed so far
-	uint64_t rpos, fstart;
+struct SdSyncRun {                  // working copy of SdFramerState + the frames listed so far; lives in LDS between steps
+	uint64_t rpos, fstart;          // (scalar registers are scarce in the demod kernel: 80 at 8 waves per SIMD)
 	int32_t collecting, inv, flen;
 	uint32_t nout;
+	uint64_t wp_seen;               // bits the lead wave has announced (and mirrored) so far
 };
+
+__device__ __forceinline__ uint64_t sd_uniform64(unsigned long long v)    // a value all lanes hold alike -> scalar registers
+{
+	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 
 // Advance the state machine over the bits [.., wp) of the channel.  `mirror` holds the ring words of the newest
 // SD_MIRROR_WORDS * 32 bits (word w of the stream at mirror[w % SD_MIRROR_WORDS]); the caller guarantees that the
 // search never trails wp by more than that (it is called at least once per tile).  Wave-synchronous, 64 lanes,
 // all control flow wave-uniform.
-__device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &fs, uint64_t wp, const uint32_t *mirror, int lane,
+__device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t wp, const uint32_t *mirror, int lane,
 	SdFrameDesc *__restrict__ descs_ch, uint32_t max_frames)
 {
+	SdSyncRun fs;
+	fs.rpos = sd_uniform64(lds_state.rpos); fs.fstart = sd_uniform64(lds_state.fstart);
+	fs.collecting = __builtin_amdgcn_readfirstlane(lds_state.collecting);
+	fs.inv = __builtin_amdgcn_readfirstlane(lds_state.inv);
+	fs.flen = __builtin_amdgcn_readfirstlane(lds_state.flen);
+	fs.nout = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_state.nout);
+	// nothing to do in the common case: a frame is being collected and its end has not arrived
+	if (fs.collecting && fs.flen && wp < fs.fstart + 8 * (uint64_t)fs.flen) return;
 	for (;;) {
 		if (!fs.collecting) {
 			bool found = false;
@@ -61,17 +76,17 @@ __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &fs, uint64_t wp, co
 				if (next > wp - 63) next = wp - 63;                       // first position whose window is not complete yet
 				fs.rpos = next;
 			}
-			if (!found) return;
+			if (!found) break;
 		}
 		if (!fs.flen) {
-			if (wp < fs.fstart + 8 * (RS41_TYPE_POS + 1)) return;
+			if (wp < fs.fstart + 8 * (RS41_TYPE_POS + 1)) break;
 			const uint64_t p = fs.fstart + 8 * RS41_TYPE_POS;
 			const uint32_t wi = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
 			const uint32_t raw = __builtin_amdgcn_alignbit(mirror[(wi + 1) & (SD_MIRROR_WORDS - 1)], mirror[wi & (SD_MIRROR_WORDS - 1)], sh);
 			const uint32_t tb = (raw ^ (fs.inv ? 0xFFu : 0u) ^ RS41_TYPE_MASK) & 0xFFu;
 			fs.flen = (__popc(tb ^ 0xF0u) < __popc(tb ^ 0x0Fu)) ? RS41_LEN_EXT : RS41_LEN_STD;
 		}
-		if (wp < fs.fstart + 8 * (uint64_t)fs.flen) return;
+		if (wp < fs.fstart + 8 * (uint64_t)fs.flen) break;
 		if (fs.nout < max_frames && lane == 0) {
 			SdFrameDesc d;
 			d.fstart = fs.fstart; d.flen = fs.flen; d.inv = fs.inv;
@@ -82,4 +97,11 @@ __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &fs, uint64_t wp, co
 		fs.collecting = 0;
 		fs.flen = 0;
 	}
+	if (lane == 0) {
+		lds_state.rpos = fs.rpos; lds_state.fstart = fs.fstart;
+		lds_state.collecting = fs.collecting; lds_state.inv = fs.inv; lds_state.flen = fs.flen; lds_state.nout = fs.nout;
+	}
+	// the next step (same wave) reads the state back: DS operations of a wave execute in order
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
 }

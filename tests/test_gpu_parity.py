@@ -264,3 +264,25 @@ def test_rs41_wide_mode(oracle):
     assert len(good) >= sent - 2 * C_
     for f in good:
         assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in frames[f["channel"]])
+
+
+def test_split_fec_kernel_equals_fused_epilogue(oracle):
+    """SONDE_FLAG_SPLIT_FEC (Reed-Solomon as its own kernel) and the default (in the demod kernel's epilogue) give the
+    same frame records, both equal to the oracle's, across several submits (frames straddle submit boundaries)."""
+    from sdrpp_radiosonde_amd._lib import FLAG_SPLIT_FEC
+    C, n, parts = 12, TILE * 72, 3
+    sb = synth.make_rs41_batch(C, n, seed=21, ebn0_db=12.5)
+    iq = _dev(sb.iq)
+    outs = []
+    for flags in (0, FLAG_SPLIT_FEC):
+        b = SondeBatch(C, n // parts, flags=flags)
+        fr = []
+        for p in range(parts):
+            b.submit(iq[:, p * (n // parts): (p + 1) * (n // parts)].contiguous())
+            fr.append(b.frames())
+        outs.append(np.concatenate(fr))
+    ref = np.concatenate([ch.frames() for ch in _oracle_channels(oracle, sb.iq.numpy())])
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    assert len(ref) >= 3 * C and (ref["nerr"] > 0).any()
+    assert key(outs[0]).tobytes() == key(ref).tobytes()
+    assert key(outs[1]).tobytes() == key(ref).tobytes()
