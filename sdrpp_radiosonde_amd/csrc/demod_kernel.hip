@@ -47,6 +47,9 @@ __device__ __forceinline__ int wave_sum(int v)
 #define SD_LH      64     // samples of history kept in front of the tile in LDS
 #define SD_BUF     (SD_LH + SD_TILE + 4)
 #define SD_WGT     512    // workgroup: waves 0-3 run the timing-loop rounds, waves 4-7 the discriminator
+#ifndef SD_K4_WAVE
+#define SD_K4_WAVE 3      // which wave runs the RS41 sync search (K4): 3 = last round wave, 7 = last discriminator wave
+#endif
 
 // LDS: the discriminator samples of [tile_start - 64, tile_end) twice, so that every (d[x], d[x+1])
 // pair the FIR needs is one 8-byte-aligned ds_read_b64 with an immediate offset:
@@ -391,7 +394,30 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 
 	// ---- the two roles run separate loops (so that neither carries the other's live registers) with the
 	// same number of s_barriers: one after the prologue, then `rounds` per tile.  is_k is wave-uniform.
+	auto k4_load = [&]() {         // one lane: the channel's search state into LDS
+		const SdFramerState f0 = fo->fstates[ch];
+		s.k4.rpos = f0.rpos; s.k4.fstart = f0.fstart; s.k4.collecting = f0.collecting; s.k4.inv = f0.inv; s.k4.flen = f0.flen;
+		s.k4.nout = 0; s.k4.wp_seen = st.wpos;
+	};
+	auto k4_finish = [&]() {       // K4's wave, after barrier E: catch up with the last rounds' bits, state and frame count back to HBM
+		sd_rs41_sync_step(s.k4, sd_uniform64(s.pub.wpos), s.mirror, lane,
+			(SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames, fo->max_frames);
+		if (lane == 0) {
+			SdFramerState f1;
+			f1.rpos = s.k4.rpos; f1.fstart = s.k4.fstart; f1.collecting = s.k4.collecting; f1.inv = s.k4.inv; f1.flen = s.k4.flen; f1.pad = 0;
+			fo->fstates[ch] = f1;
+			fo->counts[ch] = s.k4.nout;
+		}
+	};
 	if (is_k) {
+		const bool k4d = framing && SD_K4_WAVE == 7 && wave == 7;
+		if (k4d && lane == 0) k4_load();
+		// K4 on a discriminator wave: behind its loads, over the bits the lead wave has announced by then (LDS operations
+		// of a wave are performed in order, so whoever sees the new wpos also sees the mirror words written before it)
+		auto k4_step = [&]() {
+			if (k4d) sd_rs41_sync_step(s.k4, sd_uniform64(__hip_atomic_load(&s.pub.wpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
+				s.mirror, lane, (SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames, fo->max_frames);
+		};
 		load_tile(0, va, pa, qa);
 		if (n_tiles > 1) load_tile(1, vb, pb, qb);
 		k1_tile(0, va, pa, qa);
@@ -406,6 +432,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				k1_tile(1, vb, pb, qb);
 				if (tile + 3 < n_tiles) load_tile(tile + 3, vb, pb, qb);
 			}
+			k4_step();
 			for (int r = 0; r < rounds; r++) __syncthreads();
 			if (tile + 1 >= n_tiles) break;
 			if (tile + 2 < n_tiles) {
@@ -414,10 +441,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				k1_tile(0, va, pa, qa);
 				if (tile + 4 < n_tiles) load_tile(tile + 4, va, pa, qa);
 			}
+			k4_step();
 			for (int r = 0; r < rounds; r++) __syncthreads();
 		}
 		if (IS_IQ && t == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
 		__syncthreads();                                   // (E)
+		if (k4d) k4_finish();
 	} else {
 		// the round waves are the critical path of a tile (update -> FIR -> reduction, all dependent);
 		// the discriminator waves only have to be done by the next barrier: let the round waves win
@@ -425,12 +454,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (lead) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
 		// K4 (wave 3 of an RS41 channel only): its state sits in LDS between steps, the output pointers in a
 		// descriptor in HBM -- scalar registers are the scarce resource of this kernel
-		const bool k4 = framing && rwave == 3;
-		if (k4 && lane == 0) {
-			const SdFramerState f0 = fo->fstates[ch];
-			s.k4.rpos = f0.rpos; s.k4.fstart = f0.fstart; s.k4.collecting = f0.collecting; s.k4.inv = f0.inv; s.k4.flen = f0.flen;
-			s.k4.nout = 0; s.k4.wp_seen = st.wpos;
-		}
+		const bool k4 = framing && SD_K4_WAVE == 3 && rwave == 3;
+		if (k4 && lane == 0) k4_load();
 		__syncthreads();
 		int K_total = 0;
 		for (int tile = 0; tile < n_tiles; tile++) {
@@ -473,17 +498,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (lead && pendK >= 0) round_back(pendK, (int)((seq & 1u) ^ 1u));
 		if (lead && lane == 0) s.pub.wpos = st.wpos;
 		__syncthreads();                                   // (E) matched by the discriminator role's last barrier
-		if (k4) {
-			// ... and K4's catch-up over the last rounds' bits; the search state and the number of listed frames go back to HBM
-			sd_rs41_sync_step(s.k4, sd_uniform64(s.pub.wpos), s.mirror, lane,
-				(SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames, fo->max_frames);
-			if (lane == 0) {
-				SdFramerState f1;
-				f1.rpos = s.k4.rpos; f1.fstart = s.k4.fstart; f1.collecting = s.k4.collecting; f1.inv = s.k4.inv; f1.flen = s.k4.flen; f1.pad = 0;
-				fo->fstates[ch] = f1;
-				fo->counts[ch] = s.k4.nout;
-			}
-		}
+		if (k4) k4_finish();      // ... and K4's catch-up over the last rounds' bits
 	}
 
 	// ---- common epilogue (after barrier E): carry history and state to the next submit
@@ -509,9 +524,16 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			const unsigned long long *dg = reinterpret_cast<const unsigned long long *>((const SdFrameDesc *)fo->descs + (size_t)ch * max_frames);
 			SondeFrame *fout = fo->frames + (size_t)ch * max_frames;
 			for (uint32_t k = (uint32_t)wave; k < nfr; k += SD_WGT / 64) {
-				// the descriptor was stored by wave 3 of this workgroup a moment ago: agent-scope loads (L2), like the ring words
-				const unsigned long long d0 = __hip_atomic_load(dg + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const unsigned long long d1 = __hip_atomic_load(dg + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				// the descriptor: from K4's list in LDS, or (beyond its first entries) from HBM, where wave 3 of this workgroup
+				// stored it a moment ago: agent-scope loads (L2), like the ring words
+				unsigned long long d0, d1;
+				if (k < SD_K4_LIST) {
+					const unsigned long long *dl = reinterpret_cast<const unsigned long long *>(&s.k4.list[k]);
+					d0 = dl[0]; d1 = dl[1];
+				} else {
+					d0 = __hip_atomic_load(dg + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					d1 = __hip_atomic_load(dg + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 				SdFrameDesc d;
 				d.fstart = sd_uniform64(d0);
 				d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "sonde_dev.h"
 
+#define SD_K4_LIST 8
 #define RS41_SYNC_THR 6
 #define RS41_LEN_STD  320
 #define RS41_LEN_EXT  518
@@ -28,6 +29,7 @@ struct SdSyncRun {                  // working copy of SdFramerState + the frame
 	int32_t collecting, inv, flen;
 	uint32_t nout;
 	uint64_t wp_seen;               // bits the lead wave has announced (and mirrored) so far
+	SdFrameDesc list[SD_K4_LIST];   // the first frames listed in this launch, for the FEC epilogue (the full list is in HBM)
 };
 
 __device__ __forceinline__ uint64_t sd_uniform64(unsigned long long v)    // a value all lanes hold alike -> scalar registers
@@ -91,6 +93,7 @@ __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t
 			SdFrameDesc d;
 			d.fstart = fs.fstart; d.flen = fs.flen; d.inv = fs.inv;
 			descs_ch[fs.nout] = d;
+			if (fs.nout < SD_K4_LIST) lds_state.list[fs.nout] = d;
 		}
 		fs.nout++;
 		fs.rpos = fs.fstart + 8 * (uint64_t)fs.flen;

@@ -163,87 +163,87 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 	}
 	WAVE_SYNC();
 
-	for (int c = 0; c < 2; c++) {
-		if (s.status[c] <= 0) continue;          // wave-uniform
-		const int L = s.L[c];
-		// ---- Chien search over the n positions of the shortened codeword, position i = lane + 64*it.
+	// ---- Chien search, omega and Forney for BOTH codewords at once: half-wave h = lane >> 5 works on codeword h, its
+	// 32 lanes on 32 positions (coefficients, errors) at a time.  The table look-ups of different k are independent, so
+	// the loops are unrolled to keep several LDS reads in flight (they were one dependent read after the other, and one
+	// codeword after the other: 7 of the 18 us this stage cost at the end of the demod kernel).
+	{
+		const int h = lane >> 5, idx = lane & 31;
+		const bool live = s.status[h] > 0;
+		const int L = live ? s.L[h] : 0;
+		const uint16_t *ll = s.loglam[h];
+		// Chien search over the n positions of the shortened codeword, position i = idx + 32*it.
 		// Lambda has degree L, hence at most L roots among the 255 candidates: "L roots inside [0, n)" is the
 		// same condition as "L roots in all and none in the padding" (SPEC 3.3).  Term k at position i is
 		// lam[k] * alpha^(-i*k): its logarithm advances by (255 - i) mod 255 per k.
-		const int nit = (n + 63) >> 6;
-		uint32_t v[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, st[4];
-#pragma unroll
-		for (int it = 0; it < 4; it++) { const uint32_t i = (uint32_t)(lane + 64 * it); st[it] = i ? 255u - i : 0u; }
-#pragma unroll 1
-		for (int k = 0; k <= L; k++) {
-			const uint32_t ll = s.loglam[c][k];
-#pragma unroll
-			for (int it = 0; it < 4; it++) {
-				if (it < nit) {
-					v[it] ^= tb.exp2[ll + e[it]];
-					e[it] += st[it];
-					if (e[it] >= 255u) e[it] -= 255u;
-				}
-			}
-		}
 		int npos = 0;
-#pragma unroll
-		for (int it = 0; it < 4; it++) {
-			if (it < nit) {
-				const int i = lane + 64 * it;
-				const bool root = i < n && v[it] == 0u;
-				const unsigned long long rm = __ballot(root);
-				if (root) {
-					const int idx = npos + __popcll(rm & ((1ull << lane) - 1ull));
-					if (idx < RS_T) s.pos[c][idx] = i;
-				}
-				npos += __popcll(rm);
-			}
-		}
-		if (npos != L) {
-			if (lane == 0) s.status[c] = -1;
-			WAVE_SYNC();
-			continue;
-		}
-		// ---- omega = S*lam mod x^24
-		if (lane < RS_R) {
-			uint32_t om = 0;
+		const int nit = (n + 31) >> 5;
 #pragma unroll 1
-			for (int k = 0; k <= lane && k <= L; k++) om ^= tb.exp2[(uint32_t)s.loglam[c][k] + (uint32_t)s.logS[c][lane - k]];
-			s.logom[c][lane] = tb.log2[om];
+		for (int it = 0; it < nit; it++) {
+			const uint32_t i = (uint32_t)(idx + 32 * it);
+			const uint32_t st = (i && i < 255u) ? 255u - i : 0u;
+			uint32_t v = 0, e = 0;
+#pragma unroll 4
+			for (int k = 0; k <= L; k++) {
+				v ^= tb.exp2[(uint32_t)ll[k] + e];
+				e += st;
+				if (e >= 255u) e -= 255u;
+			}
+			const bool root = live && (int)i < n && v == 0u;
+			const unsigned long long rm = __ballot(root);
+			const uint32_t rmh = h ? (uint32_t)(rm >> 32) : (uint32_t)rm;
+			if (root) {
+				const int slot = npos + __popc(rmh & ((1u << idx) - 1u));
+				if (slot < RS_T) s.pos[h][slot] = (int)i;
+			}
+			npos += __popc(rmh);
+		}
+		const bool ok = live && npos == L;
+		if (live && !ok && idx == 0) s.status[h] = -1;
+		// ---- omega = S*lam mod x^24
+		if (ok && idx < RS_R) {
+			uint32_t om = 0;
+			const int kmax = idx < L ? idx : L;
+#pragma unroll 4
+			for (int k = 0; k <= kmax; k++) om ^= tb.exp2[(uint32_t)ll[k] + (uint32_t)s.logS[h][idx - k]];
+			s.logom[h][idx] = tb.log2[om];
 		}
 		WAVE_SYNC();
-		// ---- Forney: e = X * omega(X^-1) / lam'(X^-1)
+		// ---- Forney: e = X * omega(X^-1) / lam'(X^-1), one error per lane
 		bool bad = false;
 		uint32_t ev = 0;
 		int p = 0;
-		if (lane < npos) {
-			p = s.pos[c][lane];
+		if (ok && idx < npos) {
+			p = s.pos[h][idx];
 			const uint32_t xi = p ? 255u - (uint32_t)p : 0u;
 			uint32_t num = 0, den = 0, ex = 0;
-#pragma unroll 1
+#pragma unroll 4
 			for (int k = 0; k < RS_R; k++) {
-				num ^= tb.exp2[(uint32_t)s.logom[c][k] + ex];
+				num ^= tb.exp2[(uint32_t)s.logom[h][k] + ex];
 				ex += xi;
 				if (ex >= 255u) ex -= 255u;
 			}
 			uint32_t xi2 = 2u * xi;
 			if (xi2 >= 255u) xi2 -= 255u;
 			ex = 0;
-#pragma unroll 1
+#pragma unroll 2
 			for (int k = 1; k <= L; k += 2) {
-				den ^= tb.exp2[(uint32_t)s.loglam[c][k] + ex];
+				den ^= tb.exp2[(uint32_t)ll[k] + ex];
 				ex += xi2;
 				if (ex >= 255u) ex -= 255u;
 			}
 			if (!den) bad = true;
 			else ev = tb.exp2[(uint32_t)p + (uint32_t)tb.log2[num] + 255u - (uint32_t)tb.log2[den]];
 		}
-		if (__ballot(bad) != 0ull) {
-			if (lane == 0) s.status[c] = -1;
-		} else {
-			if (lane < npos) s.cw[c][p] ^= (uint8_t)ev;
-			if (lane == 0) s.status[c] = npos;
+		const unsigned long long bm = __ballot(bad);
+		const bool anybad = (h ? (uint32_t)(bm >> 32) : (uint32_t)bm) != 0u;     // a zero denominator voids the whole codeword
+		if (ok) {
+			if (anybad) {
+				if (idx == 0) s.status[h] = -1;
+			} else {
+				if (idx < npos) s.cw[h][p] ^= (uint8_t)ev;
+				if (idx == 0) s.status[h] = npos;
+			}
 		}
 		WAVE_SYNC();
 	}
