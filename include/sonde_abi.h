@@ -142,10 +142,13 @@ long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap);
  * one stateful parser per channel.  Call repeatedly until it returns 0; fragments not fetched before the next
  * submit's poll are kept and delivered first.  Returns the number written (<= cap) or a negative error. */
 long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t cap);
-/* Average device time (ms) of the demod and of the framer kernel over the submits since the previous
- * call of this function (at most the last 128), from HIP events recorded on the submit stream around
- * each launch.  Synchronises. */
+/* Average device time (ms) of the demod kernel (for RS41 channels it includes the sync search and the FEC epilogue) and of
+ * the framer/FEC kernels behind it (0 if there are none) over the TIMED submits since the previous call of this function
+ * (at most the last 128), from HIP events recorded on the submit stream around each launch.  Synchronises.
+ * Every event record is a bubble of a few microseconds in the command stream, so by default only every 8th submit is
+ * timed; sonde_batch_set_timing changes that (1 = every submit, 0 = none) and restarts the count, so the next submit is timed. */
 int  sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *framer_ms);
+int  sonde_batch_set_timing(SondeBatch *b, int every_n);
 
 /* introspection for staged parity tests */
 int      sonde_batch_read_bits(SondeBatch *b, uint32_t channel, uint64_t from, size_t count, uint8_t *out /* one bit per byte */);

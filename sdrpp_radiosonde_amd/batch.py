@@ -115,6 +115,10 @@ class SondeBatch:
         self._chk(self.L.sonde_batch_kernel_ms(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_timing(self, every_n: int):
+        """Record kernel-timing events on every n-th submit only (0: never); the next submit is timed."""
+        self._chk(self.L.sonde_batch_set_timing(self.h, int(every_n)))
+
     def nbits(self, channel: int) -> int:
         return int(self.L.sonde_batch_nbits(self.h, channel))
 

@@ -129,6 +129,11 @@ struct SondeBatch {
 	static const int kEvSlots = 128;       // submits timed between two sonde_batch_kernel_ms() calls
 	hipEvent_t ev[3 * kEvSlots] = {};
 	int ev_used = 0;
+	// an event record is a bubble of a few microseconds in the command stream (three of them cost a 0.29 ms step 3 %), so
+	// only every timing_every-th submit is timed (0: none)
+	int timing_every = 8;
+	unsigned long n_submits = 0;
+	bool ev_has_framer[kEvSlots] = {};
 	hipStream_t last_stream = nullptr;
 	bool pending = false, have_counts = false;
 	std::vector<uint32_t> h_counts;
@@ -357,8 +362,10 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	HIPCHK(hipSetDevice(b->device));
 	hipStream_t stream = (hipStream_t)stream_;
 	const int n_tiles = (int)(n_samples / SONDE_TILE);
+	const bool timed = b->timing_every > 0 && b->n_submits % (unsigned long)b->timing_every == 0;
+	b->n_submits++;
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
-	HIPCHK(hipEventRecord(ev[0], stream));
+	if (timed) HIPCHK(hipEventRecord(ev[0], stream));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
 	const bool iq = b->input_kind == SONDE_INPUT_IQ;
 	const SdFramerOut *fo = b->d_fo;    // RS41 channels: the demod kernel runs the sync search itself and lists complete frames there
@@ -389,27 +396,34 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		}
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(ev[1], stream));
+	if (timed) HIPCHK(hipEventRecord(ev[1], stream));
+	bool framer_launched = false;
 	// d_counts: zeroed at creation; every sync kernel rewrites the entry of each channel it owns on every submit
 	if (!b->chlist[SONDE_RS41].empty() && !b->fuse_fec) {
 		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
 			b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_descs,
 			b->d_frames, b->d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);
 		HIPCHK(hipGetLastError());
+		framer_launched = true;
 	}
 	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10 }) {
 		if (b->chlist[t].empty()) continue;
 		sd_launch_framer_other(t, (uint32_t)b->chlist[t].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
 			b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t]);
 		HIPCHK(hipGetLastError());
+		framer_launched = true;
 	}
 	if (n_afsk) {
 		sd_launch_framer_imet((uint32_t)n_afsk, stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
 			b->d_frames, b->d_counts, b->max_frames, b->d_chlist[SONDE_IMET4]);
 		HIPCHK(hipGetLastError());
+		framer_launched = true;
 	}
-	HIPCHK(hipEventRecord(ev[2], stream));
-	b->ev_used++;
+	if (timed) {
+		if (framer_launched) HIPCHK(hipEventRecord(ev[2], stream));     // nothing behind the demod kernel: no third bubble
+		b->ev_has_framer[b->ev_used % SondeBatch::kEvSlots] = framer_launched;
+		b->ev_used++;
+	}
 	b->last_stream = stream;
 	b->pending = true;
 	b->have_counts = false;
@@ -525,17 +539,27 @@ extern "C" int sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *fram
 	if (sonde_batch_sync(b) < 0) return -1;
 	float a = 0.0f, c = 0.0f;
 	const int n = std::min(b->ev_used, (int)SondeBatch::kEvSlots);
-	if (n == 0) return fail("sonde_batch_kernel_ms: no submit since the last query");
+	if (n == 0) return fail("sonde_batch_kernel_ms: no timed submit since the last query (sonde_batch_set_timing)");
 	for (int i = 0; i < n; i++) {
 		float x = 0.0f, y = 0.0f;
 		HIPCHK(hipEventElapsedTime(&x, b->ev[3 * i], b->ev[3 * i + 1]));
-		HIPCHK(hipEventElapsedTime(&y, b->ev[3 * i + 1], b->ev[3 * i + 2]));
+		if (b->ev_has_framer[i]) HIPCHK(hipEventElapsedTime(&y, b->ev[3 * i + 1], b->ev[3 * i + 2]));
 		a += x; c += y;
 	}
 	a /= (float)n; c /= (float)n;
 	b->ev_used = 0;
 	if (demod_ms) *demod_ms = a;
 	if (framer_ms) *framer_ms = c;
+	return 0;
+}
+
+extern "C" int sonde_batch_set_timing(SondeBatch *b, int every_n)
+{
+	if (!b || every_n < 0) return fail("sonde_batch_set_timing: bad argument");
+	if (sonde_batch_sync(b) < 0) return -1;
+	b->timing_every = every_n;
+	b->n_submits = 0;
+	b->ev_used = 0;
 	return 0;
 }
 
