@@ -53,6 +53,64 @@ extern "C" float sonde_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0
 	return rh;
 }
 
+// RS41-SGP pressure sensor: a capacitance measured like the other sensors (count f between two reference counts),
+// mapped to hPa by a polynomial in the normalised count and the sensor's own temperature; 18 coefficients sit in the
+// calibration memory at 0x25E.. and fill a 6 x 4 matrix (rows: powers of cfP[24]/fp, columns: powers of T) in the
+// order the public RS41 decoders read them ([RECALL]; the reference only reads fragment.pressure,
+// /root/reference/src/decode/decoder.hpp:89).  Single precision, row-major accumulation.
+extern "C" float sonde_rs41_pressure(uint32_t f, uint32_t f1, uint32_t f2, float tpress, const float *cfP /* [25] */)
+{
+	if (f1 == f2 || f1 == f) return 0.0f;
+	const float a0 = cfP[24] / (((float)f - (float)f1) / ((float)f2 - (float)f1));
+	const float a1 = tpress;
+	float p = 0.0f, a0j = 1.0f;
+	for (int j = 0; j < 6; j++) {
+		float a1k = 1.0f;
+		for (int k = 0; k < 4; k++) {
+			p = p + a0j * a1k * cfP[j * 4 + k];
+			a1k = a1k * a1;
+		}
+		a0j = a0j * a0;
+	}
+	return p;
+}
+
+// calibration memory -> cfP[25]: 0x25E + 4i, i = 0..17, scattered into the matrix as the public decoders do ([RECALL])
+static const uint8_t k_rs41_cfp_slot[18] = { 0, 4, 8, 12, 16, 20, 24, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11 };
+
+// Ozone partial pressure (mPa) of an ECC ozonesonde from its cell current (uA) and pump temperature (deg C):
+// P = 4.3085e-4 * (I - I_bg) * T_pump[K] * t100, t100 = seconds the pump needs for 100 ml (nominal 28 s; the
+// per-instrument value and the background current are flight-preparation data the sonde does not transmit).
+// Behind fragment.o3_mpa (decoder.hpp:102-106; the body is in the absent sondedump) [RECALL].
+extern "C" float sonde_ozone_mpa(float cell_ua, float tpump_c)
+{
+	const float t100 = 28.0f, ibg = 0.0f;
+	const float p = 4.3085e-4f * (cell_ua - ibg) * (tpump_c + 273.15f) * t100;
+	return p > 0.0f ? p : 0.0f;
+}
+
+static int hexval(int c) { return (c >= '0' && c <= '9') ? c - '0' : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : -1; }
+static bool hexfield(const uint8_t *p, int n, uint32_t *out)
+{
+	uint32_t v = 0;
+	for (int i = 0; i < n; i++) { const int h = hexval(p[i]); if (h < 0) return false; v = (v << 4) | (uint32_t)h; }
+	*out = v;
+	return true;
+}
+// XDATA of an OIF411 ozone interface, ASCII hex: "05" instrument type, 2 instrument number, 4 pump temperature (0.01 C),
+// 5 cell current (0.0001 uA), 2 battery (0.1 V), 3 pump current (mA), 2 external voltage (0.1 V) [RECALL: public XDATA notes]
+static bool xdata_ozone_ascii(const uint8_t *p, int n, float *o3)
+{
+	for (int i = 0; i + 20 <= n; i++) {
+		if (p[i] != '0' || p[i + 1] != '5') continue;
+		uint32_t num, tp, cur;
+		if (!hexfield(p + i + 2, 2, &num) || !hexfield(p + i + 4, 4, &tp) || !hexfield(p + i + 8, 5, &cur)) continue;
+		*o3 = sonde_ozone_mpa((float)cur * 1.0e-4f, (float)(int16_t)tp * 0.01f);
+		return true;
+	}
+	return false;
+}
+
 // WGS84 ECEF (metres) -> geodetic latitude/longitude (degrees) and height (metres)
 static void ecef_to_lla(double x, double y, double z, double *lat, double *lon, double *alt)
 {
@@ -171,8 +229,8 @@ static long long days_from_civil(int y, int m, int d)
 
 // DFM06/09/17: frame = 33 corrected Hamming codewords (data nibble = high nibble): 7 CONF, 13 DAT1, 13 DAT2.
 // Each DAT block = 48 payload bits + sub-packet id nibble (ids per public DFM notes):
-//   0 frame counter, 1 UTC ms of minute, 2 lat (1e-7 deg) + ground speed (cm/s), 3 lon + heading (0.01 deg),
-//   4 altitude (cm) + climb (cm/s), 8 date/time.
+//   0 frame counter (8 bits at bit 24 of the payload), 1 UTC ms of minute (last 16 bits), 2 lat (1e-7 deg) + ground
+//   speed (cm/s), 3 lon + heading (0.01 deg), 4 altitude (cm) + climb (cm/s), 8 date/time (12/4/5/5/6 bits from the top).
 // DFM temperature (public DFM-09 decoders' formula, [RECALL]): the CONF block carries one measurement channel per
 // frame as a 24-bit float (20-bit mantissa / 2^exponent); channel 0 is the NTC thermistor, 3 and 4 the references.
 extern "C" float sonde_dfm_temp(float f, float f1, float f2)
@@ -220,12 +278,12 @@ void SondeParser::feed_dfm(const SondeFrame &f, std::vector<SondeData> &out)
 		switch (id) {
 		case 0:
 			sd.fields = DATA_SEQ;
-			sd.seq = (int)((pay >> 24) & 0xFFFF);
+			sd.seq = (int)((pay >> 16) & 0xFF);
 			break;
 		case 1:
 			if (m_dfm_date >= 0) {
 				sd.fields = DATA_TIME;
-				sd.time = (time_t)(m_dfm_date + (long long)((pay >> 16) & 0xFFFF) / 1000);
+				sd.time = (time_t)(m_dfm_date + (long long)(pay & 0xFFFF) / 1000);
 			}
 			break;
 		case 2:

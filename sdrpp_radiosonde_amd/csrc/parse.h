@@ -15,6 +15,7 @@ private:
 	void feed_dfm(const SondeFrame &f, std::vector<SondeData> &out);
 	void feed_m10(const SondeFrame &f, std::vector<SondeData> &out);
 	void feed_imet(const SondeFrame &f, std::vector<SondeData> &out);
+	void feed_ims100(const SondeFrame &f, std::vector<SondeData> &out);
 	int m_type;
 	uint64_t m_calib_mask = 0;         // RS41: which of the 51 calibration fragments have been seen
 	uint8_t m_calib[51 * 16] = {};
@@ -24,6 +25,9 @@ private:
 	int m_dfm_have = 0;               // bit0 lat, bit1 lon
 	float m_dfm_meas[5] = {};         // CONF measurement channels 0..4
 	unsigned m_dfm_meas_mask = 0;
+	// iMS-100 / RS-11G: the calibration words arrive one per frame (frame counter mod 4)
+	uint32_t m_ims_cal[4] = {};
+	unsigned m_ims_cal_mask = 0;
 };
 
 uint16_t sonde_crc16_ccitt(const uint8_t *p, size_t n);
