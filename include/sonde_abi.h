@@ -175,6 +175,15 @@ float sonde_rs41_temp(uint32_t f, uint32_t f1, uint32_t f2, float rf1, float rf2
 float sonde_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float temp);
 /* DFM thermistor: measurement channel 0 against the reference channels 3 and 4 (already converted from 24-bit floats) */
 float sonde_dfm_temp(float f, float f1, float f2);
+/* RS41-SGP pressure (hPa) from the sensor counts, the sensor temperature (deg C) and the 25-entry coefficient matrix */
+float sonde_rs41_pressure(uint32_t f, uint32_t f1, uint32_t f2, float tpress, const float *cfP /* [25] */);
+/* ozone partial pressure (mPa) of an ECC ozonesonde (RS41 / iMet XDATA) from cell current (uA) and pump temperature (deg C) */
+float sonde_ozone_mpa(float cell_ua, float tpump_c);
+/* M10 / M20 / iMS-100 sensor conversions behind fragment.temp / .rh */
+float sonde_m10_temp(unsigned scale, unsigned adc);
+float sonde_m10_rh(uint32_t cap_sensor, uint32_t cap_ref, float temp);
+float sonde_m20_temp(unsigned adc);
+float sonde_ims100_temp(uint32_t f, float c0, float c1, float c2);
 
 /* ------------------------------------------------------------------ wideband front-end (BASELINE config 4)
  * 10 MS/s complex IQ -> 512-bin polyphase channelizer (19531.25 Hz spacing, 40 kS/s per bin) -> per-bin FM

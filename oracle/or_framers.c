@@ -178,22 +178,27 @@ static int m10_run(OrFramerPub *f, const uint8_t *bits, uint64_t wpos)
 	int produced = 0;
 	while (next_fixed(f, bits, wpos, sync, 32, M10_SYNC_THR, 1, M10_FRAME_CHIPS)) {
 		OrFrame *fr = push_frame(f);
-		fr->len = M10_FRAME_BYTES;
 		fr->flags = f->inv ? 1u : 0u;
 		fr->bitpos = f->fstart;
-		int viol = 0;
-		for (int i = 0; i < M10_FRAME_BYTES; i++) {
+		/* the first byte is the length of what follows: 0x64 = M10 (101 bytes in all), 0x45 = M20 (70); the window
+		 * behind the sync is always 101 bytes long, whatever lies behind an M20 frame is dropped */
+		int viol = 0, total = M10_FRAME_BYTES;
+		for (int i = 0; i < total; i++) {
 			uint8_t v = 0;
+			int vi = 0;
 			for (int k = 0; k < 8; k++) {
 				const uint64_t p = f->fstart + 32 + 16 * (uint64_t)i + 2 * (uint64_t)k;
 				const int a = bits[p] ^ f->inv, b = bits[p + 1] ^ f->inv;
 				v = (uint8_t)((v << 1) | a);                 /* 10 -> 1, 01 -> 0, MSB first */
-				viol += (a == b);
+				vi += (a == b);
 			}
 			fr->data[i] = v;
+			viol += vi;
+			if (i == 0 && v == 0x45) total = 70;
 		}
-		const unsigned cs = or_m10_checksum(fr->data, M10_FRAME_BYTES - 2);
-		fr->nerr[0] = (cs == (((unsigned)fr->data[99] << 8) | fr->data[100])) ? 0 : -1;
+		fr->len = total;
+		const unsigned cs = or_m10_checksum(fr->data, (size_t)total - 2);
+		fr->nerr[0] = (cs == (((unsigned)fr->data[total - 2] << 8) | fr->data[total - 1])) ? 0 : -1;
 		fr->nerr[1] = viol;
 		produced++;
 		done_fixed(f, M10_FRAME_CHIPS);

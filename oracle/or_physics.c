@@ -84,3 +84,61 @@ float or_dfm_temp(float f, float f1, float f2)
 	if (!(R > 0.0f)) return -273.15f;
 	return 1.0f / (1.0f / T0 + 1.0f / B0 * logf(R / R0)) - 273.15f;
 }
+
+/* ---- independent double-precision restatements of the sensor conversions added in round 2 (product: single precision,
+ * csrc/parse.cpp).  Written in a different algebraic form on purpose (Horner instead of running powers, exp/log
+ * rearranged): tests compare within a stated tolerance, not bit for bit, so that they are not a self-comparison.
+ * Formulas: public decoders' models [RECALL]; the reference only reads fragment.temp/.rh/.pressure/.o3_mpa
+ * (/root/reference/src/decode/decoder.hpp:87-89,104). */
+double or_rs41_pressure_d(uint32_t f, uint32_t f1, uint32_t f2, double tpress, const float *cfP)
+{
+	if (f1 == f2 || f1 == f) return 0.0;
+	const double fp = ((double)f - (double)f1) / ((double)f2 - (double)f1);
+	const double a0 = (double)cfP[24] / fp;
+	double p = 0.0;
+	for (int j = 5; j >= 0; j--) {                 /* Horner in a0, inner Horner in the sensor temperature */
+		double row = 0.0;
+		for (int k = 3; k >= 0; k--) row = row * tpress + (double)cfP[4 * j + k];
+		p = p * a0 + row;
+	}
+	return p;
+}
+
+double or_ozone_mpa_d(double cell_ua, double tpump_c)
+{
+	/* P[mPa] = 0.043085 * T[K] * I[uA] / flow[ml/s], flow = 100 ml / 28 s */
+	const double flow = 100.0 / 28.0;
+	const double p = 0.043085 * (tpump_c + 273.15) * cell_ua / flow;
+	return p > 0.0 ? p : 0.0;
+}
+
+double or_m10_temp_d(unsigned scale, unsigned adc)
+{
+	static const double Rs[3] = { 12.1e3, 36.5e3, 475.0e3 }, Gp[3] = { 0.0, 1.0 / 330.0e3, 1.0 / 2000.0e3 };
+	if (scale > 2 || adc == 0 || adc >= 4095) return -273.15;
+	/* divider: Vout/Vcc = adc/4095 across Rs, the thermistor in parallel with Rp on top.  In conductances:
+	 * 1/R = (Vcc - Vout)/(Vout Rs) - 1/Rp */
+	const double g = ((4095.0 - (double)adc) / (double)adc) / Rs[scale] - Gp[scale];
+	if (!(g > 0.0)) return -273.15;
+	const double l = -log(g);
+	return 1.0 / (1.07303516e-03 + l * (2.41296733e-04 + l * (2.26744154e-06 + l * 6.52855181e-08))) - 273.15;
+}
+
+double or_m10_rh_d(uint32_t cap_sensor, uint32_t cap_ref, double T)
+{
+	if (cap_ref == 0) return -1.0;
+	double rh = ((double)cap_sensor - 0.8955 * (double)cap_ref) / (0.002 * (double)cap_ref) + 0.03 * (20.0 - T);
+	return rh < 0.0 ? 0.0 : (rh > 100.0 ? 100.0 : rh);
+}
+
+double or_m20_temp_d(unsigned adc)
+{
+	if (adc == 0 || adc >= 4095) return -273.15;
+	const double lr = log(22.1e3 / 15.0e3) + log((double)adc) - log(4095.0 - (double)adc);
+	return 3450.0 * 273.15 / (3450.0 + 273.15 * lr) - 273.15;
+}
+
+double or_ims100_temp_d(uint32_t f, double c0, double c1, double c2)
+{
+	return c0 + (double)f * (c1 + (double)f * c2);
+}

@@ -155,6 +155,13 @@ float or_altitude_to_pressure(float alt);
 float or_rs41_temp(uint32_t f, uint32_t f1, uint32_t f2, float rf1, float rf2, const float *co, const float *cal);
 float or_rs41_rh(uint32_t f, uint32_t f1, uint32_t f2, float calh0, float T);
 float or_dfm_temp(float f, float f1, float f2);
+/* double-precision, differently factored restatements (compared within a tolerance, tests/test_parsers_cpu.py) */
+double or_rs41_pressure_d(uint32_t f, uint32_t f1, uint32_t f2, double tpress, const float *cfP);
+double or_ozone_mpa_d(double cell_ua, double tpump_c);
+double or_m10_temp_d(unsigned scale, unsigned adc);
+double or_m10_rh_d(uint32_t cap_sensor, uint32_t cap_ref, double T);
+double or_m20_temp_d(unsigned adc);
+double or_ims100_temp_d(uint32_t f, double c0, double c1, double c2);
 
 #ifdef __cplusplus
 }

@@ -53,7 +53,8 @@ ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
     "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
-    "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp",
+    "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp", "sonde_rs41_pressure", "sonde_ozone_mpa",
+    "sonde_m10_temp", "sonde_m10_rh", "sonde_m20_temp", "sonde_ims100_temp",
     "sonde_last_error", "sonde_version", "sonde_hbm_read_probe", "sonde_dewpt", "sonde_altitude_to_pressure",
     "sonde_gpx_open", "sonde_gpx_close", "sonde_gpx_start_track", "sonde_gpx_stop_track", "sonde_gpx_add_point",
     "sonde_ptu_open", "sonde_ptu_close", "sonde_ptu_add_point",
@@ -112,6 +113,18 @@ def load() -> C.CDLL:
     L.sonde_parser_feed.restype = C.c_int
     L.sonde_parser_destroy.argtypes = [vp]
     L.sonde_parser_destroy.restype = None
+    L.sonde_rs41_pressure.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_float)]
+    L.sonde_rs41_pressure.restype = C.c_float
+    L.sonde_ozone_mpa.argtypes = [C.c_float, C.c_float]
+    L.sonde_ozone_mpa.restype = C.c_float
+    L.sonde_m10_temp.argtypes = [C.c_uint, C.c_uint]
+    L.sonde_m10_temp.restype = C.c_float
+    L.sonde_m10_rh.argtypes = [C.c_uint32, C.c_uint32, C.c_float]
+    L.sonde_m10_rh.restype = C.c_float
+    L.sonde_m20_temp.argtypes = [C.c_uint]
+    L.sonde_m20_temp.restype = C.c_float
+    L.sonde_ims100_temp.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_float]
+    L.sonde_ims100_temp.restype = C.c_float
     L.sonde_rs41_temp.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.sonde_rs41_temp.restype = C.c_float
     L.sonde_rs41_rh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]

@@ -201,30 +201,33 @@ __global__ __launch_bounds__(64) void sd_dec_m10_kernel(
 	const uint32_t *ring = bitring + (size_t)ch * ring_words;
 	const uint32_t mask = ring_words - 1;
 	const SdFrameDesc d = descs[(size_t)ch * max_frames + k];
-	int viol = 0;
-	for (int i = lane; i < 101; i += 64) {
+	int vb[2] = { 0, 0 };                            // Manchester violations of this lane's bytes (lane, lane + 64)
+	for (int i = lane, q = 0; i < 101; i += 64, q++) {
 		uint32_t v = 0;
 		for (int b = 0; b < 8; b++) {
 			const uint64_t p = d.fstart + 32 + 16 * (uint64_t)i + 2 * (uint64_t)b;
 			const uint32_t a = chip_at(ring, mask, p) ^ (uint32_t)d.inv, c = chip_at(ring, mask, p + 1) ^ (uint32_t)d.inv;
 			v = (v << 1) | a;
-			viol += (a == c);
+			vb[q] += (a == c);
 		}
 		s_fr[i] = (uint8_t)v;
 	}
+	__syncthreads();
+	// the first byte is the length of what follows: 0x64 = M10 (101 bytes in all), 0x45 = M20 (70)
+	const int total = s_fr[0] == 0x45 ? 70 : 101;
+	int viol = (lane < total ? vb[0] : 0) + (lane + 64 < total ? vb[1] : 0);
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) viol += __shfl_xor(viol, off, 64);
-	__syncthreads();
 	SondeFrame *fr = frames + (size_t)ch * max_frames + k;
 	if (lane == 0) {
 		unsigned cs = 0;
-		for (int i = 0; i < 99; i++) cs = m10_check_step(cs, s_fr[i]);
-		fr->channel = ch; fr->type = SONDE_M10; fr->len = 101;
-		fr->nerr[0] = (cs == (((unsigned)s_fr[99] << 8) | s_fr[100])) ? 0 : -1;
+		for (int i = 0; i < total - 2; i++) cs = m10_check_step(cs, s_fr[i]);
+		fr->channel = ch; fr->type = SONDE_M10; fr->len = total;
+		fr->nerr[0] = (cs == (((unsigned)s_fr[total - 2] << 8) | s_fr[total - 1])) ? 0 : -1;
 		fr->nerr[1] = viol;
 		fr->flags = d.inv ? 1u : 0u; fr->bitpos = d.fstart;
 	}
-	for (int i = lane; i < SONDE_FRAME_MAX; i += 64) fr->data[i] = i < 101 ? s_fr[i] : 0;
+	for (int i = lane; i < SONDE_FRAME_MAX; i += 64) fr->data[i] = i < total ? s_fr[i] : 0;
 }
 
 // ---------------------------------------------------------------- iMS-100: biphase-S + BCH(63,51) shortened to (46,34)

@@ -3,6 +3,7 @@
 // as the run() loop there expects ("one decode call yields one fragment").
 // RS41 subframe layout: SURVEY.md Appendix B.2.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 #include "parse.h"
 
@@ -206,7 +207,24 @@ void SondeParser::feed_rs41(const SondeFrame &f, std::vector<SondeData> &out)
 			sd.fields = DATA_PTU;
 			sd.temp = T;
 			sd.rh = sonde_rs41_rh(m[3], m[4], m[5], calh0, T);
-			sd.pressure = 0.0f;      // RS41-SG has no pressure sensor: the caller falls back to the ISA model (decoder.hpp:108-110)
+			// RS41-SGP: pressure sensor counts (measurement triple 4) + its temperature (i16, 0.01 C, body offset 38) and
+			// the coefficient block at 0x25E..0x2A5 (calibration fragments 0x25..0x2A).  An RS41-SG sends zeros there:
+			// pressure = 0 and the caller falls back to the ISA model (decoder.hpp:108-110)
+			sd.pressure = 0.0f;
+			if (m[9] != 0 && m[11] > m[10] && len >= 40 && ((m_calib_mask >> 0x25) & 0x3F) == 0x3F) {
+				float cfP[25] = {};
+				for (int i = 0; i < 18; i++) cfP[k_rs41_cfp_slot[i]] = rd_f32(m_calib + 0x25E + 4 * i);
+				const float P = sonde_rs41_pressure(m[9], m[10], m[11], (float)rd_i16(body + 38) * 0.01f, cfP);
+				if (P > 0.0f && P < 1200.0f) sd.pressure = P;
+			}
+			break;
+		}
+		case 0x7E: { // XDATA: one instrument-chain byte, then the ASCII hex string of the attached instrument(s)
+			float o3;
+			if (len >= 21 && xdata_ozone_ascii(body + 1, len - 1, &o3)) {
+				sd.fields = DATA_OZONE;
+				sd.o3_mpa = o3;
+			}
 			break;
 		}
 		default:
@@ -313,30 +331,110 @@ void SondeParser::feed_dfm(const SondeFrame &f, std::vector<SondeData> &out)
 	}
 }
 
-// M10: 101-byte frame, big-endian fields at fixed offsets (public M10 notes)
+// M10 thermistor (public M10 decoders' model, [RECALL]): a 12-bit ADC reads an NTC behind one of three series/parallel
+// resistor ranges; R -> T by a cubic in ln R.  frame: scale byte 0x3E, ADC word 0x3F (LE, offset 0xA000).
+extern "C" float sonde_m10_temp(unsigned scale, unsigned adc)
+{
+	static const float Rs[3] = { 12.1e3f, 36.5e3f, 475.0e3f }, Rp[3] = { 1.0e20f, 330.0e3f, 2000.0e3f };
+	const float p0 = 1.07303516e-03f, p1 = 2.41296733e-04f, p2 = 2.26744154e-06f, p3 = 6.52855181e-08f;
+	if (scale > 2 || adc == 0 || adc >= 4095) return -273.15f;
+	const float x = (4095.0f - (float)adc) / (float)adc;                  // (Vcc - Vout) / Vout
+	const float R = Rs[scale] / (x - Rs[scale] / Rp[scale]);
+	if (!(R > 0.0f)) return -273.15f;
+	const float l = logf(R);
+	return 1.0f / (p0 + p1 * l + p2 * l * l + p3 * l * l * l) - 273.15f;
+}
+
+// M10 humidity: ratio of two 24-bit timer captures (sensor against reference, frame 0x35 / 0x32, LE) mapped linearly,
+// with a small temperature term ([RECALL], low confidence on the constants)
+extern "C" float sonde_m10_rh(uint32_t cap_sensor, uint32_t cap_ref, float T)
+{
+	if (cap_ref == 0) return -1.0f;
+	const float q = (float)cap_sensor / (float)cap_ref;
+	float rh = (q - 0.8955f) / 0.002f;
+	rh = rh + (20.0f - T) * 0.03f;
+	if (rh < 0.0f) rh = 0.0f;
+	if (rh > 100.0f) rh = 100.0f;
+	return rh;
+}
+
+// M20 thermistor ([RECALL]): 12-bit ADC word at 0x04 (LE), fixed 22.1 k series resistor, Beta model (B = 3450 K, 15 k at 0 C)
+extern "C" float sonde_m20_temp(unsigned adc)
+{
+	if (adc == 0 || adc >= 4095) return -273.15f;
+	const float R = 22.1e3f * (float)adc / (4095.0f - (float)adc);
+	return 1.0f / (1.0f / 273.15f + logf(R / 15.0e3f) / 3450.0f) - 273.15f;
+}
+
+// M10: 101-byte frame (length byte 0x64, type 0x9F), M20: 70-byte frame (0x45, 0x20); big-endian fields at fixed
+// offsets (public M10/M20 notes [RECALL]).  The framer checks the 16-bit checksum at the
+// position the length byte implies.
 void SondeParser::feed_m10(const SondeFrame &f, std::vector<SondeData> &out)
 {
-	if (f.len != 101 || f.nerr[0] != 0) return;      // checksum failed
+	if (f.nerr[0] != 0) return;                      // checksum failed
 	const uint8_t *d = f.data;
-	if (d[1] != 0x9F) return;                        // 0x9F = M10 (M20 differs)
 	auto be16 = [&](int o) { return (int16_t)((d[o] << 8) | d[o + 1]); };
+	auto be24 = [&](int o) { return (int32_t)(((uint32_t)d[o] << 16) | ((uint32_t)d[o + 1] << 8) | d[o + 2]); };
 	auto be32 = [&](int o) { return (int32_t)(((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]); };
 	SondeData sd;
 	memset(&sd, 0, sizeof(sd));
-	const double ve = be16(0x04) / 200.0, vn = be16(0x06) / 200.0, vu = be16(0x08) / 200.0;
-	const uint32_t tow_ms = (uint32_t)be32(0x0A);
-	const unsigned week = (unsigned)(uint16_t)be16(0x20);
-	sd.fields = DATA_POS | DATA_SPEED | DATA_TIME;
-	sd.lat = (float)(be32(0x0E) * (360.0 / 4294967296.0));
-	sd.lon = (float)(be32(0x12) * (360.0 / 4294967296.0));
-	sd.alt = (float)(be32(0x16) / 1000.0);
-	sd.speed = (float)sqrt(ve * ve + vn * vn);
-	double hdg = atan2(ve, vn) * 180.0 / M_PI;
-	if (hdg < 0.0) hdg += 360.0;
-	sd.heading = (float)hdg;
-	sd.climb = (float)vu;
-	sd.time = (time_t)(315964800LL + (long long)week * 604800LL + (long long)(tow_ms / 1000) - 18LL);
-	out.push_back(sd);
+	if (f.len == 101 && d[0] == 0x64 && d[1] == 0x9F) {
+		const double ve = be16(0x04) / 200.0, vn = be16(0x06) / 200.0, vu = be16(0x08) / 200.0;
+		const uint32_t tow_ms = (uint32_t)be32(0x0A);
+		const unsigned week = (unsigned)(uint16_t)be16(0x20);
+		sd.fields = DATA_POS | DATA_SPEED | DATA_TIME;
+		sd.lat = (float)(be32(0x0E) * (360.0 / 4294967296.0));
+		sd.lon = (float)(be32(0x12) * (360.0 / 4294967296.0));
+		sd.alt = (float)(be32(0x16) / 1000.0);
+		sd.speed = (float)sqrt(ve * ve + vn * vn);
+		double hdg = atan2(ve, vn) * 180.0 / M_PI;
+		if (hdg < 0.0) hdg += 360.0;
+		sd.heading = (float)hdg;
+		sd.climb = (float)vu;
+		sd.time = (time_t)(315964800LL + (long long)week * 604800LL + (long long)(tow_ms / 1000) - 18LL);
+		out.push_back(sd);
+		// temperature / humidity (README.md:12 ticks both for M10)
+		const unsigned adc = (unsigned)(((d[0x40] << 8) | d[0x3F]) - 0xA000) & 0xFFFFu;
+		const float T = sonde_m10_temp(d[0x3E], adc);
+		if (T > -270.0f) {
+			SondeData pt;
+			memset(&pt, 0, sizeof(pt));
+			pt.fields = DATA_PTU;
+			pt.temp = T;
+			const uint32_t ref = (uint32_t)d[0x32] | ((uint32_t)d[0x33] << 8) | ((uint32_t)d[0x34] << 16);
+			const uint32_t sen = (uint32_t)d[0x35] | ((uint32_t)d[0x36] << 8) | ((uint32_t)d[0x37] << 16);
+			const float rh = sonde_m10_rh(sen, ref, T);
+			pt.rh = rh < 0.0f ? 0.0f : rh;
+			pt.calib_percent = 100.0f;
+			out.push_back(pt);
+		}
+	} else if (f.len == 70 && d[0] == 0x45 && d[1] == 0x20) {
+		// M20: alt 0x08 (3 bytes, cm), vE 0x0B, vN 0x0D (0.01 m/s), time of week 0x0F (3 bytes, s), vU 0x18, week 0x1A,
+		// lat 0x1C, lon 0x20 (1e-6 deg)
+		const double ve = be16(0x0B) / 100.0, vn = be16(0x0D) / 100.0, vu = be16(0x18) / 100.0;
+		const uint32_t tow_s = (uint32_t)be24(0x0F);
+		const unsigned week = (unsigned)(uint16_t)be16(0x1A);
+		sd.fields = DATA_POS | DATA_SPEED | DATA_TIME;
+		sd.lat = (float)(be32(0x1C) * 1e-6);
+		sd.lon = (float)(be32(0x20) * 1e-6);
+		sd.alt = (float)(be24(0x08) / 100.0);
+		sd.speed = (float)sqrt(ve * ve + vn * vn);
+		double hdg = atan2(ve, vn) * 180.0 / M_PI;
+		if (hdg < 0.0) hdg += 360.0;
+		sd.heading = (float)hdg;
+		sd.climb = (float)vu;
+		sd.time = (time_t)(315964800LL + (long long)week * 604800LL + (long long)tow_s - 18LL);
+		out.push_back(sd);
+		const float T = sonde_m20_temp((unsigned)(d[0x04] | (d[0x05] << 8)) & 0xFFFu);     // README.md:13: M20 GPS + T
+		if (T > -270.0f) {
+			SondeData pt;
+			memset(&pt, 0, sizeof(pt));
+			pt.fields = DATA_PTU;
+			pt.temp = T;
+			pt.calib_percent = 100.0f;
+			out.push_back(pt);
+		}
+	}
 }
 
 // iMet-1 / iMet-4 packets (SPEC 3.3c; field layout: public iMet notes, [RECALL]):
@@ -345,11 +443,11 @@ void SondeParser::feed_m10(const SondeFrame &f, std::vector<SondeData> &out)
 // little-endian fields, CRC big-endian.  Packets with a bad CRC are dropped.
 void SondeParser::feed_imet(const SondeFrame &f, std::vector<SondeData> &out)
 {
-	if (f.nerr[0] != 0 || f.len < 14) return;
+	if (f.nerr[0] != 0 || f.len < 7) return;
 	const uint8_t *d = f.data;
 	SondeData sd;
 	memset(&sd, 0, sizeof(sd));
-	if (d[1] == 1 || d[1] == 4) {
+	if ((d[1] == 1 || d[1] == 4) && f.len >= 14) {
 		sd.fields = DATA_SEQ | DATA_PTU;
 		sd.seq = (int)rd_u16(d + 2);
 		sd.pressure = (float)rd_u24(d + 4) / 100.0f;
@@ -362,8 +460,95 @@ void SondeParser::feed_imet(const SondeFrame &f, std::vector<SondeData> &out)
 		sd.lon = rd_f32(d + 6);
 		sd.alt = (float)rd_u16(d + 10) - 5000.0f;
 		sd.time = (time_t)(3600 * (int)d[13] + 60 * (int)d[14] + (int)d[15]);      // time of day only: no date on air
+	} else if (d[1] == 3 && f.len >= 5 + 8 && d[3] == 0x01) {
+		// XDATA, binary: 01 03 len | instrument id (01 = ECC ozonesonde) index | cell current u16 BE (0.001 uA),
+		// pump temperature i16 BE (0.01 C), pump current u8 (mA), battery u8 (0.1 V)  [RECALL: public iMet XDATA notes]
+		const float cur = (float)((d[5] << 8) | d[6]) * 1.0e-3f;
+		const float tp = (float)(int16_t)((d[7] << 8) | d[8]) * 0.01f;
+		sd.fields = DATA_OZONE;
+		sd.o3_mpa = sonde_ozone_mpa(cur, tp);
 	}
 	if (sd.fields) out.push_back(sd);
+}
+
+// iMS-100 / RS-11G (Meisei).  The FEC stage delivers the 408 data bits of a frame = 12 BCH blocks x 2 groups of 17 bits:
+// a 16-bit word, MSB first, followed by its parity bit (odd overall parity: the 17 bits hold an odd number of ones).
+// Words with a wrong parity bit, or from a block the BCH decoder gave up on, are unusable: a field is emitted only if
+// all of its words are good.  Word layout ([RECALL]: the word/parity/BCH structure is the public description of the
+// format; the offsets below are this repo's -- the reference's layout is in the absent sondedump):
+//   w0 frame counter | w1:w2 calibration word #(counter mod 4): 0 serial number (u32), 1..3 float32 c0, c1, c2 of the
+//   thermistor polynomial | w3 temperature count f (T = c0 + c1 f + c2 f^2) | w4 humidity, 0.01 % |
+//   w5:w6 GPS time of week, ms | w7 GPS week | w8:w9 latitude, w10:w11 longitude (i32, 1e-6 deg) | w12:w13 altitude
+//   (i32, cm) | w14 ground speed, w15 heading (u16, 0.01) | w16 climb (i16, 0.01 m/s) | w17..w23 spare
+extern "C" float sonde_ims100_temp(uint32_t f, float c0, float c1, float c2)
+{
+	const float x = (float)f;
+	return c0 + c1 * x + c2 * x * x;
+}
+
+void SondeParser::feed_ims100(const SondeFrame &f, std::vector<SondeData> &out)
+{
+	if (f.len != 51) return;
+	uint16_t w[24];
+	uint32_t good = 0;
+	for (int g = 0; g < 24; g++) {
+		uint32_t v = 0;
+		for (int b = 0; b < 17; b++) {
+			const int bit = 17 * g + b;
+			v = (v << 1) | ((f.data[bit >> 3] >> (7 - (bit & 7))) & 1u);
+		}
+		w[g] = (uint16_t)(v >> 1);
+		if (__builtin_popcount(v) & 1) good |= 1u << g;
+	}
+	if (f.nerr[1] != 0) good = 0;          // an uncorrectable BCH block: which one is not recorded, drop the frame
+	auto ok = [&](int a, int b) { const uint32_t m = ((1u << (b - a + 1)) - 1u) << a; return (good & m) == m; };
+	auto u32 = [&](int a) { return ((uint32_t)w[a] << 16) | w[a + 1]; };
+	SondeData sd;
+	if (ok(0, 0)) {
+		memset(&sd, 0, sizeof(sd));
+		sd.fields = DATA_SEQ;
+		sd.seq = w[0];
+		if (ok(1, 2)) {
+			m_ims_cal[w[0] & 3] = u32(1);
+			m_ims_cal_mask |= 1u << (w[0] & 3);
+			if ((w[0] & 3) == 0) {
+				sd.fields |= DATA_SERIAL;
+				snprintf(sd.serial, sizeof(sd.serial), "%u", (unsigned)u32(1));
+			}
+		}
+		out.push_back(sd);
+	}
+	if (ok(5, 7)) {
+		memset(&sd, 0, sizeof(sd));
+		sd.fields = DATA_TIME;
+		sd.time = (time_t)(315964800LL + (long long)w[7] * 604800LL + (long long)(u32(5) / 1000u) - 18LL);
+		out.push_back(sd);
+	}
+	if (ok(8, 16)) {
+		memset(&sd, 0, sizeof(sd));
+		sd.fields = DATA_POS | DATA_SPEED;
+		sd.lat = (float)((int32_t)u32(8) * 1e-6);
+		sd.lon = (float)((int32_t)u32(10) * 1e-6);
+		sd.alt = (float)((int32_t)u32(12) * 1e-2);
+		sd.speed = (float)(w[14] * 1e-2);
+		sd.heading = (float)(w[15] * 1e-2);
+		sd.climb = (float)((int16_t)w[16] * 1e-2);
+		out.push_back(sd);
+	}
+	if (ok(3, 4)) {
+		int have = 0;
+		for (int i = 0; i < 4; i++) have += (m_ims_cal_mask >> i) & 1;
+		if ((m_ims_cal_mask & 0xEu) == 0xEu) {
+			float c[3];
+			for (int i = 0; i < 3; i++) memcpy(&c[i], &m_ims_cal[1 + i], 4);
+			memset(&sd, 0, sizeof(sd));
+			sd.fields = DATA_PTU;
+			sd.temp = sonde_ims100_temp(w[3], c[0], c[1], c[2]);
+			sd.rh = (float)w[4] * 0.01f;
+			sd.calib_percent = 100.0f * (float)have / 4.0f;
+			if (sd.temp > -273.0f && sd.temp < 200.0f) out.push_back(sd);
+		}
+	}
 }
 
 void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
@@ -373,7 +558,8 @@ void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
 	case SONDE_DFM09: feed_dfm(f, out); break;
 	case SONDE_M10: feed_m10(f, out); break;
 	case SONDE_IMET4: feed_imet(f, out); break;
-	default: break;   // iMS-100: frames are delivered, field layout not implemented
+	case SONDE_IMS100: feed_ims100(f, out); break;
+	default: break;
 	}
 }
 

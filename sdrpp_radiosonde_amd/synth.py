@@ -111,6 +111,38 @@ RS41_CALH0 = 45.0
 RS41_F1, RS41_F2 = 133000, 190000           # reference counts (temperature and humidity channels alike)
 
 
+# RS41-SGP pressure sensor model: P(hPa) = sum_j sum_k cfP[4j+k] * a0^j * T^k with a0 = cfP[24] / fp, fp the normalised
+# count.  Only the j = 0, 1 / k = 0, 1 terms are used here: P = 1100 - 1000 a0 + 0.02 T.
+RS41_CFP = np.zeros(25)
+RS41_CFP[0], RS41_CFP[4], RS41_CFP[1], RS41_CFP[24] = 1100.0, -1000.0, 0.02, 0.5
+RS41_CFP_SLOT = (0, 4, 8, 12, 16, 20, 24, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11)      # calibration word i -> matrix entry
+RS41_TPRESS = 21.5                                                                # pressure sensor temperature, deg C
+
+
+def rs41_true_pressure(frame_idx):
+    """hPa the SGP variant of the generator encodes for frame k (0 for the sensor-less RS41-SG)."""
+    alt = 1000.0 + 5.0 * np.asarray(frame_idx, dtype=np.float64)
+    return 1013.25 * np.exp(-alt / 8000.0)
+
+
+def rs41_pressure_counts(P):
+    a0 = (1100.0 + 0.02 * RS41_TPRESS - np.asarray(P)) / 1000.0
+    fp = RS41_CFP[24] / a0
+    return np.rint(RS41_F1 + fp * (RS41_F2 - RS41_F1)).astype(np.int64)
+
+
+def xdata_ozone_string(cell_ua: float, tpump_c: float) -> bytes:
+    """ASCII hex XDATA of an OIF411 ozone interface: type 05, number 01, pump temperature, cell current, battery,
+    pump current, external voltage."""
+    return b"0501%04X%05X%02X%03X%02X" % (int(round(tpump_c * 100)) & 0xFFFF, int(round(cell_ua * 1e4)), 125, 95, 0)
+
+
+def ozone_true(frame_idx):
+    """(cell current uA, pump temperature C) the generator's ozonesonde reports in frame k."""
+    k = np.asarray(frame_idx, dtype=np.float64)
+    return 1.5 + 0.01 * k, 25.0 - 0.02 * k
+
+
 def rs41_calibration_memory(channel: int) -> np.ndarray:
     """The 816-byte calibration table of a sonde (51 fragments of 16 bytes); only the words the PTU
     conversion reads are meaningful, the rest is a channel-dependent pattern."""
@@ -121,6 +153,7 @@ def rs41_calibration_memory(channel: int) -> np.ndarray:
     putf(0x4D, RS41_CO1); putf(0x59, RS41_CALT1)
     putf(0x75, [RS41_CALH0, 0.0])
     putf(0x125, RS41_CO1); putf(0x131, RS41_CALT1)
+    putf(0x25E, [RS41_CFP[k] for k in RS41_CFP_SLOT])                       # pressure polynomial (RS41-SGP)
     kill = 0xFFFF if channel % 2 == 0 else 3600 + channel          # burst-kill countdown (s); 0xFFFF = not armed
     mem[0x316], mem[0x317] = kill & 0xFF, kill >> 8
     return mem
@@ -147,7 +180,7 @@ def rs41_ptu_counts(T, RH):
     return fT, fH
 
 
-def rs41_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray, extended: bool = False) -> np.ndarray:
+def rs41_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray, extended: bool = False, sgp: bool = False) -> np.ndarray:
     """Return unscrambled RS41 frames [F, len] (uint8) for the (channel, frame number) pairs.
 
     Telemetry values are deterministic functions of (seed, channel, frame) so any
@@ -189,10 +222,14 @@ def rs41_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray,
         elif stype == 0x7A:  # measurements: 12 x 24-bit counts
             T, RH = rs41_true_ptu(channel_ids, frame_idx)
             fT, fH = rs41_ptu_counts(T, RH)
+            if sgp:     # RS41-SGP: pressure sensor counts + the sensor's temperature (i16, 0.01 C) at body offset 38
+                pm = (rs41_pressure_counts(rs41_true_pressure(frame_idx)), np.full(F, RS41_F1), np.full(F, RS41_F2))
+                _put_le(body, 38, np.full(F, int(round(RS41_TPRESS * 100))), 2)
+            else:
+                pm = (np.zeros(F), np.zeros(F), np.zeros(F))
             for k, v in enumerate((fT, np.full(F, RS41_F1), np.full(F, RS41_F2),
                                    fH, np.full(F, RS41_F1), np.full(F, RS41_F2),
-                                   fT, np.full(F, RS41_F1), np.full(F, RS41_F2),
-                                   np.zeros(F), np.zeros(F), np.zeros(F))):
+                                   fT, np.full(F, RS41_F1), np.full(F, RS41_F2)) + pm):
                 _put_le(body, 3 * k, v, 3)
         elif stype == 0x7C:  # GPS info: week, ms of week
             _put_le(body, 0, np.full(F, 2200), 2)
@@ -215,6 +252,13 @@ def rs41_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray,
             for k in range(3):
                 _put_le(body, 12 + 2 * k, np.round(v[:, k] * 100).astype(np.int64) & 0xFFFF, 2)
             body[:, 18] = 9  # sats
+        elif stype == 0x7E:  # XDATA: instrument-chain byte, ASCII hex string of an ozone interface, zero padding
+            body[:] = 0
+            body[:, 0] = 1
+            cur, tp = ozone_true(frame_idx)
+            for i in range(F):
+                xs = np.frombuffer(xdata_ozone_string(float(cur[i]), float(tp[i])), dtype=np.uint8)
+                body[i, 1: 1 + len(xs)] = xs
         elif stype == 0x76:
             body[:] = 0
         crc = crc16_ccitt(body)
@@ -250,7 +294,7 @@ class SynthBatch:
     amp: np.ndarray
 
 
-def rs41_bitstreams(seed: int, channels: np.ndarray, nbits: int, extended: bool = False, preamble_bytes: int = 40):
+def rs41_bitstreams(seed: int, channels: np.ndarray, nbits: int, extended: bool = False, preamble_bytes: int = 40, sgp: bool = False):
     """Continuous on-air bit streams: random lead-in of alternating bits, then
     [40-byte alternating preamble | whitened frame] back to back."""
     channels = np.asarray(channels, dtype=np.int64)
@@ -262,7 +306,7 @@ def rs41_bitstreams(seed: int, channels: np.ndarray, nbits: int, extended: bool 
     lead = rng.integers(64, stride, size=C)
     ch_rep = np.repeat(channels, nfr)
     fi_rep = np.tile(np.arange(nfr), C)
-    frames = rs41_build_frames(seed, ch_rep, fi_rep, extended).reshape(C, nfr, flen)
+    frames = rs41_build_frames(seed, ch_rep, fi_rep, extended, sgp).reshape(C, nfr, flen)
     air = rs41_scramble(frames.reshape(C * nfr, flen))
     fbits = bytes_to_bits_lsb(air).reshape(C, nfr, 8 * flen)
     alt = (np.arange(stride + 8 * preamble_bytes) & 1).astype(np.uint8)
@@ -330,11 +374,11 @@ def gfsk_modulate(bits: np.ndarray, n_samples: int, baud: float, *, seed: int = 
 
 def make_rs41_batch(n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
                     device: str | torch.device = "cpu", first_channel: int = 0, extended: bool = False,
-                    invert: bool = False, **mod_kw) -> SynthBatch:
+                    invert: bool = False, sgp: bool = False, **mod_kw) -> SynthBatch:
     baud = 4800.0
     nbits = int(n_samples * baud / FS) + 16
     channels = np.arange(first_channel, first_channel + n_channels)
-    bits, frames = rs41_bitstreams(seed, channels, nbits, extended)
+    bits, frames = rs41_bitstreams(seed, channels, nbits, extended, sgp=sgp)
     iq, cfo, tau, amp = gfsk_modulate(bits, n_samples, baud, seed=seed + first_channel, ebn0_db=ebn0_db,
                                       device=device, invert=invert, **mod_kw)
     return SynthBatch(iq=iq, frames=frames, bits=bits, cfo_hz=cfo, tau=tau, amp=amp)
@@ -415,8 +459,8 @@ def dfm_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray):
     for blk in range(2):
         pid = ids[:, blk]
         payload = np.zeros(F, dtype=np.int64)           # 48 bits
-        payload = np.where(pid == 0, (fi & 0xFFFF) << 24, payload)
-        payload = np.where(pid == 1, ((fi * 1000 + 123000) % 60000 & 0xFFFF) << 16, payload)   # UTC ms of minute
+        payload = np.where(pid == 0, (fi & 0xFF) << 16, payload)                                # frame counter: 8 bits at bit 24
+        payload = np.where(pid == 1, (fi * 1000 + 123000) % 60000 & 0xFFFF, payload)            # UTC ms of minute: last 16 bits
         payload = np.where(pid == 2, ((lat & 0xFFFFFFFF) << 16) | 1200, payload)               # lat 1e-7, hor. speed cm/s
         payload = np.where(pid == 3, ((lon & 0xFFFFFFFF) << 16) | 9000, payload)               # lon 1e-7, heading 0.01 deg
         payload = np.where(pid == 4, ((alt & 0xFFFFFFFF) << 16) | 500, payload)                # alt cm, climb cm/s
@@ -441,10 +485,10 @@ M10_SYNC_CHIPS = np.array([int(c) for c in "10011001100110010100110010011001"], 
 M10_FRAME_BYTES = 101
 
 
-def m10_checksum(frames: np.ndarray) -> np.ndarray:
-    """Meteomodem 16-bit checksum over frames[:, :99] (vectorised over frames)."""
+def m10_checksum(frames: np.ndarray, n: int = 99) -> np.ndarray:
+    """Meteomodem 16-bit checksum over frames[:, :n] (vectorised over frames)."""
     cs = np.zeros(frames.shape[0], dtype=np.int64)
-    for i in range(99):
+    for i in range(n):
         b = frames[:, i].astype(np.int64)
         c1 = cs & 0xFF
         b = ((b >> 1) | ((b & 1) << 7)) & 0xFF
@@ -464,6 +508,75 @@ def _put_be(buf, off, val, nbytes):
         buf[:, off + b] = (v >> (8 * (nbytes - 1 - b))) & 0xFF
 
 
+def m10_true_ptu(channel_ids, frame_idx):
+    T = 14.0 - 0.02 * np.asarray(frame_idx, dtype=np.float64) - 0.01 * (np.asarray(channel_ids) % 40)
+    RH = 35.0 + 0.1 * (np.asarray(frame_idx) % 100)
+    return T, RH
+
+
+def m10_temp_adc(T, scale: int = 1):
+    """ADC reading the M10 thermistor model maps back to T (range `scale`): inverse of sonde_m10_temp."""
+    p0, p1, p2, p3 = 1.07303516e-03, 2.41296733e-04, 2.26744154e-06, 6.52855181e-08
+    Rs, Rp = (12.1e3, 36.5e3, 475.0e3)[scale], (1.0e20, 330.0e3, 2000.0e3)[scale]
+    T = np.atleast_1d(np.asarray(T, dtype=np.float64))
+    lnr = np.zeros_like(T)
+    for i, t in enumerate(T):                     # solve the cubic in ln R by bisection (monotone)
+        lo, hi = 2.0, 20.0
+        for _ in range(80):
+            mid = 0.5 * (lo + hi)
+            if 1.0 / (p0 + p1 * mid + p2 * mid ** 2 + p3 * mid ** 3) - 273.15 > t:
+                lo = mid
+            else:
+                hi = mid
+        lnr[i] = 0.5 * (lo + hi)
+    R = np.exp(lnr)
+    x = Rs / R + Rs / Rp
+    return np.rint(4095.0 / (1.0 + x)).astype(np.int64)
+
+
+def m10_rh_counts(RH, T, ref: int = 100000):
+    q = (np.asarray(RH) - (20.0 - np.asarray(T)) * 0.03) * 0.002 + 0.8955
+    return np.rint(q * ref).astype(np.int64), ref
+
+
+def m20_true_temp(channel_ids, frame_idx):
+    return 9.0 - 0.02 * np.asarray(frame_idx, dtype=np.float64) - 0.01 * (np.asarray(channel_ids) % 40)
+
+
+def m20_temp_adc(T):
+    R = 15.0e3 * np.exp(3450.0 * (1.0 / (np.asarray(T, dtype=np.float64) + 273.15) - 1.0 / 273.15))
+    return np.rint(4095.0 * R / (R + 22.1e3)).astype(np.int64)
+
+
+M20_FRAME_BYTES = 70
+
+
+def m20_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray) -> np.ndarray:
+    """M20: 70-byte frame (length byte 0x45, type 0x20), the same rolling checksum over all but the last two bytes.
+    Returned padded to the 101-byte window of the M10 framer (the pad is what the transmitter idles behind the frame)."""
+    ch = np.asarray(channel_ids, dtype=np.int64)
+    fi = np.asarray(frame_idx, dtype=np.int64)
+    F = ch.shape[0]
+    fr = np.zeros((F, M10_FRAME_BYTES), dtype=np.uint8)
+    g = np.random.Generator(np.random.Philox(key=(seed * 37 + 11) & 0xFFFFFFFFFFFFFFFF))
+    fr[:, :M20_FRAME_BYTES] = g.integers(0, 256, size=(F, M20_FRAME_BYTES), dtype=np.uint8)
+    fr[:, M20_FRAME_BYTES:] = 0xAA                                                       # idle pattern behind the frame
+    fr[:, 0], fr[:, 1] = 0x45, 0x20
+    adc = m20_temp_adc(m20_true_temp(ch, fi))
+    fr[:, 0x04], fr[:, 0x05] = adc & 0xFF, (adc >> 8) & 0x0F
+    _put_be(fr, 0x08, np.round((1000.0 + 5.0 * fi) * 100).astype(np.int64) & 0xFFFFFF, 3)   # altitude, cm
+    _put_be(fr, 0x0B, np.full(F, 1200), 2)                                               # vE, 0.01 m/s
+    _put_be(fr, 0x0D, np.zeros(F, dtype=np.int64), 2)                                    # vN
+    _put_be(fr, 0x0F, (fi + 123456) % 604800, 3)                                         # GPS time of week, s
+    _put_be(fr, 0x18, np.full(F, 500), 2)                                                # vU
+    _put_be(fr, 0x1A, np.full(F, 2200), 2)                                               # GPS week
+    _put_be(fr, 0x1C, np.round((47.0 + 1e-3 * ch) * 1e6).astype(np.int64) & 0xFFFFFFFF, 4)
+    _put_be(fr, 0x20, np.round((8.0 + 1e-5 * fi) * 1e6).astype(np.int64) & 0xFFFFFFFF, 4)
+    cs = m10_checksum(fr, M20_FRAME_BYTES - 2)
+    fr[:, M20_FRAME_BYTES - 2], fr[:, M20_FRAME_BYTES - 1] = (cs >> 8) & 0xFF, cs & 0xFF
+    return fr
+
+
 def m10_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray) -> np.ndarray:
     ch = np.asarray(channel_ids, dtype=np.int64)
     fi = np.asarray(frame_idx, dtype=np.int64)
@@ -480,6 +593,14 @@ def m10_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray) 
     _put_be(fr, 0x12, np.round((8.0 + 1e-5 * fi) * (2 ** 32 / 360.0)).astype(np.int64) & 0xFFFFFFFF, 4)
     _put_be(fr, 0x16, np.round((1000.0 + 5.0 * fi) * 1000).astype(np.int64) & 0xFFFFFFFF, 4)   # mm
     _put_be(fr, 0x20, np.full(F, 2200), 2)                                              # GPS week
+    T, RH = m10_true_ptu(ch, fi)                                                         # thermistor + humidity captures
+    adc = m10_temp_adc(T, 1) + 0xA000
+    fr[:, 0x3E] = 1
+    fr[:, 0x3F], fr[:, 0x40] = adc & 0xFF, (adc >> 8) & 0xFF
+    sen, ref = m10_rh_counts(RH, T)
+    for b in range(3):
+        fr[:, 0x32 + b] = (ref >> (8 * b)) & 0xFF
+        fr[:, 0x35 + b] = (sen >> (8 * b)) & 0xFF
     cs = m10_checksum(fr)
     fr[:, 99], fr[:, 100] = (cs >> 8) & 0xFF, cs & 0xFF
     return fr
@@ -499,19 +620,55 @@ def bch_parity(data34: int) -> int:
     return r & 0xFFF
 
 
-def ims_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray):
-    """Returns (data bytes [F,51], air bits [F, 576])."""
+IMS_CAL = (-70.0, 3.0e-3, 1.0e-8)          # thermistor polynomial c0 + c1 f + c2 f^2 of the generator's sonde
+
+
+def ims_true_ptu(channel_ids, frame_idx):
+    """(temperature C as the parser reconstructs it from the integer count, humidity %) of frame k."""
+    f = ims_temp_count(channel_ids, frame_idx).astype(np.float64)
+    return IMS_CAL[0] + IMS_CAL[1] * f + IMS_CAL[2] * f * f, 45.0 + 0.05 * (np.asarray(frame_idx) % 200)
+
+
+def ims_temp_count(channel_ids, frame_idx):
+    return (27000 - 40 * np.asarray(frame_idx, dtype=np.int64) - 10 * (np.asarray(channel_ids) % 50)).astype(np.int64)
+
+
+def ims_words(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray) -> np.ndarray:
+    """The 24 sixteen-bit words of an iMS-100 frame (layout: parse.cpp feed_ims100)."""
     ch = np.asarray(channel_ids, dtype=np.int64)
     fi = np.asarray(frame_idx, dtype=np.int64)
     F = ch.shape[0]
-    data = np.zeros((F, IMS_DATA_BYTES), dtype=np.uint8)
     g = np.random.Generator(np.random.Philox(key=(seed * 131 + 3) & 0xFFFFFFFFFFFFFFFF))
-    data[:] = g.integers(0, 256, size=data.shape, dtype=np.uint8)
-    _put_be(data, 0, fi & 0xFFFF, 2)                                                    # frame counter
-    _put_be(data, 2, np.round((47.0 + 1e-3 * ch) * 1e6).astype(np.int64) & 0xFFFFFFFF, 4)
-    _put_be(data, 6, np.round((8.0 + 1e-5 * fi) * 1e6).astype(np.int64) & 0xFFFFFFFF, 4)
-    _put_be(data, 10, np.round((1000.0 + 5.0 * fi) * 100).astype(np.int64) & 0xFFFFFFFF, 4)
-    dbits = np.unpackbits(data, axis=1)                                                 # [F, 408] MSB first
+    w = g.integers(0, 65536, size=(F, 24)).astype(np.int64)
+
+    def put32(col, v):
+        v = np.asarray(v).astype(np.int64) & 0xFFFFFFFF
+        w[:, col], w[:, col + 1] = v >> 16, v & 0xFFFF
+    w[:, 0] = fi & 0xFFFF
+    cal = np.frombuffer(np.asarray(IMS_CAL, dtype=">f4").tobytes(), dtype=">u4").astype(np.int64)
+    calw = np.where(fi % 4 == 0, 5000000 + ch, cal[np.clip(fi % 4 - 1, 0, 2)])
+    put32(1, calw)
+    _, RH = ims_true_ptu(ch, fi)
+    w[:, 3] = ims_temp_count(ch, fi)
+    w[:, 4] = np.round(RH * 100).astype(np.int64)
+    put32(5, (fi * 500 + 123456000) % 604800000)
+    w[:, 7] = 2200
+    put32(8, np.round((47.0 + 1e-3 * ch) * 1e6))
+    put32(10, np.round((8.0 + 1e-5 * fi) * 1e6))
+    put32(12, np.round((1000.0 + 2.5 * fi) * 100))
+    w[:, 14], w[:, 15], w[:, 16] = 1200, 9000, 500
+    return w
+
+
+def ims_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray):
+    """Returns (data bytes [F,51] as the FEC stage delivers them, air bits [F, 576]).  408 data bits = 24 groups of
+    a 16-bit word (MSB first) + one parity bit that makes the number of ones in the 17 bits odd."""
+    w = ims_words(seed, channel_ids, frame_idx)
+    F = w.shape[0]
+    wb = ((w[:, :, None] >> np.arange(15, -1, -1)[None, None, :]) & 1).astype(np.uint8)      # [F, 24, 16]
+    par = (1 - wb.sum(axis=2) % 2).astype(np.uint8)                                           # odd overall parity
+    dbits = np.concatenate([wb, par[:, :, None]], axis=2).reshape(F, 408)
+    data = np.packbits(dbits, axis=1)
     bits = np.zeros((F, 24 + IMS_NBLK * IMS_BLK_BITS), dtype=np.uint8)
     bits[:, :24] = _bits_msb(np.full(F, IMS_SYNC24), 24)
     for f in range(F):
@@ -542,7 +699,7 @@ def biphase_s(bits: np.ndarray) -> np.ndarray:
 SONDE_BAUD = {0: 4800.0, 1: 5000.0, 2: 4800.0, 3: 9600.0}     # on-air symbol (chip) rates
 
 
-def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int):
+def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int, m20: bool = False):
     """Continuous on-air chip streams [C, nchips] plus, per channel, the list of
     (chip offset of the sync, expected decoded frame bytes)."""
     channels = np.asarray(channels, dtype=np.int64)
@@ -568,7 +725,7 @@ def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int):
         expect, bits = dfm_build_frames(seed, ch_rep, fi_rep)
         chips = manchester(bits)
     elif sonde_type == 3:
-        expect = m10_build_frames(seed, ch_rep, fi_rep)
+        expect = (m20_build_frames if m20 else m10_build_frames)(seed, ch_rep, fi_rep)
         chips = np.concatenate([np.tile(M10_SYNC_CHIPS, (C * nfr, 1)), manchester(np.unpackbits(expect, axis=1))], axis=1)
     else:
         expect, bits = ims_build_frames(seed, ch_rep, fi_rep)
@@ -596,8 +753,9 @@ def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int):
 
 
 def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
-               device: str | torch.device = "cpu", first_channel: int = 0, invert: bool = False, **mod_kw) -> SynthBatch:
-    """Synthetic batch of any supported sonde type (0 RS41, 1 DFM09, 2 iMS-100, 3 M10, 4 iMet-4)."""
+               device: str | torch.device = "cpu", first_channel: int = 0, invert: bool = False, m20: bool = False,
+               **mod_kw) -> SynthBatch:
+    """Synthetic batch of any supported sonde type (0 RS41, 1 DFM09, 2 iMS-100, 3 M10 (m20=True: M20 frames), 4 iMet-4)."""
     if sonde_type == 4:
         return make_imet_batch(n_channels, n_samples, seed=seed, snr_db=ebn0_db, device=device, first_channel=first_channel)
     if sonde_type == 0:
@@ -606,7 +764,7 @@ def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 
     baud = SONDE_BAUD[sonde_type]
     nchips = int(n_samples * baud / FS) + 16
     channels = np.arange(first_channel, first_channel + n_channels)
-    chips, frames = chip_streams(sonde_type, seed, channels, nchips)
+    chips, frames = chip_streams(sonde_type, seed, channels, nchips, m20=m20)
     iq, cfo, tau, amp = gfsk_modulate(chips, n_samples, baud, seed=seed + first_channel + 1000 * sonde_type,
                                       ebn0_db=ebn0_db, device=device, invert=invert, **mod_kw)
     return SynthBatch(iq=iq, frames=frames, bits=chips, cfo_hz=cfo, tau=tau, amp=amp)
@@ -634,8 +792,8 @@ def imet_true_values(channel: int, k: int):
             8.0 + 1e-4 * k, alt, 12, (k // 60) % 60, k % 60)
 
 
-def imet_build_packets(channel: int, k: int):
-    """[PTU packet, GPS packet] of second k (uint8 arrays, CRC included)."""
+def imet_build_packets(channel: int, k: int, xdata: bool = False):
+    """[PTU packet, GPS packet (, XDATA packet of an ECC ozonesonde)] of second k (uint8 arrays, CRC included)."""
     P, T, U, lat, lon, alt, hh, mm, ss = imet_true_values(channel, k)
     ptu = bytearray([0x01, 0x01])
     ptu += int(k & 0xFFFF).to_bytes(2, "little")
@@ -647,8 +805,16 @@ def imet_build_packets(channel: int, k: int):
     gps += np.asarray([lat, lon], dtype="<f4").tobytes()
     gps += int(round(alt) + 5000).to_bytes(2, "little")
     gps += bytes([9, hh, mm, ss])
+    pkts = [ptu, gps]
+    if xdata:   # 01 03 len | 01 (ECC ozonesonde) index | cell current u16 BE (0.001 uA) | pump temperature i16 BE (0.01 C) | mA | 0.1 V
+        cur, tp = ozone_true(k)
+        xd = bytearray([0x01, 0x03, 8, 0x01, 0x00])
+        xd += int(round(float(cur) * 1000)).to_bytes(2, "big")
+        xd += int(round(float(tp) * 100)).to_bytes(2, "big", signed=True)
+        xd += bytes([95, 125])
+        pkts.append(xd)
     out = []
-    for pkt in (ptu, gps):
+    for pkt in pkts:
         a = np.frombuffer(bytes(pkt), dtype=np.uint8)
         c = imet_crc(a)
         out.append(np.concatenate([a, np.array([c >> 8, c & 0xFF], dtype=np.uint8)]))
@@ -664,7 +830,7 @@ def uart_bits(pkt: np.ndarray) -> np.ndarray:
     return b.reshape(-1)
 
 
-def imet_bitstreams(seed: int, channels: np.ndarray, nbits: int):
+def imet_bitstreams(seed: int, channels: np.ndarray, nbits: int, xdata: bool = False):
     """Per channel: idle marks, then PTU and GPS packets separated by short idle gaps.
     Returns (bits [C, nbits], per channel list of (bit offset of the first start bit, packet bytes))."""
     channels = np.asarray(channels, dtype=np.int64)
@@ -675,7 +841,7 @@ def imet_bitstreams(seed: int, channels: np.ndarray, nbits: int):
         pos = int(rng.integers(40, 200))
         lst, k = [], 0
         while pos < nbits:
-            for pkt in imet_build_packets(int(c), k):
+            for pkt in imet_build_packets(int(c), k, xdata):
                 ub = uart_bits(pkt)
                 bits[ci, pos: pos + len(ub)] = ub
                 if pos + len(ub) <= nbits:
@@ -715,10 +881,10 @@ def afsk_modulate(bits: np.ndarray, n_samples: int, *, seed: int = 0, snr_db: fl
 
 
 def make_imet_batch(n_channels: int, n_samples: int, *, seed: int = 1, snr_db: float = 30.0,
-                    device: str | torch.device = "cpu", first_channel: int = 0, **mod_kw) -> SynthBatch:
+                    device: str | torch.device = "cpu", first_channel: int = 0, xdata: bool = False, **mod_kw) -> SynthBatch:
     nbits = int(n_samples * IMET_BAUD / FS) + 16
     channels = np.arange(first_channel, first_channel + n_channels)
-    bits, frames = imet_bitstreams(seed, channels, nbits)
+    bits, frames = imet_bitstreams(seed, channels, nbits, xdata)
     iq, cfo, tau, amp = afsk_modulate(bits, n_samples, seed=seed + first_channel, snr_db=snr_db, device=device, **mod_kw)
     return SynthBatch(iq=iq, frames=frames, bits=bits, cfo_hz=cfo, tau=tau, amp=amp)
 

@@ -87,6 +87,18 @@ def lib():
     L.or_rs41_rh.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
     L.or_dfm_temp.restype = C.c_float
     L.or_dfm_temp.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.or_rs41_pressure_d.restype = C.c_double
+    L.or_rs41_pressure_d.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, f32p]
+    L.or_ozone_mpa_d.restype = C.c_double
+    L.or_ozone_mpa_d.argtypes = [C.c_double, C.c_double]
+    L.or_m10_temp_d.restype = C.c_double
+    L.or_m10_temp_d.argtypes = [C.c_uint, C.c_uint]
+    L.or_m10_rh_d.restype = C.c_double
+    L.or_m10_rh_d.argtypes = [C.c_uint32, C.c_uint32, C.c_double]
+    L.or_m20_temp_d.restype = C.c_double
+    L.or_m20_temp_d.argtypes = [C.c_uint]
+    L.or_ims100_temp_d.restype = C.c_double
+    L.or_ims100_temp_d.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_double]
     L.or_modem_set_decim.argtypes = [C.c_int, C.c_int]
     L.or_afsk_table.argtypes = [f32p]
     L.or_imet_crc.restype = C.c_uint16

@@ -124,3 +124,56 @@ def test_batch_decoder_cpp(tmp_path, oracle):
         assert float.fromhex(re.search(r"pressure=(\S+)", l).group(1)) > 0
         dew = float.fromhex(re.search(r"dewpt=(\S+)", l).group(1))
         assert abs(dew - float(L.or_dewpt(np.float32(temp), np.float32(rh)))) < 0.05 and alt > 900
+
+
+def test_ims100_b1_fields(oracle):
+    """ims100_decode (main.hpp:38, row a6): GPS, time, T/RH fragments of an iMS-100 / RS-11G stream (README.md:14-15)."""
+    n = 2048 * 60
+    sb = synth.make_batch(2, 1, n, seed=33, ebn0_db=26.0)
+    frags = _run_b1("ims100", _discriminate(oracle, sb.iq.numpy()[0]), 4096)
+    pos = [f for f in frags if f["fields"] & _lib.DATA_POS]
+    assert len(pos) >= 3
+    for p in pos:
+        assert abs(p["lat"] - 47.0) < 1e-3 and abs(p["lon"] - 8.0) < 1e-2 and 990.0 < p["alt"] < 1100.0
+        assert abs(p["climb"] - 5.0) < 0.01 and abs(p["speed"] - 12.0) < 0.01 and abs(p["heading"] - 90.0) < 0.01
+    seqs = [f["seq"] for f in frags if f["fields"] & _lib.DATA_SEQ]
+    assert seqs == list(range(seqs[0], seqs[0] + len(seqs)))
+    assert any(f["fields"] & _lib.DATA_SERIAL and f["serial"] == b"5000000" for f in frags)
+    ptu = [f for f in frags if f["fields"] & _lib.DATA_PTU]
+    assert len(ptu) >= 2 and all(-60.0 < f["temp"] < 30.0 and 40.0 < f["rh"] < 60.0 for f in ptu)
+    times = [f["time"] for f in frags if f["fields"] & _lib.DATA_TIME]
+    assert len(times) >= 3 and all(t > 1_400_000_000 for t in times)
+
+
+def test_m20_and_m10_ptu_b1(oracle):
+    n = 2048 * 60
+    for m20 in (False, True):
+        sb = synth.make_batch(3, 1, n, seed=35, ebn0_db=26.0, m20=m20)
+        frags = _run_b1("m10", _discriminate(oracle, sb.iq.numpy()[0]), 4096)
+        pos = [f for f in frags if f["fields"] & _lib.DATA_POS]
+        ptu = [f for f in frags if f["fields"] & _lib.DATA_PTU]
+        assert len(pos) >= 3 and len(ptu) >= 3, m20
+        assert all(abs(p["lat"] - 47.0) < 1e-3 and 990.0 < p["alt"] < 1200.0 for p in pos)
+        assert all(-5.0 < f["temp"] < 15.0 for f in ptu)
+        if not m20:
+            assert all(30.0 < f["rh"] < 50.0 for f in ptu)
+
+
+def test_rs41_sgp_pressure_and_ozone_b1(oracle):
+    """RS41-SGP with an ozone interface: extended (518-byte) frames through the GPU decoder; the PTU fragments carry
+    the sensor's pressure (decoder.hpp:89) and the XDATA subframe yields DATA_OZONE (decoder.hpp:102-106)."""
+    n = 2048 * 640                        # 27 s: the calibration words of the pressure block arrive 16 bytes per frame
+    sb = synth.make_rs41_batch(1, n, seed=14, ebn0_db=26.0, extended=True, sgp=True)
+    frags = _run_b1("rs41", _discriminate(oracle, sb.iq.numpy()[0]), 48000)
+    o3 = [f["o3_mpa"] for f in frags if f["fields"] & _lib.DATA_OZONE]
+    assert len(o3) >= 20 and all(3.0 < v < 8.0 for v in o3)
+    assert any(f["fields"] & _lib.DATA_SERIAL for f in frags)
+
+
+def test_imet_xdata_b1(oracle):
+    G = 16384
+    sb = synth.make_imet_batch(1, G * 8, seed=31, snr_db=30.0, xdata=True)
+    frags = _run_b1("imet4", _discriminate(oracle, sb.iq.numpy()[0]), 4800)
+    o3 = [f["o3_mpa"] for f in frags if f["fields"] & _lib.DATA_OZONE]
+    assert len(o3) >= 2 and all(4.0 < v < 6.0 for v in o3)
+    assert sum(1 for f in frags if f["fields"] & _lib.DATA_PTU) >= 2

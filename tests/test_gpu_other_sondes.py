@@ -66,3 +66,19 @@ def test_mixed_types_per_channel_dispatch(oracle):
     got2 = np.concatenate(parts)
     got2 = got2[np.lexsort((got2["bitpos"], got2["channel"]))]
     assert got2.tobytes() == ref.tobytes()
+
+
+def test_m20_frames_bit_exact(oracle):
+    """M20 (label "M10/M20", /root/reference/src/main.hpp:48): 70-byte frames through the same framer; the length byte
+    selects where the checksum sits.  GPU records == oracle records, and equal to what was transmitted."""
+    C, n = 8, TILE * 40
+    sb = synth.make_batch(3, C, n, seed=47, ebn0_db=28.0, m20=True)
+    b = SondeBatch(C, n, types=np.full(C, 3, dtype=np.uint8))
+    b.submit(sb.iq.to("cuda:0"))
+    got = b.frames()
+    ref = oracle.batch_run(3, sb.iq.numpy(), nthreads=4)
+    assert len(ref) >= C and got.tobytes() == ref.tobytes()
+    assert (got["len"] == 70).all() and (got["nerr"][:, 0] == 0).sum() >= len(got) - C
+    sent = sum(len(f) for f in sb.frames)
+    exact = sum(any(np.array_equal(tx[:70], f["data"][:70]) for _, tx in sb.frames[f["channel"]]) for f in got)
+    assert exact >= sent - C
