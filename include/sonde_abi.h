@@ -198,6 +198,9 @@ uint32_t    sonde_chan_samples_per_submit(const SondeChannelizer *c);
 int         sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t n_samples, void *stream);
 SondeBatch *sonde_chan_batch(SondeChannelizer *c);     /* frames of the 512 bins: sonde_batch_sync / _frames on this */
 int         sonde_chan_read(SondeChannelizer *c, float *bins, float *out48);      /* parity-test introspection */
+/* average device time (ms) of the filter-bank kernel, the discriminator + resampler kernel and the decoder kernels over the
+ * timed submits (every 8th) since the previous call; synchronises */
+int         sonde_chan_kernel_ms(SondeChannelizer *c, float *pfb_ms, float *disc_resamp_ms, float *demod_ms, float *framer_ms);
 int         sonde_chan_tables(float *h, float *tw, float *g);
 
 /* post-FEC derived quantities, as /root/reference/src/decode/decoder.hpp:132-174 computes them */

@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "sonde_gpx_open", "sonde_gpx_close", "sonde_gpx_start_track", "sonde_gpx_stop_track", "sonde_gpx_add_point",
     "sonde_ptu_open", "sonde_ptu_close", "sonde_ptu_add_point",
     "sonde_chan_create", "sonde_chan_destroy", "sonde_chan_samples_per_submit", "sonde_chan_submit", "sonde_chan_batch",
-    "sonde_chan_read", "sonde_chan_tables",
+    "sonde_chan_read", "sonde_chan_tables", "sonde_chan_kernel_ms",
 ] + [f"{x}_{fn}" for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1")
      for fn in ("decoder_init", "decoder_deinit", "decode")]
 
@@ -141,6 +141,7 @@ def load() -> C.CDLL:
     L.sonde_chan_samples_per_submit.argtypes = [vp]
     L.sonde_chan_samples_per_submit.restype = C.c_uint32
     L.sonde_chan_submit.argtypes = [vp, vp, C.c_size_t, vp]
+    L.sonde_chan_kernel_ms.argtypes = [vp] + [C.POINTER(C.c_float)] * 4
     L.sonde_chan_batch.argtypes = [vp]
     L.sonde_chan_batch.restype = vp
     L.sonde_chan_read.argtypes = [vp, vp, vp]

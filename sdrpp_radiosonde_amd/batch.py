@@ -166,6 +166,13 @@ class SondeChannelizer:
     def frames(self) -> np.ndarray:
         return SondeBatch.frames(self.batch)
 
+    def kernel_ms(self):
+        """(filter bank, discriminator + resampler, demodulator, framers) average ms over the timed submits."""
+        v = [C.c_float() for _ in range(4)]
+        if self.L.sonde_chan_kernel_ms(self.h, *[C.byref(x) for x in v]) != 0:
+            raise SondeError(_lib.last_error() or "sonde_chan_kernel_ms failed")
+        return tuple(x.value for x in v)
+
     def read(self):
         bins = np.zeros((512, self.n_steps, 2), dtype=np.float32)
         out48 = np.zeros((512, self.n_steps * 6 // 5), dtype=np.float32)

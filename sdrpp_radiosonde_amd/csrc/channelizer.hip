@@ -114,6 +114,12 @@ struct SondeChannelizer {
 	SondeBatch *batch = nullptr;
 	float2 *d_wbuf = nullptr, *d_bins = nullptr, *d_tw = nullptr, *d_iqlast = nullptr;
 	float *d_h = nullptr, *d_g = nullptr, *d_dhist = nullptr, *d_out48 = nullptr;
+	// kernel timing (HIP events on the submit stream), sampled: every 8th submit
+	hipEvent_t ev[3] = {};
+	unsigned long n_submits = 0;
+	double acc_ms[2] = { 0.0, 0.0 };
+	int n_timed = 0;
+	bool ev_pending = false;
 };
 
 static void make_tables(std::vector<float> &h, std::vector<float> &tw, std::vector<float> &g)
@@ -162,6 +168,7 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	sonde_batch_destroy(c->batch);
+	for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	(void)hipFree(c->d_wbuf); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_iqlast);
 	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48);
 	delete c;
@@ -199,6 +206,7 @@ extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submi
 	     hipMemcpy(c->d_h, h.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_tw, tw.data(), CH_M * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_g, g.data(), RS_UP * RS_TAPS * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+	for (int i = 0; i < 3 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
 	if (!ok) { sonde_chan_destroy(c); return -1; }
 	*out = c;
 	return 0;
@@ -213,15 +221,49 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 	hipStream_t stream = (hipStream_t)stream_;
 	if (hipSetDevice(c->device) != hipSuccess) return -1;
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
+	// fold the previous timed submit's events into the running sums (they have long completed)
+	if (c->ev_pending && hipEventQuery(c->ev[2]) == hipSuccess) {
+		float a = 0.f, b = 0.f;
+		if (hipEventElapsedTime(&a, c->ev[0], c->ev[1]) == hipSuccess && hipEventElapsedTime(&b, c->ev[1], c->ev[2]) == hipSuccess) {
+			c->acc_ms[0] += a; c->acc_ms[1] += b; c->n_timed++;
+		}
+		c->ev_pending = false;
+	}
+	const bool timed = !c->ev_pending && (c->n_submits++ % 8) == 0;
 	// [history | block]: the block lands behind the 7942 samples carried from the previous submit
 	if (hipMemcpyAsync(c->d_wbuf + CH_H, iq_dev, n_samples * sizeof(float2), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
+	if (timed) (void)hipEventRecord(c->ev[0], stream);
 	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps), dim3(256), 0, stream, c->d_wbuf, c->d_h, c->d_tw, c->d_bins, c->n_steps);
+	if (timed) (void)hipEventRecord(c->ev[1], stream);
 	hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
 	                   c->d_bins, c->n_steps, c->d_g, c->d_iqlast, c->d_dhist, c->d_out48);
+	if (timed) { (void)hipEventRecord(c->ev[2], stream); c->ev_pending = true; }
 	// roll the history: the last 7942 samples of [history | block] move to the front (regions do not overlap)
 	if (hipMemcpyAsync(c->d_wbuf, c->d_wbuf + n_samples, (size_t)CH_H * sizeof(float2), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
 	if (hipGetLastError() != hipSuccess) return -1;
 	return sonde_batch_submit(c->batch, c->d_out48, n_out, n_out, stream_);
+}
+
+// Average device time (ms) of the filter-bank kernel and of the discriminator + resampler kernel over the timed submits
+// (every 8th) since the previous call, then of the decoder behind them (sonde_batch_kernel_ms of the embedded batch).
+extern "C" int sonde_chan_kernel_ms(SondeChannelizer *c, float *pfb_ms, float *disc_resamp_ms, float *demod_ms, float *framer_ms)
+{
+	if (!c) return -1;
+	if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+	if (c->ev_pending) {
+		float a = 0.f, b = 0.f;
+		if (hipEventElapsedTime(&a, c->ev[0], c->ev[1]) == hipSuccess && hipEventElapsedTime(&b, c->ev[1], c->ev[2]) == hipSuccess) {
+			c->acc_ms[0] += a; c->acc_ms[1] += b; c->n_timed++;
+		}
+		c->ev_pending = false;
+	}
+	if (c->n_timed == 0) return -1;
+	if (pfb_ms) *pfb_ms = (float)(c->acc_ms[0] / c->n_timed);
+	if (disc_resamp_ms) *disc_resamp_ms = (float)(c->acc_ms[1] / c->n_timed);
+	c->acc_ms[0] = c->acc_ms[1] = 0.0;
+	c->n_timed = 0;
+	c->n_submits = 0;
+	return sonde_batch_kernel_ms(c->batch, demod_ms, framer_ms);
 }
 
 // introspection for the parity tests: copies of the intermediate products of the last submit
