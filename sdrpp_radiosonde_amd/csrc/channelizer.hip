@@ -23,53 +23,145 @@
 #define RS_DN 5
 #define RS_TAPS 16
 
-// ---- PFB: one workgroup per output time step m.  Fold 16 taps per bin, circular shift by (m*D mod 512),
-// 512-point radix-2 DIT FFT in LDS (bit-reversed load), one butterfly per thread per stage.
-__global__ __launch_bounds__(256) void sd_pfb_kernel(const float2 *__restrict__ wbuf, const float *__restrict__ h,
-                                                      const float2 *__restrict__ tw, float2 *__restrict__ bins, uint32_t n_steps)
+// ---- PFB: one 1024-thread workgroup per PFB_S = 16 consecutive output time steps.
+//   1. the 8192 + 15*250 wideband samples the 16 windows cover are staged in LDS ONCE (95.5 KB; a workgroup per step
+//      re-read a 64 KB window per 250 new samples: 32.8x through L2);
+//   2. fold: thread (r, g) accumulates the 16 taps of bin residue r for the 8 steps of group g, taps in registers,
+//      t ascending (SPEC 3.5: v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc));
+//   3. circular shift by (m*D mod 512) + bit reversal into a per-wave buffer (aliasing the dead window);
+//   4. 512-point radix-2 DIT FFT, one WAVE per time step: every lane keeps 8 points in registers and runs three stages
+//      on them, three times, with two transposes through the wave's own LDS buffer in between -- the butterflies, their
+//      operand order and the twiddles are exactly those of the stage-by-stage form (oracle/or_chan.c or_fft512), only
+//      the 18 workgroup barriers are gone;
+//   5. the 512 x 16 output tile is transposed through LDS so that every bin row receives one aligned 128-byte run
+//      (it was an 8-byte store per bin per step, 40 KB apart).
+#define PFB_S    16
+#define PFB_WIN  (CH_L + (PFB_S - 1) * CH_D)          // 11942 samples
+#define PFB_FB   (CH_M + CH_M / 8)                    // FFT buffer per wave: one pad element per 8 (bank spread)
+#define PFB_OT   (PFB_S + 1)                          // output tile row stride (float2)
+static_assert(PFB_S * PFB_FB <= PFB_WIN && CH_M * PFB_OT <= PFB_WIN, "the FFT buffers and the output tile alias the window");
+static_assert(PFB_WIN % 2 == 0 && (CH_D * sizeof(float2)) % 16 == 0, "16-byte staging loads");
+
+__device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
 {
-	__shared__ float s_re[CH_M], s_im[CH_M];
-	const uint32_t m = blockIdx.x;
-	const int tid = threadIdx.x;
-	const float2 *x = wbuf + (size_t)m * CH_D;
-	const uint32_t shift = (m * CH_D) & (CH_M - 1);
+	const float tr = __builtin_fmaf(-b.y, w.y, b.x * w.x);
+	const float ti = __builtin_fmaf(b.x, w.y, b.y * w.x);
+	const float2 a0 = a;
+	a = make_float2(a0.x + tr, a0.y + ti);
+	b = make_float2(a0.x - tr, a0.y - ti);
+}
+__device__ __forceinline__ int pfb_pad(int i) { return i + (i >> 3); }
+
+__global__ __launch_bounds__(64 * PFB_S) void sd_pfb_kernel(const float2 *__restrict__ wbuf, const float *__restrict__ h,
+                                                         const float2 *__restrict__ tw, float2 *__restrict__ bins, uint32_t n_steps)
+{
+	__shared__ __attribute__((aligned(16))) float2 s_x[PFB_WIN];
+	__shared__ float2 s_tw[CH_M / 2];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t m0 = blockIdx.x * PFB_S;
+	{	// 1. stage the window (16-byte loads; wbuf + m0*250 samples is 16-byte aligned) and the twiddles
+		// all loads first, then all LDS stores: one memory round trip per workgroup instead of one per loop iteration
+		const float4 *src = reinterpret_cast<const float4 *>(wbuf + (size_t)m0 * CH_D);
+		float4 *dst = reinterpret_cast<float4 *>(s_x);
+		constexpr int NQ = (PFB_WIN / 2 + 64 * PFB_S - 1) / (64 * PFB_S);
+		float4 tmp[NQ];
 #pragma unroll
-	for (int q = 0; q < 2; q++) {
-		const int r = tid + 256 * q;
+		for (int q = 0; q < NQ; q++) {
+			const int i = tid + 64 * PFB_S * q;
+			tmp[q] = i < PFB_WIN / 2 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		const float2 twv = tid < CH_M / 2 ? tw[tid] : make_float2(0.f, 0.f);
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			const int i = tid + 64 * PFB_S * q;
+			if (i < PFB_WIN / 2) dst[i] = tmp[q];
+		}
+		if (tid < CH_M / 2) s_tw[tid] = twv;
+	}
+	// 2. fold: r = tid & 511, steps 8g .. 8g+7 with g = tid >> 9
+	const int r = tid & (CH_M - 1), g = tid >> 9;
+	float hr[CH_T];
+#pragma unroll
+	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
+	__syncthreads();
+	float2 v[PFB_S / 2];
+#pragma unroll
+	for (int q = 0; q < PFB_S / 2; q++) {
+		const float2 *xs = s_x + (8 * g + q) * CH_D + r;
 		float ar = 0.0f, ai = 0.0f;
 #pragma unroll
 		for (int t = 0; t < CH_T; t++) {
-			const int i = r + t * CH_M;
-			const float2 v = x[i];
-			const float hv = h[i];
-			ar = __builtin_fmaf(hv, v.x, ar);
-			ai = __builtin_fmaf(hv, v.y, ai);
+			const float2 xv = xs[t * CH_M];
+			ar = __builtin_fmaf(hr[t], xv.x, ar);
+			ai = __builtin_fmaf(hr[t], xv.y, ai);
 		}
+		v[q] = make_float2(ar, ai);
+	}
+	__syncthreads();                       // the window is dead from here on
+	// 3. rotate + bit-reverse into the buffer of the wave that owns the step
+#pragma unroll
+	for (int q = 0; q < PFB_S / 2; q++) {
+		const int sidx = 8 * g + q;
+		const uint32_t shift = ((m0 + (uint32_t)sidx) * CH_D) & (CH_M - 1);
 		const uint32_t pos = ((uint32_t)r + shift) & (CH_M - 1);
-		const uint32_t rev = __brev(pos) >> 23;                  // 9-bit reversal
-		s_re[rev] = ar;
-		s_im[rev] = ai;
+		const int rev = (int)(__brev(pos) >> 23);               // 9-bit reversal
+		s_x[sidx * PFB_FB + pfb_pad(rev)] = v[q];
 	}
 	__syncthreads();
+	// 4. FFT of step m0 + wave, by this wave alone
+	float2 *fb = s_x + wave * PFB_FB;
+	float2 e[8];
+	// stages 1-3 on elements 8*lane + j
 #pragma unroll
-	for (int st = 1; st <= 9; st++) {
-		const int half = 1 << (st - 1), step = CH_M >> st;
-		const int jj = tid & (half - 1);
-		const int a = ((tid >> (st - 1)) << st) + jj, b = a + half;
-		const float2 w = tw[jj * step];
-		const float br = s_re[b], bi = s_im[b];
-		const float tr = __builtin_fmaf(-bi, w.y, br * w.x);
-		const float ti = __builtin_fmaf(br, w.y, bi * w.x);
-		const float ar = s_re[a], ai = s_im[a];
-		__syncthreads();
-		s_re[a] = ar + tr; s_im[a] = ai + ti;
-		s_re[b] = ar - tr; s_im[b] = ai - ti;
-		__syncthreads();
+	for (int j = 0; j < 8; j++) e[j] = fb[pfb_pad(8 * lane + j)];
+#pragma unroll
+	for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], s_tw[0]);
+#pragma unroll
+	for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], s_tw[(j & 1) * 128]);
+#pragma unroll
+	for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], s_tw[j * 64]);
+#pragma unroll
+	for (int j = 0; j < 8; j++) fb[pfb_pad(8 * lane + j)] = e[j];
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	// stages 4-6 on elements lo + 8 j + 64 hi
+	{
+		const int lo = lane & 7, hi = lane >> 3;
+#pragma unroll
+		for (int j = 0; j < 8; j++) e[j] = fb[pfb_pad(lo + 8 * j + 64 * hi)];
+#pragma unroll
+		for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], s_tw[lo * 32]);
+#pragma unroll
+		for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], s_tw[(lo + 8 * (j & 1)) * 16]);
+#pragma unroll
+		for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], s_tw[(lo + 8 * j) * 8]);
+#pragma unroll
+		for (int j = 0; j < 8; j++) fb[pfb_pad(lo + 8 * j + 64 * hi)] = e[j];
 	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	// stages 7-9 on elements lane + 64 j
 #pragma unroll
-	for (int q = 0; q < 2; q++) {
-		const int k = tid + 256 * q;
-		bins[(size_t)k * n_steps + m] = make_float2(s_re[k], s_im[k]);
+	for (int j = 0; j < 8; j++) e[j] = fb[pfb_pad(lane + 64 * j)];
+#pragma unroll
+	for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], s_tw[lane * 4]);
+#pragma unroll
+	for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], s_tw[(lane + 64 * (j & 1)) * 2]);
+#pragma unroll
+	for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], s_tw[lane + 64 * j]);
+	__syncthreads();                       // every wave has left its FFT buffer: the output tile aliases them
+	// 5. tile[bin][step] (row stride 17), then one 64-byte run per thread: bin = tid >> 1, steps 8*(tid & 1) ..
+#pragma unroll
+	for (int j = 0; j < 8; j++) s_x[(lane + 64 * j) * PFB_OT + wave] = e[j];
+	__syncthreads();
+	{
+		const int k = tid >> 1, s0 = 8 * (tid & 1);
+		float2 o[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) o[j] = s_x[k * PFB_OT + s0 + j];
+		float4 *dst = reinterpret_cast<float4 *>(bins + (size_t)k * n_steps + m0 + s0);
+#pragma unroll
+		for (int j = 0; j < 4; j++) dst[j] = make_float4(o[2 * j].x, o[2 * j].y, o[2 * j + 1].x, o[2 * j + 1].y);
 	}
 }
 
@@ -86,10 +178,24 @@ __global__ __launch_bounds__(256) void sd_disc_resamp_kernel(const float2 *__res
 	if (tid < RS_UP * RS_TAPS) s_g[tid] = g[tid];
 	if (tid < RS_TAPS) s_d[tid] = dhist[(size_t)k * RS_TAPS + tid];
 	const float2 first_prev = iq_last[k];
-	for (uint32_t i = tid; i < n_steps; i += 256) {
-		const float2 cur = x[i];
-		const float2 prv = i ? x[i - 1] : first_prev;
-		s_d[RS_TAPS + i] = sd_disc(cur.x, cur.y, prv.x, prv.y);
+	// chunks of 5120 samples: every thread issues its 10 sixteen-byte loads (two samples each) and the 10 predecessor
+	// samples before the first result is needed -- one memory round trip per chunk instead of one per sample
+	for (uint32_t c0 = 0; c0 < n_steps; c0 += 5120) {
+		const float4 *x4 = reinterpret_cast<const float4 *>(x + c0);
+		float4 cur[10];
+		float2 prv[10];
+#pragma unroll
+		for (int q = 0; q < 10; q++) {
+			const uint32_t i4 = (uint32_t)tid + 256u * q;            // float4 index inside the chunk: samples 2*i4, 2*i4 + 1
+			cur[q] = x4[i4];
+			prv[q] = (c0 + i4) ? x[c0 + 2 * i4 - 1] : first_prev;
+		}
+#pragma unroll
+		for (int q = 0; q < 10; q++) {
+			const uint32_t i = c0 + 2 * ((uint32_t)tid + 256u * q);
+			s_d[RS_TAPS + i] = sd_disc(cur[q].x, cur[q].y, prv[q].x, prv[q].y);
+			s_d[RS_TAPS + i + 1] = sd_disc(cur[q].z, cur[q].w, cur[q].x, cur[q].y);
+		}
 	}
 	__syncthreads();
 	const uint32_t n_out = n_steps * RS_UP / RS_DN;
@@ -233,7 +339,7 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 	// [history | block]: the block lands behind the 7942 samples carried from the previous submit
 	if (hipMemcpyAsync(c->d_wbuf + CH_H, iq_dev, n_samples * sizeof(float2), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
 	if (timed) (void)hipEventRecord(c->ev[0], stream);
-	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps), dim3(256), 0, stream, c->d_wbuf, c->d_h, c->d_tw, c->d_bins, c->n_steps);
+	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(64 * PFB_S), 0, stream, c->d_wbuf, c->d_h, c->d_tw, c->d_bins, c->n_steps);
 	if (timed) (void)hipEventRecord(c->ev[1], stream);
 	hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
 	                   c->d_bins, c->n_steps, c->d_g, c->d_iqlast, c->d_dhist, c->d_out48);
