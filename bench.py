@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time spent on the all-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--mix", action="store_true", help="BASELINE configs[2]: sonde type = (RS41, M10, DFM09)[channel % 3] (not the headline workload)")
+    ap.add_argument("--sonde-type", type=int, default=0, help="all channels of this SONDE_* type (1 DFM09, 2 iMS-100, 3 M10; not the headline workload)")
     ap.add_argument("--wideband", action="store_true", help="BASELINE configs[3]: 10 MS/s IQ -> 512-bin channelizer -> per-bin demod+FEC")
     ap.add_argument("--wb-streams", type=int, default=1, help="--wideband: independent 10 MS/s streams processed per step")
     ap.add_argument("--time-every", type=int, default=8, help="kernel-timing events on every n-th timed step (1: all)")
@@ -252,6 +253,9 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
         for t in order:
             idx = np.nonzero(types == t)[0]
             iq[torch.from_numpy(idx).to(dev)] = synth.make_batch(int(t), len(idx), n, seed=1000 + rank + 10 * t, ebn0_db=args.ebn0 + 2.0, device=dev).iq
+    elif args.sonde_type:
+        types = np.full(C, args.sonde_type, dtype=np.uint8)
+        iq = synth.make_batch(args.sonde_type, C, n, seed=1000 + rank, ebn0_db=args.ebn0 + 2.0, device=dev).iq
     else:
         iq = synth.make_rs41_batch(C, n, seed=1000 + rank, ebn0_db=args.ebn0, device=dev, first_channel=rank * C).iq
     if args.stride_pad:
@@ -323,6 +327,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": (f"RS41/M10/DFM09 by channel % 3 x {C} channels/GPU x {n} samples (48 kS/s)" if args.mix else
+                                f"SONDE type {args.sonde_type} x {C} channels/GPU x {n} samples (48 kS/s)" if args.sonde_type else
                                 f"RS41-SG x {C} channels/GPU x {n} samples (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)"),
                    "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{world}",
                    "ingest": "rccl-scatter" if scatter_ms is not None else "rank-local"},
@@ -341,7 +346,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
     }
     if scatter_ms is not None:
         out["scatter_ms"] = round(scatter_ms, 3)
-    if rank == 0 and world == 1 and not args.no_cpu and not args.mix:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.mix and not args.sonde_type:
         out["cpu_baseline"] = cpu_baseline(iq, C, n, args)
         out["cpu_baseline"]["frames_match_gpu_first_submit"] = bool(out["cpu_baseline"]["frames_per_pass"] == nfr_first) \
             if (args.cpu_channels or C) == C else None

@@ -308,7 +308,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	}
 	{
 		b->fuse_fec = (cfg->flags & SONDE_FLAG_SPLIT_FEC) ? 0u : 1u;
-		const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts, b->max_frames, b->fuse_fec, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_frames };
+		const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts, b->max_frames, b->fuse_fec, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames };
 		CHK(hipMemcpy(b->d_fo, &fo, sizeof(fo), hipMemcpyHostToDevice));
 	}
 	// initial channel state
@@ -409,7 +409,8 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10 }) {
 		if (b->chlist[t].empty()) continue;
 		sd_launch_framer_other(t, (uint32_t)b->chlist[t].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-			b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t]);
+			b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],
+			/* with_sync = */ !b->fuse_fec);        // default: the demod kernel has run the sync search (K4) itself
 		HIPCHK(hipGetLastError());
 		framer_launched = true;
 	}

@@ -22,6 +22,7 @@
 #include "sd_math.h"
 #include "sd_rs41.h"
 #include "sd_rsdec.h"
+#include "sd_fixed.h"
 #include "launch.h"
 
 typedef float sd_f32x4 __attribute__((ext_vector_type(4)));
@@ -169,16 +170,27 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		s.pub.flag = 0;
 		s.pub.wpos = st.wpos;
 	}
-	// K4 (RS41 channels): the sync search runs in here, on round wave 3, over an LDS mirror of the newest ring words
-	const bool framing = st.type == SONDE_RS41;          // workgroup-uniform
+	// K4: the sync search of the framed sondes runs in here, on round wave 3, over an LDS mirror of the newest ring words
+	// (RS41 always; DFM / iMS-100 / M10 unless the batch asked for the stand-alone framer kernels)
+	// Which sonde types an instantiation can meet follows from its decimation factor (batch.hip k_modems): 4 -> RS41;
+	// 2 -> DFM, iMS-100, RS41 in wide mode; 1 -> M10 (and the iMet 6 kS/s stream, which is framed elsewhere).  Testing DEC
+	// first lets the compiler drop the other types' code from each instantiation.
+	const int stype = __builtin_amdgcn_readfirstlane(st.type);
+	const bool is_rs41 = DEC != 1 && stype == SONDE_RS41, is_dfm = DEC == 2 && stype == SONDE_DFM09,
+	           is_ims = DEC == 2 && stype == SONDE_IMS100, is_m10 = DEC == 1 && stype == SONDE_M10;
+	const bool fuse = fo->fuse_fec != 0;
+	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10));   // workgroup-uniform
 	if (framing && tid >= SD_WGT - SD_MIRROR_WORDS) {
 		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WGT - 1 - tid);      // the words up to and including wpos's
 		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
 	}
 
-	const bool fec_here = DEC != 1 && framing && fo->fuse_fec != 0;     // workgroup-uniform
+	// K5/K6 in this kernel's epilogue: RS41 only (few, heavy frames per submit).  The short frames of the fixed-length
+	// framers (a DFM frame every 2.7 tiles) decode faster as one wave per frame across the whole GPU (framer2_kernel.hip)
+	// than eight at a time at the end of each workgroup: measured 0.358 vs 0.324 ms per step for 4096 DFM channels.
+	const bool fec_here = is_rs41 && fuse;     // workgroup-uniform
 	EpiTabs &et = *reinterpret_cast<EpiTabs *>(&s.B[1][SD_EPI_TAB_OFF]);
-	if (fec_here) {
+	if (fec_here && is_rs41) {
 		// GF(2^8) tables for the epilogue: one 16-byte global load per thread now, hidden behind the first tile's loads
 		if (tid < GF_EXP2 / 16) reinterpret_cast<uint4 *>(et.tabs.exp2)[tid] = reinterpret_cast<const uint4 *>(fo->gf_exp)[tid];
 		else if (tid < GF_EXP2 / 16 + 512 / 16) reinterpret_cast<uint4 *>(et.tabs.log2)[tid - GF_EXP2 / 16] = reinterpret_cast<const uint4 *>(fo->gf_log)[tid - GF_EXP2 / 16];
@@ -399,9 +411,16 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		s.k4.rpos = f0.rpos; s.k4.fstart = f0.fstart; s.k4.collecting = f0.collecting; s.k4.inv = f0.inv; s.k4.flen = f0.flen;
 		s.k4.nout = 0; s.k4.wp_seen = st.wpos;
 	};
+	auto k4_run = [&](uint64_t wp) {   // one step of the channel's sync-search state machine (wave-uniform type dispatch)
+		SdFrameDesc *dch = (SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames;
+		const uint32_t mf = fo->max_frames;
+		if (is_rs41) sd_rs41_sync_step(s.k4, wp, s.mirror, lane, dch, mf);
+		else if (is_dfm) sd_fixed_sync_step<SONDE_DFM09>(s.k4, wp, s.mirror, lane, dch, mf);
+		else if (is_m10) sd_fixed_sync_step<SONDE_M10>(s.k4, wp, s.mirror, lane, dch, mf);
+		else if (is_ims) sd_fixed_sync_step<SONDE_IMS100>(s.k4, wp, s.mirror, lane, dch, mf);
+	};
 	auto k4_finish = [&]() {       // K4's wave, after barrier E: catch up with the last rounds' bits, state and frame count back to HBM
-		sd_rs41_sync_step(s.k4, sd_uniform64(s.pub.wpos), s.mirror, lane,
-			(SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames, fo->max_frames);
+		k4_run(sd_uniform64(s.pub.wpos));
 		if (lane == 0) {
 			SdFramerState f1;
 			f1.rpos = s.k4.rpos; f1.fstart = s.k4.fstart; f1.collecting = s.k4.collecting; f1.inv = s.k4.inv; f1.flen = s.k4.flen; f1.pad = 0;
@@ -415,8 +434,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		// K4 on a discriminator wave: behind its loads, over the bits the lead wave has announced by then (LDS operations
 		// of a wave are performed in order, so whoever sees the new wpos also sees the mirror words written before it)
 		auto k4_step = [&]() {
-			if (k4d) sd_rs41_sync_step(s.k4, sd_uniform64(__hip_atomic_load(&s.pub.wpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
-				s.mirror, lane, (SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames, fo->max_frames);
+			if (k4d) k4_run(sd_uniform64(__hip_atomic_load(&s.pub.wpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
 		};
 		load_tile(0, va, pa, qa);
 		if (n_tiles > 1) load_tile(1, vb, pb, qb);
@@ -481,8 +499,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				} else {
 					// K4 instead of spinning while the lead wave runs the loop filter: the search works on the bits the
 					// PREVIOUS publish announced (one round behind; the epilogue catches up)
-					if (k4) sd_rs41_sync_step(s.k4, sd_uniform64(s.k4.wp_seen), s.mirror, lane,
-						(SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames, fo->max_frames);
+					if (k4) k4_run(sd_uniform64(s.k4.wp_seen));
 					while (__hip_atomic_load(&s.pub.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1u)
 						__builtin_amdgcn_s_sleep(2);
 					t_next = s.pub.t_next; period = s.pub.period; bias = s.pub.bias; K = s.pub.K;

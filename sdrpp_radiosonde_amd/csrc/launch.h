@@ -13,6 +13,7 @@ struct SdFramerOut {
 	SdFramerState *fstates; void *descs; uint32_t *counts; uint32_t max_frames;
 	uint32_t fuse_fec;                      // 1: the demod kernel decodes the listed frames in its epilogue; 0: sd_rsdec_rs41_kernel does
 	const uint8_t *gf_exp, *gf_log; const uint32_t *gf_swar;
+	const uint8_t *gf64;                    // GF(2^6) tables of the iMS-100 BCH decoder
 	SondeFrame *frames;
 };
 void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
@@ -32,4 +33,5 @@ void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream, const uint32_t *
 
 void sd_launch_framer_other(int type, uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
-	const uint8_t *g64, void *descs, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist);
+	const uint8_t *g64, void *descs, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist,
+	bool with_sync /* false: the demod kernel has listed the frames already */);

@@ -82,3 +82,26 @@ def test_m20_frames_bit_exact(oracle):
     sent = sum(len(f) for f in sb.frames)
     exact = sum(any(np.array_equal(tx[:70], f["data"][:70]) for _, tx in sb.frames[f["channel"]]) for f in got)
     assert exact >= sent - C
+
+
+def test_split_framers_equal_in_kernel_sync(oracle):
+    """SONDE_FLAG_SPLIT_FEC: sync search and decode as kernels of their own (the round-1 structure) give the same frame
+    records as the default (sync search inside the demod kernel) for DFM / iMS-100 / M10, over two submits."""
+    from sdrpp_radiosonde_amd._lib import FLAG_SPLIT_FEC
+    C, n = 9, TILE * 48
+    types = np.array([(1, 2, 3)[c % 3] for c in range(C)], dtype=np.uint8)
+    iq = torch.empty((C, n, 2), dtype=torch.float32)
+    for t in (1, 2, 3):
+        idx = np.nonzero(types == t)[0]
+        iq[idx] = synth.make_batch(int(t), len(idx), n, seed=60 + int(t), ebn0_db=16.0).iq
+    dev = iq.to("cuda:0")
+    outs = []
+    for flags in (0, FLAG_SPLIT_FEC):
+        b = SondeBatch(C, n // 2, types=types, flags=flags)
+        parts = []
+        for lo in (0, n // 2):
+            b.submit(dev[:, lo: lo + n // 2].contiguous())
+            parts.append(b.frames())
+        g = np.concatenate(parts)
+        outs.append(g[np.lexsort((g["bitpos"], g["channel"]))])
+    assert len(outs[0]) >= 2 * C and outs[0].tobytes() == outs[1].tobytes()
