@@ -107,6 +107,7 @@ struct SondeBatch {
 	float *d_taps = nullptr;
 	SdModem *d_modems = nullptr;
 	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_g64 = nullptr;
+	uint16_t *d_m10tab = nullptr;          // Meteomodem checksum as a GF(2) matrix product: rows A^k B, sd_fixed.h
 	uint32_t fuse_fec = 1;                 // RS41 FEC in the demod kernel's epilogue (default) or as its own kernel (SONDE_FLAG_SPLIT_FEC)
 	SdFramerOut *d_fo = nullptr;           // where the demod kernel's in-kernel sync search keeps its state (device copy)
 	uint32_t *d_gfswar = nullptr;          // byte-slice tables of the 24 syndrome multipliers alpha^(4j), framer_kernel.hip
@@ -157,7 +158,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
 	for (int k = 0; k < 3; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_fo); (void)hipFree(b->d_g64); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
+	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_fo); (void)hipFree(b->d_g64); (void)hipFree(b->d_m10tab); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	delete b;
@@ -223,6 +224,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_gfswar, 24 * 8 * sizeof(uint32_t));
 	ALLOC(b->d_fo, sizeof(SdFramerOut));
 	ALLOC(b->d_g64, 192);
+	ALLOC(b->d_m10tab, 99 * 8 * sizeof(uint16_t));
 	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
@@ -305,6 +307,25 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		for (int i = 0; i < 63; i++) { g64[i] = (uint8_t)x; g64[128 + x] = (uint8_t)i; x <<= 1; if (x & 0x40) x ^= 0x43; }
 		for (int i = 63; i < 128; i++) g64[i] = g64[i - 63];
 		CHK(hipMemcpy(b->d_g64, g64, sizeof(g64), hipMemcpyHostToDevice));
+	}
+	{	// M10 checksum: c' = f(c, b) is GF(2)-linear, c' = A c + B b; row k holds A^k B e_j for the eight unit bytes e_j
+		auto step = [](unsigned c, unsigned bb) {
+			const unsigned c1 = c & 0xFF;
+			bb = ((bb >> 1) | ((bb & 1) << 7)) & 0xFF;
+			bb ^= (bb >> 2) & 0xFF;
+			const unsigned t6 = (c & 1) ^ ((c >> 2) & 1) ^ ((c >> 4) & 1);
+			const unsigned t7 = ((c >> 1) & 1) ^ ((c >> 3) & 1) ^ ((c >> 5) & 1);
+			const unsigned t = (c & 0x3F) | (t6 << 6) | (t7 << 7);
+			unsigned sft = (c >> 7) & 0xFF;
+			sft ^= (sft >> 2) & 0xFF;
+			return ((c1 << 8) | (bb ^ t ^ sft)) & 0xFFFFu;
+		};
+		uint16_t tab[99 * 8];
+		for (int j = 0; j < 8; j++) {
+			unsigned c = step(0, 1u << j);
+			for (int k = 0; k < 99; k++) { tab[8 * k + j] = (uint16_t)c; c = step(c, 0); }
+		}
+		CHK(hipMemcpy(b->d_m10tab, tab, sizeof(tab), hipMemcpyHostToDevice));
 	}
 	{
 		b->fuse_fec = (cfg->flags & SONDE_FLAG_SPLIT_FEC) ? 0u : 1u;
@@ -409,7 +430,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10 }) {
 		if (b->chlist[t].empty()) continue;
 		sd_launch_framer_other(t, (uint32_t)b->chlist[t].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-			b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],
+			t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],
 			/* with_sync = */ !b->fuse_fec);        // default: the demod kernel has run the sync search (K4) itself
 		HIPCHK(hipGetLastError());
 		framer_launched = true;

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void sd_sync_fixed_kernel(
 }
 
 // ---------------------------------------------------------------- stand-alone decoders: one wave per listed frame (sd_fixed.h)
+// `g64`: the type's constant table -- iMS-100: GF(2^6) exp[128] + log[64]; M10: the checksum matrix rows (uint16 [99][8])
 template <int T>
 __global__ __launch_bounds__(64) void sd_dec_fixed_kernel(
 	const uint32_t *__restrict__ bitring, uint32_t ring_words, const uint8_t *__restrict__ g64,
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(64) void sd_dec_fixed_kernel(
 	const SdFrameDesc d = descs[(size_t)ch * max_frames + k];
 	SondeFrame *fr = frames + (size_t)ch * max_frames + k;
 	if (T == SONDE_DFM09) sd_dfm_decode_frame<false>(s, ring, ring_words - 1, d, fr, ch, lane);
-	else if (T == SONDE_M10) sd_m10_decode_frame<false>(s, ring, ring_words - 1, d, fr, ch, lane);
+	else if (T == SONDE_M10) sd_m10_decode_frame<false>(s, reinterpret_cast<const uint16_t *>(g64), ring, ring_words - 1, d, fr, ch, lane);
 	else sd_ims_decode_frame<false>(s, g64, ring, ring_words - 1, d, fr, ch, lane);
 }
 

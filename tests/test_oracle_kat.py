@@ -293,3 +293,21 @@ def test_robustness_modulation_index_onset_and_level(oracle):
     x[:, n // 2:, :] *= 0.01
     fr = oracle.batch_run(0, x, nthreads=4)
     assert int((fr["nerr"] >= 0).all(axis=1).sum()) >= sent - C
+
+
+def test_m10_checksum_is_gf2_linear(oracle):
+    """The GPU decoder evaluates the Meteomodem checksum as a GF(2) matrix product (csrc/sd_fixed.h); that rests on the
+    recurrence being linear: cs(a xor b) = cs(a) xor cs(b) for equal-length byte strings, cs(0...0) = 0."""
+    import ctypes as C
+    L = oracle.lib()
+    L.or_m10_checksum.restype = C.c_uint16
+    L.or_m10_checksum.argtypes = [C.POINTER(C.c_uint8), C.c_size_t]
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 68, 99):
+        z = np.zeros(n, dtype=np.uint8)
+        assert L.or_m10_checksum(oracle.u8ptr(z), n) == 0
+        for _ in range(200):
+            a = rng.integers(0, 256, n, dtype=np.uint8)
+            b = rng.integers(0, 256, n, dtype=np.uint8)
+            x = a ^ b
+            assert L.or_m10_checksum(oracle.u8ptr(x), n) == L.or_m10_checksum(oracle.u8ptr(a), n) ^ L.or_m10_checksum(oracle.u8ptr(b), n)
