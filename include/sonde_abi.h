@@ -118,9 +118,6 @@ typedef struct {
 /* RS41 channels: run the Reed-Solomon stage as a kernel of its own behind the demodulator instead of in the demodulator
  * kernel's epilogue (one launch more per submit; same frames).  Kept for A/B measurements. */
 #define SONDE_FLAG_SPLIT_FEC 2u
-/* Mixed batches: one demodulator launch per decimation class on side streams instead of one launch in which every
- * workgroup runs the demodulator of its own channel's class.  Kept for A/B measurements. */
-#define SONDE_FLAG_CLASS_LAUNCHES 4u
 
 typedef struct SondeBatch SondeBatch;
 

@@ -46,7 +46,6 @@ class SondeBatchConfig(C.Structure):
 
 FLAG_RS41_WIDE = 1
 FLAG_SPLIT_FEC = 2
-FLAG_CLASS_LAUNCHES = 4
 
 
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them

@@ -108,7 +108,6 @@ struct SondeBatch {
 	SdModem *d_modems = nullptr;
 	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_g64 = nullptr;
 	uint16_t *d_m10tab = nullptr;          // Meteomodem checksum as a GF(2) matrix product: rows A^k B, sd_fixed.h
-	bool class_launches = false;           // SONDE_FLAG_CLASS_LAUNCHES
 	uint32_t fuse_fec = 1;                 // RS41 FEC in the demod kernel's epilogue (default) or as its own kernel (SONDE_FLAG_SPLIT_FEC)
 	SdFramerOut *d_fo = nullptr;           // where the demod kernel's in-kernel sync search keeps its state (device copy)
 	uint32_t *d_gfswar = nullptr;          // byte-slice tables of the 24 syndrome multipliers alpha^(4j), framer_kernel.hip
@@ -330,7 +329,6 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	}
 	{
 		b->fuse_fec = (cfg->flags & SONDE_FLAG_SPLIT_FEC) ? 0u : 1u;
-		b->class_launches = (cfg->flags & SONDE_FLAG_CLASS_LAUNCHES) != 0;
 		const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts, b->max_frames, b->fuse_fec, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames };
 		CHK(hipMemcpy(b->d_fo, &fo, sizeof(fo), hipMemcpyHostToDevice));
 	}
@@ -396,24 +394,17 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		sd_launch_demod(iq, b->only_class, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo);
 	} else {
-		// several classes: ONE launch over all channels, each workgroup takes the demodulator of its channel's class
-		// (SONDE_FLAG_CLASS_LAUNCHES: one launch per class on side streams instead, the round-1 structure)
-		if (!b->class_launches) {
-			if (b->n_classes > 0)
-				sd_launch_demod_mixed(iq, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
-					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, fo);
-		} else {
-			HIPCHK(hipEventRecord(b->ev_fork, stream));
-			int used = 0;
-			for (int k = 0; k < 3; k++) {
-				if (!b->n_cls[k]) continue;
-				hipStream_t sk = used == 0 ? stream : b->aux[k];
-				if (sk != stream) HIPCHK(hipStreamWaitEvent(sk, b->ev_fork, 0));
-				sd_launch_demod(iq, k == 2 ? 4 : k + 1, b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
-					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_cls[k], false, fo);
-				if (sk != stream) { HIPCHK(hipEventRecord(b->ev_join[k], sk)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[k], 0)); }
-				used++;
-			}
+		// fork: the class launches are independent (disjoint channels), let them share the GPU
+		HIPCHK(hipEventRecord(b->ev_fork, stream));
+		int used = 0;
+		for (int k = 0; k < 3; k++) {
+			if (!b->n_cls[k]) continue;
+			hipStream_t sk = used == 0 ? stream : b->aux[k];
+			if (sk != stream) HIPCHK(hipStreamWaitEvent(sk, b->ev_fork, 0));
+			sd_launch_demod(iq, k == 2 ? 4 : k + 1, b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
+				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_cls[k], false, fo);
+			if (sk != stream) { HIPCHK(hipEventRecord(b->ev_join[k], sk)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[k], 0)); }
+			used++;
 		}
 		if (n_afsk) {
 			// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows

@@ -130,13 +130,15 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 // factor of every channel of this launch (the host launches once per class), so that the three discriminator
 // variants do not share one register allocation.
 template <bool IS_IQ, bool LIST, int DEC>
-__device__ __forceinline__ void sd_demod_body(DemodLds &s,
+__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
 	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo)
 {
+	__shared__ __attribute__((aligned(16))) DemodLds s;
+
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -557,46 +559,6 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s,
 			}
 		}
 	}
-}
-
-#define SD_DEMOD_PARAMS const float *__restrict__ in, size_t ch_stride, int n_tiles, SdChanState *__restrict__ states, float *__restrict__ hist, \
-	uint32_t *__restrict__ bitring, uint32_t ring_words, const float *__restrict__ taps_all, const SdModem *__restrict__ modems, \
-	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo
-#define SD_DEMOD_FWD in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, compact_in, fo
-
-// one decimation class per launch (a batch of one class, or the AFSK scratch rows)
-template <bool IS_IQ, bool LIST, int DEC>
-__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(SD_DEMOD_PARAMS)
-{
-	__shared__ __attribute__((aligned(16))) DemodLds s;
-	sd_demod_body<IS_IQ, LIST, DEC>(s, SD_DEMOD_FWD);
-}
-
-// mixed batch: every workgroup takes the body of its own channel's class.  One launch over all channels instead of one
-// per class on side streams: the workgroups of the classes interleave on every CU (an M10 channel is bound by VALU and
-// latency, an RS41 channel by HBM), and the register allocation is the maximum of the three bodies, not their union.
-// Channels whose samples this launch does not cover (the AFSK sondes, demodulated from scratch rows) leave at once.
-template <bool IS_IQ>
-__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_mixed_kernel(SD_DEMOD_PARAMS)
-{
-	__shared__ __attribute__((aligned(16))) DemodLds s;
-	const int type = __builtin_amdgcn_readfirstlane(states[blockIdx.x].type);
-	if (type == SONDE_IMET4) return;
-	const int dec = __builtin_amdgcn_readfirstlane(modems[type].decim);
-	if (dec == 4) sd_demod_body<IS_IQ, false, 4>(s, SD_DEMOD_FWD);
-	else if (dec == 2) sd_demod_body<IS_IQ, false, 2>(s, SD_DEMOD_FWD);
-	else sd_demod_body<IS_IQ, false, 1>(s, SD_DEMOD_FWD);
-}
-
-void sd_launch_demod_mixed(bool is_iq, uint32_t n_channels, hipStream_t stream,
-	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
-	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems, const SdFramerOut *fo)
-{
-	const dim3 g(n_channels), blk(SD_WGT);
-	const uint32_t *chlist = nullptr;
-	const int compact_in = 0;
-	if (is_iq) hipLaunchKernelGGL((sd_demod_mixed_kernel<true>), g, blk, 0, stream, SD_DEMOD_FWD);
-	else hipLaunchKernelGGL((sd_demod_mixed_kernel<false>), g, blk, 0, stream, SD_DEMOD_FWD);
 }
 
 void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,

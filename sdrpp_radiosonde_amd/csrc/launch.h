@@ -21,11 +21,6 @@ void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t str
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */);
 
-// mixed batch: one launch over channels 0..n_channels-1, every workgroup runs the demodulator of its channel's class
-void sd_launch_demod_mixed(bool is_iq, uint32_t n_channels, hipStream_t stream,
-	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
-	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems, const SdFramerOut *fo);
-
 void sd_launch_afsk(bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
 	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride);
 void sd_launch_framer_imet(uint32_t n_list, hipStream_t stream, const SdChanState *states, SdFramerState *fstates,
