@@ -103,8 +103,8 @@ static OrModem g_modems[OR_NTYPES] = {
 	{ OR_IMS100, 4800.0, 0, 0.65f, 2, 1 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
 	{ OR_M10,    9600.0, 0, 0.65f, 1, 1 },  /* M10/M20: 9600 chips/s Manchester: stays at 48 kS/s (5 samples/chip) */
 	{ OR_IMET4,  1200.0, 0, 0.65f, 1, 8 },  /* iMet-1/4: Bell-202 AFSK 1200 Bd; tone demodulator in front, 6 kS/s behind it */
-	{ OR_C50,    2400.0, 0, 0.65f, 2, 1 },  /* placeholders */
-	{ OR_MRZN1,  2400.0, 0, 0.65f, 2, 1 },
+	{ OR_C50,    2400.0, 0, 0.65f, 2, 1 },  /* placeholder */
+	{ OR_MRZN1,  4800.0, 0, 0.65f, 2, 1 },  /* MRZ-N1: 2400 bit/s Manchester => 4800 chips/s */
 };
 static OrModem g_modem_rt[OR_NTYPES];
 

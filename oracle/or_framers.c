@@ -394,6 +394,60 @@ static int imet4_run(OrFramerPub *f, const uint8_t *bits, uint64_t wpos)
 	return added;
 }
 
+/* ------------------------------------------------------------------ MRZ-N1 (SPEC 3.3d; [RECALL]: 2400 bit/s GFSK,
+ * Manchester, CRC16 reflected 0xA001 as the public MP3-H1 / MRZ decoders describe; header and field offsets: this repo's).
+ * Frame: preamble/header AA BF 35 (24 bits, the sync window), 45 payload bytes MSB first, the last two = CRC16-MODBUS
+ * (init 0xFFFF, little-endian) of the first 43. */
+#define MRZ_FRAME_BYTES 45
+#define MRZ_SYNC_CHIPS  48
+#define MRZ_FRAME_CHIPS (MRZ_SYNC_CHIPS + 16 * MRZ_FRAME_BYTES)
+#define MRZ_SYNC_THR    4
+
+uint16_t or_crc16_modbus(const uint8_t *p, size_t n)
+{
+	uint16_t crc = 0xFFFF;
+	for (size_t i = 0; i < n; i++) {
+		crc ^= p[i];
+		for (int k = 0; k < 8; k++) crc = (crc & 1) ? (uint16_t)((crc >> 1) ^ 0xA001) : (uint16_t)(crc >> 1);
+	}
+	return crc;
+}
+
+static int mrzn1_run(OrFramerPub *f, const uint8_t *bits, uint64_t wpos)
+{
+	static const uint8_t hdr[3] = { 0xAA, 0xBF, 0x35 };
+	uint8_t sync[MRZ_SYNC_CHIPS];
+	for (int i = 0; i < 24; i++) {
+		const int b = (hdr[i >> 3] >> (7 - (i & 7))) & 1;
+		sync[2 * i] = (uint8_t)b;
+		sync[2 * i + 1] = (uint8_t)!b;          /* Manchester: 1 -> 10, 0 -> 01 */
+	}
+	int produced = 0;
+	while (next_fixed(f, bits, wpos, sync, MRZ_SYNC_CHIPS, MRZ_SYNC_THR, 1, MRZ_FRAME_CHIPS)) {
+		OrFrame *fr = push_frame(f);
+		fr->len = MRZ_FRAME_BYTES;
+		fr->flags = f->inv ? 1u : 0u;
+		fr->bitpos = f->fstart;
+		int viol = 0;
+		for (int i = 0; i < MRZ_FRAME_BYTES; i++) {
+			uint8_t v = 0;
+			for (int k = 0; k < 8; k++) {
+				const uint64_t p = f->fstart + MRZ_SYNC_CHIPS + 16 * (uint64_t)i + 2 * (uint64_t)k;
+				const int a = bits[p] ^ f->inv, b = bits[p + 1] ^ f->inv;
+				v = (uint8_t)((v << 1) | a);
+				viol += (a == b);
+			}
+			fr->data[i] = v;
+		}
+		const unsigned crc = or_crc16_modbus(fr->data, MRZ_FRAME_BYTES - 2);
+		fr->nerr[0] = (crc == ((unsigned)fr->data[43] | ((unsigned)fr->data[44] << 8))) ? 0 : -1;
+		fr->nerr[1] = viol;
+		produced++;
+		done_fixed(f, MRZ_FRAME_CHIPS);
+	}
+	return produced;
+}
+
 int or_framer_run_other(void *fp, const uint8_t *bits, uint64_t wpos)
 {
 	OrFramerPub *f = fp;
@@ -402,6 +456,7 @@ int or_framer_run_other(void *fp, const uint8_t *bits, uint64_t wpos)
 	case OR_M10:    return m10_run(f, bits, wpos);
 	case OR_IMS100: return ims100_run(f, bits, wpos);
 	case OR_IMET4:  return imet4_run(f, bits, wpos);
+	case OR_MRZN1:  return mrzn1_run(f, bits, wpos);
 	default: return 0;
 	}
 }

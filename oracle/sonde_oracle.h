@@ -107,6 +107,7 @@ void     or_rs255_encode(uint8_t *cw, int n);   /* fills cw[0..23] from cw[24..n
 uint16_t or_crc16_ccitt(const uint8_t *p, size_t n);
 uint16_t or_m10_checksum(const uint8_t *p, size_t n);
 uint16_t or_imet_crc(const uint8_t *p, size_t n);        /* CRC16-CCITT, init 0x1D0F */
+uint16_t or_crc16_modbus(const uint8_t *p, size_t n);   /* reflected 0xA001, init 0xFFFF (MRZ-N1) */
 uint32_t or_bch_parity(uint64_t data34);                 /* BCH(63,51) shortened to (46,34) */
 uint64_t or_bch_decode(uint64_t blk46, int *st);         /* st: errors corrected (0..2) or -1 */
 

@@ -107,4 +107,4 @@ SONDE_B1_DEF(IMS100Decoder, ims100, SONDE_IMS100, true)
 SONDE_B1_DEF(M10Decoder,    m10,    SONDE_M10,    true)
 SONDE_B1_DEF(IMET4Decoder,  imet4,  SONDE_IMET4,  true)    // Bell-202 AFSK: tone demodulator in front (SPEC 3.6)
 SONDE_B1_DEF(C50Decoder,    c50,    SONDE_C50,    false)
-SONDE_B1_DEF(MRZN1Decoder,  mrzn1,  SONDE_MRZN1,  false)
+SONDE_B1_DEF(MRZN1Decoder,  mrzn1,  SONDE_MRZN1,  true)

@@ -42,7 +42,7 @@ static const ModemDef k_modems[SONDE_NTYPES] = {
 	{ 9600.0, 0.65f, 1, 1 },   // M10    9600 chips/s Manchester: stays at 48 kS/s (5 samples per chip)
 	{ 1200.0, 0.65f, 1, 8 },   // iMet-1/4 Bell-202 AFSK 1200 Bd: tone demodulator, then 6 kS/s through the same loop
 	{ 2400.0, 0.65f, 2, 1 },   // SRS-C50 (AFSK, not implemented)
-	{ 2400.0, 0.65f, 2, 1 },   // MRZ-N1  (not implemented)
+	{ 4800.0, 0.65f, 2, 1 },   // MRZ-N1  2400 bit/s Manchester -> 4800 chips/s
 };
 
 static int modem_div(const ModemDef *md, int type) { return md[type].decim * md[type].pre; }     // input samples per internal sample
@@ -197,7 +197,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	b->ring_words = pow2ceil((uint32_t)((max_bits + 8 * SONDE_FRAME_MAX + 1024 + 31) / 32));
 	b->max_frames = 2;
 	{	// frames per submit per type: submit bits (at that type's fastest period) / shortest frame of the type, + carry-over
-		static const uint32_t min_frame_bits[SONDE_NTYPES] = { 320 * 8, 560, 1152, 1648, 140, 1u << 30, 1u << 30 };
+		static const uint32_t min_frame_bits[SONDE_NTYPES] = { 320 * 8, 560, 1152, 1648, 140, 1u << 30, 768 };
 		for (int t = 0; t < SONDE_NTYPES; t++) {
 			if (b->chlist[t].empty()) continue;
 			const int32_t p = modem_period0(md, t) - (modem_period0(md, t) >> 8);
@@ -427,7 +427,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		HIPCHK(hipGetLastError());
 		framer_launched = true;
 	}
-	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10 }) {
+	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10, SONDE_MRZN1 }) {
 		if (b->chlist[t].empty()) continue;
 		sd_launch_framer_other(t, (uint32_t)b->chlist[t].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
 			t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],

@@ -173,13 +173,14 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// K4: the sync search of the framed sondes runs in here, on round wave 3, over an LDS mirror of the newest ring words
 	// (RS41 always; DFM / iMS-100 / M10 unless the batch asked for the stand-alone framer kernels)
 	// Which sonde types an instantiation can meet follows from its decimation factor (batch.hip k_modems): 4 -> RS41;
-	// 2 -> DFM, iMS-100, RS41 in wide mode; 1 -> M10 (and the iMet 6 kS/s stream, which is framed elsewhere).  Testing DEC
+	// 2 -> DFM, iMS-100, MRZ-N1, RS41 in wide mode; 1 -> M10 (and the iMet 6 kS/s stream, which is framed elsewhere).  Testing DEC
 	// first lets the compiler drop the other types' code from each instantiation.
 	const int stype = __builtin_amdgcn_readfirstlane(st.type);
 	const bool is_rs41 = DEC != 1 && stype == SONDE_RS41, is_dfm = DEC == 2 && stype == SONDE_DFM09,
-	           is_ims = DEC == 2 && stype == SONDE_IMS100, is_m10 = DEC == 1 && stype == SONDE_M10;
+	           is_ims = DEC == 2 && stype == SONDE_IMS100, is_m10 = DEC == 1 && stype == SONDE_M10,
+	           is_mrz = DEC == 2 && stype == SONDE_MRZN1;
 	const bool fuse = fo->fuse_fec != 0;
-	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10));   // workgroup-uniform
+	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10 || is_mrz));   // workgroup-uniform
 	if (framing && tid >= SD_WGT - SD_MIRROR_WORDS) {
 		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WGT - 1 - tid);      // the words up to and including wpos's
 		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		else if (is_dfm) sd_fixed_sync_step<SONDE_DFM09>(s.k4, wp, s.mirror, lane, dch, mf);
 		else if (is_m10) sd_fixed_sync_step<SONDE_M10>(s.k4, wp, s.mirror, lane, dch, mf);
 		else if (is_ims) sd_fixed_sync_step<SONDE_IMS100>(s.k4, wp, s.mirror, lane, dch, mf);
+		else if (is_mrz) sd_fixed_sync_step<SONDE_MRZN1>(s.k4, wp, s.mirror, lane, dch, mf);
 	};
 	auto k4_finish = [&]() {       // K4's wave, after barrier E: catch up with the last rounds' bits, state and frame count back to HBM
 		k4_run(sd_uniform64(s.pub.wpos));

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(64) void sd_dec_fixed_kernel(
 	SondeFrame *fr = frames + (size_t)ch * max_frames + k;
 	if (T == SONDE_DFM09) sd_dfm_decode_frame<false>(s, ring, ring_words - 1, d, fr, ch, lane);
 	else if (T == SONDE_M10) sd_m10_decode_frame<false>(s, reinterpret_cast<const uint16_t *>(g64), ring, ring_words - 1, d, fr, ch, lane);
+	else if (T == SONDE_MRZN1) sd_mrz_decode_frame<false>(s, ring, ring_words - 1, d, fr, ch, lane);
 	else sd_ims_decode_frame<false>(s, g64, ring, ring_words - 1, d, fr, ch, lane);
 }
 
@@ -118,6 +119,7 @@ void sd_launch_framer_other(int type, uint32_t n_list, hipStream_t stream,
 		case SONDE_DFM09: hipLaunchKernelGGL(sd_dec_fixed_kernel<SONDE_DFM09>, g2, dim3(64), 0, stream, bitring, ring_words, g64, descs, counts, max_frames, frames, chlist); break;
 		case SONDE_M10: hipLaunchKernelGGL(sd_dec_fixed_kernel<SONDE_M10>, g2, dim3(64), 0, stream, bitring, ring_words, g64, descs, counts, max_frames, frames, chlist); break;
 		case SONDE_IMS100: hipLaunchKernelGGL(sd_dec_fixed_kernel<SONDE_IMS100>, g2, dim3(64), 0, stream, bitring, ring_words, g64, descs, counts, max_frames, frames, chlist); break;
+		case SONDE_MRZN1: hipLaunchKernelGGL(sd_dec_fixed_kernel<SONDE_MRZN1>, g2, dim3(64), 0, stream, bitring, ring_words, g64, descs, counts, max_frames, frames, chlist); break;
 		default: break;
 		}
 		return;
@@ -134,6 +136,10 @@ void sd_launch_framer_other(int type, uint32_t n_list, hipStream_t stream,
 	case SONDE_IMS100:
 		hipLaunchKernelGGL(sd_sync_fixed_kernel<SONDE_IMS100>, dim3(n_list), dim3(64), lds, stream, states, fstates, bitring, ring_words, descs, counts, max_frames, chlist);
 		hipLaunchKernelGGL(sd_dec_fixed_kernel<SONDE_IMS100>, g2, dim3(64), 0, stream, bitring, ring_words, g64, descs, counts, max_frames, frames, chlist);
+		break;
+	case SONDE_MRZN1:
+		hipLaunchKernelGGL(sd_sync_fixed_kernel<SONDE_MRZN1>, dim3(n_list), dim3(64), lds, stream, states, fstates, bitring, ring_words, descs, counts, max_frames, chlist);
+		hipLaunchKernelGGL(sd_dec_fixed_kernel<SONDE_MRZN1>, g2, dim3(64), 0, stream, bitring, ring_words, g64, descs, counts, max_frames, frames, chlist);
 		break;
 	default:
 		break;

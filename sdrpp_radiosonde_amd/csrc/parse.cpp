@@ -551,6 +551,57 @@ void SondeParser::feed_ims100(const SondeFrame &f, std::vector<SondeData> &out)
 	}
 }
 
+// MRZ-N1 (README.md:19: GPS + temperature).  45-byte frame behind the AA BF 35 header, little-endian fields
+// ([RECALL]: ECEF position/velocity, time of day + date, a rotating calibration/serial word and a CRC16 are what the
+// public MP3-H1 / MRZ decoders describe; the offsets are this repo's, the reference's layout is in the absent sondedump):
+//   0 frame counter u16 | 2 hh mm ss | 5 day month year-2000 | 8 X, 12 Y, 16 Z (i32, cm ECEF) | 20 vX, 22 vY, 24 vZ
+//   (i16, cm/s) | 26 satellites | 27 temperature (i16, 0.01 C) | 29 fragment index, 30 fragment word u32 (index 0: serial)
+//   | 34..42 spare | 43 CRC16 (reflected 0xA001, init 0xFFFF) of bytes 0..42
+void SondeParser::feed_mrzn1(const SondeFrame &f, std::vector<SondeData> &out)
+{
+	if (f.len != 45 || f.nerr[0] != 0) return;
+	const uint8_t *d = f.data;
+	SondeData sd;
+	memset(&sd, 0, sizeof(sd));
+	sd.fields = DATA_SEQ;
+	sd.seq = (int)rd_u16(d);
+	if (d[29] == 0) {
+		sd.fields |= DATA_SERIAL;
+		snprintf(sd.serial, sizeof(sd.serial), "MRZ-%u", (unsigned)rd_u32(d + 30));
+	}
+	out.push_back(sd);
+	if (d[6] >= 1 && d[6] <= 12 && d[5] >= 1 && d[5] <= 31 && d[2] < 24 && d[3] < 60 && d[4] < 61) {
+		memset(&sd, 0, sizeof(sd));
+		sd.fields = DATA_TIME;
+		sd.time = (time_t)(days_from_civil(2000 + d[7], d[6], d[5]) * 86400LL + d[2] * 3600LL + d[3] * 60LL + d[4]);
+		out.push_back(sd);
+	}
+	const double x = rd_i32(d + 8) / 100.0, y = rd_i32(d + 12) / 100.0, z = rd_i32(d + 16) / 100.0;
+	if (d[26] >= 4 && !(x == 0.0 && y == 0.0 && z == 0.0)) {
+		const double vx = rd_i16(d + 20) / 100.0, vy = rd_i16(d + 22) / 100.0, vz = rd_i16(d + 24) / 100.0;
+		double lat, lon, alt;
+		ecef_to_lla(x, y, z, &lat, &lon, &alt);
+		const double la = lat * M_PI / 180.0, lo = lon * M_PI / 180.0;
+		const double ve = -vx * sin(lo) + vy * cos(lo);
+		const double vn = -vx * sin(la) * cos(lo) - vy * sin(la) * sin(lo) + vz * cos(la);
+		const double vu = vx * cos(la) * cos(lo) + vy * cos(la) * sin(lo) + vz * sin(la);
+		double hdg = atan2(ve, vn) * 180.0 / M_PI;
+		if (hdg < 0.0) hdg += 360.0;
+		memset(&sd, 0, sizeof(sd));
+		sd.fields = DATA_POS | DATA_SPEED;
+		sd.lat = (float)lat; sd.lon = (float)lon; sd.alt = (float)alt;
+		sd.speed = (float)sqrt(ve * ve + vn * vn);
+		sd.heading = (float)hdg;
+		sd.climb = (float)vu;
+		out.push_back(sd);
+	}
+	memset(&sd, 0, sizeof(sd));
+	sd.fields = DATA_PTU;
+	sd.temp = (float)rd_i16(d + 27) * 0.01f;
+	sd.calib_percent = 100.0f;
+	out.push_back(sd);
+}
+
 void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
 {
 	switch (f.type) {
@@ -559,6 +610,7 @@ void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
 	case SONDE_M10: feed_m10(f, out); break;
 	case SONDE_IMET4: feed_imet(f, out); break;
 	case SONDE_IMS100: feed_ims100(f, out); break;
+	case SONDE_MRZN1: feed_mrzn1(f, out); break;
 	default: break;
 	}
 }

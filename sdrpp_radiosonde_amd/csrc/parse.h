@@ -16,6 +16,7 @@ private:
 	void feed_m10(const SondeFrame &f, std::vector<SondeData> &out);
 	void feed_imet(const SondeFrame &f, std::vector<SondeData> &out);
 	void feed_ims100(const SondeFrame &f, std::vector<SondeData> &out);
+	void feed_mrzn1(const SondeFrame &f, std::vector<SondeData> &out);
 	int m_type;
 	uint64_t m_calib_mask = 0;         // RS41: which of the 51 calibration fragments have been seen
 	uint8_t m_calib[51 * 16] = {};

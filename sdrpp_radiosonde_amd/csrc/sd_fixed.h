@@ -32,12 +32,23 @@ template <> struct SyncTraits<SONDE_IMS100> {
 	static constexpr int WIN = 48, THR = 2, FRAME_CHIPS = 2 * (24 + 12 * 46);
 };
 
+template <> struct SyncTraits<SONDE_MRZN1> {
+	// Manchester(AA BF 35), 48 chips, first chip in bit 0
+	static constexpr uint32_t SYNC_LO = 0x55599999u, SYNC_HI = 0x0000665Au;
+	static constexpr int WIN = 48, THR = 4, FRAME_CHIPS = 48 + 16 * 45;
+};
+
 template <int T>
 __device__ __forceinline__ bool sync_match(uint32_t w0, uint32_t w1, uint32_t w2, int sft, int &inv)
 {
 	typedef SyncTraits<T> Tr;
 	const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sft);
-	if (T == SONDE_IMS100) {
+	if (T == SONDE_MRZN1) {
+		const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sft);
+		const int c = __popc(lo ^ SyncTraits<SONDE_MRZN1>::SYNC_LO) + __popc((hi ^ SyncTraits<SONDE_MRZN1>::SYNC_HI) & 0xFFFFu);
+		inv = c >= 48 - Tr::THR;
+		return c <= Tr::THR || c >= 48 - Tr::THR;
+	} else if (T == SONDE_IMS100) {
 		const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sft);
 		// biphase-S: bit = 1 when both chips of the cell are equal
 		const uint32_t tl = ~(lo ^ (lo >> 1)), th = ~(hi ^ (hi >> 1));
@@ -46,7 +57,7 @@ __device__ __forceinline__ bool sync_match(uint32_t w0, uint32_t w1, uint32_t w2
 		inv = 0;
 		return hd <= Tr::THR;
 	} else {
-		const int c = __popc(lo ^ SyncTraits<T == SONDE_IMS100 ? SONDE_DFM09 : T>::SYNC);
+		const int c = __popc(lo ^ SyncTraits<(T == SONDE_IMS100 || T == SONDE_MRZN1) ? SONDE_DFM09 : T>::SYNC);
 		inv = c >= 32 - Tr::THR;
 		return c <= Tr::THR || c >= 32 - Tr::THR;
 	}
@@ -311,6 +322,51 @@ __device__ __forceinline__ void sd_ims_decode_frame(FixedLds &s, const uint8_t *
 				v |= bv << (8 * k);
 			}
 		}
+		reinterpret_cast<uint32_t *>(fr->data)[i] = v;
+	}
+	SD_FIX_SYNC();
+}
+
+// MRZ-N1: Manchester, 45 bytes MSB first behind the 48-chip header; CRC16 (reflected 0xA001, init 0xFFFF) of the first 43
+template <bool COHERENT>
+__device__ __forceinline__ void sd_mrz_decode_frame(FixedLds &s, const uint32_t *__restrict__ ring, uint32_t mask, const SdFrameDesc d,
+	SondeFrame *__restrict__ fr, uint32_t ch, int lane)
+{
+	sd_fixed_fetch<COHERENT>(s, ring, mask, d.fstart, SyncTraits<SONDE_MRZN1>::FRAME_CHIPS, lane);
+	int viol = 0;
+	if (lane < 45) {
+		const int c0 = 48 + 16 * lane;
+		const uint64_t pair = (uint64_t)s.words[c0 >> 5] | ((uint64_t)s.words[(c0 >> 5) + 1] << 32);
+		uint32_t x = (uint32_t)(pair >> (c0 & 31)) & 0xFFFFu;
+		if (d.inv) x ^= 0xFFFFu;
+		uint32_t v = 0;
+#pragma unroll
+		for (int b = 0; b < 8; b++) {
+			const uint32_t a = (x >> (2 * b)) & 1u, c = (x >> (2 * b + 1)) & 1u;
+			v = (v << 1) | a;
+			viol += (a == c);
+		}
+		s.bytes[lane] = (uint8_t)v;
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) viol += __shfl_xor(viol, off, 64);
+	if (lane >= 45) s.bytes[lane] = 0;
+	SD_FIX_SYNC();
+	if (lane == 0) {
+		unsigned crc = 0xFFFFu;
+		for (int i = 0; i < 43; i++) {
+			crc ^= s.bytes[i];
+#pragma unroll
+			for (int k = 0; k < 8; k++) crc = (crc & 1u) ? ((crc >> 1) ^ 0xA001u) : (crc >> 1);
+		}
+		fr->channel = ch; fr->type = SONDE_MRZN1; fr->len = 45;
+		fr->nerr[0] = (crc == ((unsigned)s.bytes[43] | ((unsigned)s.bytes[44] << 8))) ? 0 : -1;
+		fr->nerr[1] = viol;
+		fr->flags = d.inv ? 1u : 0u; fr->bitpos = d.fstart;
+	}
+	for (int i = lane; i < SONDE_FRAME_MAX / 4; i += 64) {
+		uint32_t v = 0;
+		if (4 * i < 48) v = (uint32_t)s.bytes[4 * i] | ((uint32_t)s.bytes[4 * i + 1] << 8) | ((uint32_t)s.bytes[4 * i + 2] << 16) | ((uint32_t)s.bytes[4 * i + 3] << 24);
 		reinterpret_cast<uint32_t *>(fr->data)[i] = v;
 	}
 	SD_FIX_SYNC();

@@ -681,6 +681,62 @@ def ims_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray):
     return data, bits
 
 
+# ---------------------------------------------------------------- MRZ-N1
+MRZ_HEADER = (0xAA, 0xBF, 0x35)
+MRZ_FRAME_BYTES = 45
+
+
+def crc16_modbus(data: np.ndarray) -> np.ndarray:
+    """[F, n] bytes -> [F] CRC16, reflected polynomial 0xA001, init 0xFFFF."""
+    data = np.asarray(data, dtype=np.uint32)
+    crc = np.full(data.shape[0], 0xFFFF, dtype=np.uint32)
+    for i in range(data.shape[1]):
+        crc ^= data[:, i]
+        for _ in range(8):
+            lsb = (crc & 1) != 0
+            crc >>= 1
+            crc = np.where(lsb, crc ^ 0xA001, crc)
+    return crc
+
+
+def mrz_true_temp(channel_ids, frame_idx):
+    return 11.0 - 0.02 * np.asarray(frame_idx, dtype=np.float64) - 0.01 * (np.asarray(channel_ids) % 40)
+
+
+def mrz_build_frames(seed: int, channel_ids: np.ndarray, frame_idx: np.ndarray) -> np.ndarray:
+    """MRZ-N1 payload frames [F, 45] (layout: parse.cpp feed_mrzn1), CRC included."""
+    ch = np.asarray(channel_ids, dtype=np.int64)
+    fi = np.asarray(frame_idx, dtype=np.int64)
+    F = ch.shape[0]
+    fr = np.zeros((F, MRZ_FRAME_BYTES), dtype=np.uint8)
+    g = np.random.Generator(np.random.Philox(key=(seed * 41 + 5) & 0xFFFFFFFFFFFFFFFF))
+    fr[:, 34:43] = g.integers(0, 256, size=(F, 9), dtype=np.uint8)
+    _put_le(fr, 0, fi & 0xFFFF, 2)
+    tod = (fi + 45296) % 86400                                              # 12:34:56 + k s
+    fr[:, 2], fr[:, 3], fr[:, 4] = tod // 3600, (tod // 60) % 60, tod % 60
+    fr[:, 5], fr[:, 6], fr[:, 7] = 15, 6, 24
+    lat = np.radians(47.0 + 1e-3 * ch)
+    lon = np.radians(8.0 + 1e-5 * fi)
+    alt = 1000.0 + 5.0 * fi
+    a, e2 = 6378137.0, 6.69437999014e-3
+    Nn = a / np.sqrt(1 - e2 * np.sin(lat) ** 2)
+    xyz = [(Nn + alt) * np.cos(lat) * np.cos(lon), (Nn + alt) * np.cos(lat) * np.sin(lon), (Nn * (1 - e2) + alt) * np.sin(lat)]
+    for k in range(3):
+        _put_le(fr, 8 + 4 * k, np.round(xyz[k] * 100).astype(np.int64) & 0xFFFFFFFF, 4)
+    up = np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)], axis=1)
+    east = np.stack([-np.sin(lon), np.cos(lon), np.zeros(F)], axis=1)
+    v = 5.0 * up + 12.0 * east
+    for k in range(3):
+        _put_le(fr, 20 + 2 * k, np.round(v[:, k] * 100).astype(np.int64) & 0xFFFF, 2)
+    fr[:, 26] = 9
+    _put_le(fr, 27, np.round(mrz_true_temp(ch, fi) * 100).astype(np.int64) & 0xFFFF, 2)
+    fr[:, 29] = fi % 4
+    _put_le(fr, 30, np.where(fi % 4 == 0, 7000000 + ch, 0x12345678 + fi), 4)
+    crc = crc16_modbus(fr[:, :43])
+    fr[:, 43], fr[:, 44] = crc & 0xFF, (crc >> 8) & 0xFF
+    return fr
+
+
 def biphase_s(bits: np.ndarray) -> np.ndarray:
     """[n] bits -> [2n] chips: transition at every bit boundary, extra mid-bit transition for a 0
     (so that a 1 reads as two equal chips).  Polarity-free by construction."""
@@ -696,7 +752,7 @@ def biphase_s(bits: np.ndarray) -> np.ndarray:
 
 
 # ---------------------------------------------------------------- chip streams + batches for any type
-SONDE_BAUD = {0: 4800.0, 1: 5000.0, 2: 4800.0, 3: 9600.0}     # on-air symbol (chip) rates
+SONDE_BAUD = {0: 4800.0, 1: 5000.0, 2: 4800.0, 3: 9600.0, 6: 4800.0}     # on-air symbol (chip) rates
 
 
 def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int, m20: bool = False):
@@ -714,6 +770,9 @@ def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int, 
     elif sonde_type == 2:    # iMS-100
         flen = 2 * (24 + IMS_NBLK * IMS_BLK_BITS)
         gap = 96
+    elif sonde_type == 6:    # MRZ-N1: one frame per second
+        flen = 48 + 16 * MRZ_FRAME_BYTES
+        gap = 4800 - flen
     else:
         raise ValueError("use rs41_bitstreams for RS41")
     stride = flen + gap
@@ -727,6 +786,10 @@ def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int, 
     elif sonde_type == 3:
         expect = (m20_build_frames if m20 else m10_build_frames)(seed, ch_rep, fi_rep)
         chips = np.concatenate([np.tile(M10_SYNC_CHIPS, (C * nfr, 1)), manchester(np.unpackbits(expect, axis=1))], axis=1)
+    elif sonde_type == 6:
+        expect = mrz_build_frames(seed, ch_rep, fi_rep)
+        hdr = np.tile(np.unpackbits(np.array(MRZ_HEADER, dtype=np.uint8)), (C * nfr, 1))
+        chips = manchester(np.concatenate([hdr, np.unpackbits(expect, axis=1)], axis=1))
     else:
         expect, bits = ims_build_frames(seed, ch_rep, fi_rep)
         chips = np.stack([biphase_s(b) for b in bits])
@@ -755,7 +818,8 @@ def chip_streams(sonde_type: int, seed: int, channels: np.ndarray, nchips: int, 
 def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
                device: str | torch.device = "cpu", first_channel: int = 0, invert: bool = False, m20: bool = False,
                **mod_kw) -> SynthBatch:
-    """Synthetic batch of any supported sonde type (0 RS41, 1 DFM09, 2 iMS-100, 3 M10 (m20=True: M20 frames), 4 iMet-4)."""
+    """Synthetic batch of any supported sonde type (0 RS41, 1 DFM09, 2 iMS-100, 3 M10 (m20=True: M20 frames), 4 iMet-4,
+    6 MRZ-N1)."""
     if sonde_type == 4:
         return make_imet_batch(n_channels, n_samples, seed=seed, snr_db=ebn0_db, device=device, first_channel=first_channel)
     if sonde_type == 0:

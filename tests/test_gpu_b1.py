@@ -177,3 +177,22 @@ def test_imet_xdata_b1(oracle):
     o3 = [f["o3_mpa"] for f in frags if f["fields"] & _lib.DATA_OZONE]
     assert len(o3) >= 2 and all(4.0 < v < 6.0 for v in o3)
     assert sum(1 for f in frags if f["fields"] & _lib.DATA_PTU) >= 2
+
+
+def test_mrzn1_b1_fields(oracle):
+    """mrzn1_decode (main.hpp:42; README.md:19: GPS + temperature)."""
+    n = 2048 * 120
+    sb = synth.make_batch(6, 1, n, seed=37, ebn0_db=26.0)
+    frags = _run_b1("mrzn1", _discriminate(oracle, sb.iq.numpy()[0]), 4096)
+    pos = [f for f in frags if f["fields"] & _lib.DATA_POS]
+    assert len(pos) >= 3
+    for p in pos:
+        assert abs(p["lat"] - 47.0) < 1e-3 and abs(p["lon"] - 8.0) < 1e-2 and 990.0 < p["alt"] < 1100.0
+        assert abs(p["climb"] - 5.0) < 0.02 and abs(p["speed"] - 12.0) < 0.02 and abs(p["heading"] - 90.0) < 0.2
+    seqs = [f["seq"] for f in frags if f["fields"] & _lib.DATA_SEQ]
+    assert seqs == list(range(seqs[0], seqs[0] + len(seqs)))
+    assert any(f["fields"] & _lib.DATA_SERIAL and f["serial"] == b"MRZ-7000000" for f in frags)
+    assert all(0.0 < f["temp"] < 12.0 for f in frags if f["fields"] & _lib.DATA_PTU)
+    import calendar
+    times = [f["time"] for f in frags if f["fields"] & _lib.DATA_TIME]
+    assert len(times) >= 3 and all(0 <= t - calendar.timegm((2024, 6, 15, 12, 34, 56)) < 200 for t in times)

@@ -182,3 +182,22 @@ def test_imet_xdata_ozone(lib, oracle):
         ref = O.or_ozone_mpa_d(round(float(cur) * 1000) / 1000, round(float(tp) * 100) / 100)
         assert len(fr) == 1 and fr[0].fields == _lib.DATA_OZONE and abs(fr[0].o3_mpa - ref) < 1e-4 * ref
     lib.sonde_parser_destroy(h)
+
+
+def test_mrzn1_fields(lib):
+    import calendar
+    nfr = 8
+    ch, fi = np.full(nfr, 12), np.arange(nfr)
+    fr = synth.mrz_build_frames(4, ch, fi)
+    h = lib.sonde_parser_create(6)
+    for k in range(nfr):
+        got = {d.fields: d for d in _feed(lib, h, 6, fr[k])}
+        seqf = _lib.DATA_SEQ | (_lib.DATA_SERIAL if k % 4 == 0 else 0)
+        assert got[seqf].seq == k and (k % 4 or got[seqf].serial == b"MRZ-7000012")
+        assert got[_lib.DATA_TIME].time == calendar.timegm((2024, 6, 15, 12, 34, 56)) + k
+        p = got[_lib.DATA_POS | _lib.DATA_SPEED]
+        assert abs(p.lat - 47.012) < 1e-5 and abs(p.lon - (8.0 + 1e-5 * k)) < 1e-5 and abs(p.alt - (1000 + 5 * k)) < 0.02
+        assert abs(p.speed - 12.0) < 0.01 and abs(p.heading - 90.0) < 0.05 and abs(p.climb - 5.0) < 0.01
+        assert abs(got[_lib.DATA_PTU].temp - synth.mrz_true_temp(ch, fi)[k]) < 0.006
+    assert _feed(lib, h, 6, fr[0], nerr=(-1, 0)) == []                # CRC failure: nothing
+    lib.sonde_parser_destroy(h)
