@@ -128,8 +128,8 @@ void sonde_batch_destroy(SondeBatch *b);
 /* Demodulate + frame + FEC n_samples more samples of every channel.
  * samples: DEVICE pointer, channel-major; channel c starts at element c*channel_stride
  * (elements = complex samples for IQ, floats for REAL).  n_samples % SONDE_TILE == 0.
- * stream: hipStream_t (NULL = default stream).  Asynchronous; frames of this submit replace the
- * previous submit's. */
+ * stream: hipStream_t (NULL = default stream).  Asynchronous.  Submits are ordered among themselves even across
+ * streams (per-channel state is carried).  The frames of a submit live until the submit after the next one starts. */
 int  sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream);
 /* Same, from HOST memory (staged through an internal pinned/device buffer; PCIe-inclusive). */
 int  sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride);
@@ -137,6 +137,14 @@ int  sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_sample
 long sonde_batch_sync(SondeBatch *b);
 /* Copy the last submit's frames to host memory, ordered by (channel, bitpos).  Returns count copied. */
 long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap);
+/* Pipelined hosts: frame slots exist twice, so the frames of submit t stay readable while submit t + 1 is queued or running.
+ * sonde_batch_ticket: the number of the last submit (1-based; 0 = none yet).  sonde_batch_frames_of waits for THAT submit only
+ * (not for the stream) and copies its frames; valid for the last two tickets, a negative error for older ones. */
+uint64_t sonde_batch_ticket(SondeBatch *b);
+long sonde_batch_frames_of(SondeBatch *b, uint64_t ticket, SondeFrame *out, size_t cap);
+/* Frames of the last submit that found no slot (more than the per-channel maximum, which is sized from max_samples and the
+ * shortest frame of the type, so this stays 0 unless the sizing rule is broken); they are dropped, never written out of bounds. */
+long sonde_batch_overflow(SondeBatch *b);
 /* The decoded telemetry of the last submit as SondeData fragments (what the reference's per-channel X_decode loops
  * would have returned, decoder.hpp:61), in (channel, time) order, with the channel each belongs to.  The engine keeps
  * one stateful parser per channel.  Call repeatedly until it returns 0; fragments not fetched before the next

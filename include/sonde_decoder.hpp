@@ -12,7 +12,9 @@
 // The aggregate has the members of SondeFullData (/root/reference/src/decode/common.hpp:4-28); unlike the
 // reference, calib_percent is initialised.
 #pragma once
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <ctime>
 #include <string>
 #include "sonde_abi.h"
@@ -165,6 +167,93 @@ private:
 	FullData *m_data = nullptr;
 	Callback m_cb = nullptr;
 	void *m_ctx = nullptr;
+};
+
+// B3 -- the module's IQ input as a stream pump: complex baseband in, FullData callback out.  This is the level
+// BASELINE.json's north_star names ("dsp::stream<dsp::complex_t> in, SondeData callback out"): in the reference the
+// VFO hands complex IQ to dsp::demod::FM, whose output goes through the resampler into the decoder block
+// (/root/reference/src/main.cpp:55-68); here FM discriminator, timing recovery, framing and FEC all run on the GPU, so
+// the host only forwards the VFO's samples.  The VFO must run at 48 kS/s (createVFO(..., bandwidth = bw,
+// sampleRate = 48000, ...)); buffers may have any length, samples are interleaved I, Q.
+class IqStreamDecoder {
+public:
+	typedef void (*Callback)(FullData *data, void *ctx);
+
+	IqStreamDecoder() = default;
+	IqStreamDecoder(const IqStreamDecoder &) = delete;
+	IqStreamDecoder &operator=(const IqStreamDecoder &) = delete;
+	~IqStreamDecoder() { deinit(); }
+
+	// sonde_type: SONDE_* (the index into supportedTypes[], main.hpp:44-52).  false: wrong rate or no GPU decoder.
+	bool init(int sonde_type, int samplerate, Callback cb, void *ctx, int device = 0, uint32_t flags = 0)
+	{
+		deinit();
+		if (samplerate != 48000) return false;
+		const uint8_t t = (uint8_t)sonde_type;
+		SondeBatchConfig cfg = {};
+		cfg.n_channels = 1;
+		cfg.types = &t;
+		cfg.max_samples = kMaxSamples;
+		cfg.input_kind = SONDE_INPUT_IQ;
+		cfg.device = device;
+		cfg.flags = flags;
+		if (sonde_batch_create(&cfg, &m_batch) != 0) return false;
+		m_granule = (sonde_type == SONDE_IMET4 || sonde_type == SONDE_C50) ? 8 * (size_t)SONDE_TILE : (size_t)SONDE_TILE;
+		m_cb = cb;
+		m_ctx = ctx;
+		m_data = FullData();
+		m_n = 0;
+		return true;
+	}
+
+	void deinit()
+	{
+		if (m_batch) sonde_batch_destroy(m_batch);
+		m_batch = nullptr;
+	}
+
+	// One stream buffer of `count` complex samples (what dsp::stream<dsp::complex_t>::read() handed out; dsp::complex_t
+	// is {float re, im}).  Returns the number of callbacks made, < 0 on error (text: sonde_last_error()).
+	int process(const float *iq, int count)
+	{
+		int fired = 0;
+		while (count > 0) {
+			const size_t take = std::min((size_t)count, (size_t)kMaxSamples - m_n);
+			std::memcpy(m_buf + 2 * m_n, iq, take * 2 * sizeof(float));
+			m_n += take;
+			iq += 2 * take;
+			count -= (int)take;
+			const size_t n = (m_n / m_granule) * m_granule;
+			if (n == 0) continue;
+			if (sonde_batch_submit_host(m_batch, m_buf, n, n) != 0) { m_n = 0; return -1; }
+			std::memmove(m_buf, m_buf + 2 * n, (m_n - n) * 2 * sizeof(float));
+			m_n -= n;
+			long k;
+			SondeData frag[32];
+			uint32_t chan[32];
+			while ((k = sonde_batch_poll(m_batch, frag, chan, 32)) > 0) {
+				for (long i = 0; i < k; i++) {
+					if (merge_fragment(m_data, frag[i])) {
+						if (m_cb) m_cb(&m_data, m_ctx);
+						fired++;
+					}
+				}
+			}
+			if (k < 0) return -1;
+		}
+		return fired;
+	}
+
+	const FullData &data() const { return m_data; }
+
+private:
+	static const uint32_t kMaxSamples = 16 * SONDE_TILE;
+	SondeBatch *m_batch = nullptr;
+	Callback m_cb = nullptr;
+	void *m_ctx = nullptr;
+	FullData m_data;
+	size_t m_granule = SONDE_TILE, m_n = 0;
+	float m_buf[2 * 16 * SONDE_TILE];
 };
 
 }  // namespace sonde

@@ -51,7 +51,7 @@ FLAG_SPLIT_FEC = 2
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them
 ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
-    "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_read_bits",
+    "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
     "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp", "sonde_rs41_pressure", "sonde_ozone_mpa",
     "sonde_m10_temp", "sonde_m10_rh", "sonde_m20_temp", "sonde_ims100_temp",
@@ -95,6 +95,13 @@ def load() -> C.CDLL:
     L.sonde_batch_sync.restype = C.c_long
     L.sonde_batch_frames.argtypes = [vp, vp, C.c_size_t]
     L.sonde_batch_frames.restype = C.c_long
+    if hasattr(L, "sonde_batch_frames_of"):
+        L.sonde_batch_frames_of.argtypes = [vp, C.c_uint64, vp, C.c_size_t]
+        L.sonde_batch_frames_of.restype = C.c_long
+        L.sonde_batch_ticket.argtypes = [vp]
+        L.sonde_batch_ticket.restype = C.c_uint64
+        L.sonde_batch_overflow.argtypes = [vp]
+        L.sonde_batch_overflow.restype = C.c_long
     L.sonde_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     if hasattr(L, "sonde_batch_set_timing"):          # absent only in older A/B builds loaded through SONDE_MI355_LIB
         L.sonde_batch_set_timing.argtypes = [vp, C.c_int]

@@ -96,6 +96,19 @@ class SondeBatch:
             out = out[:got]
         return out
 
+    def ticket(self) -> int:
+        """Number of the last submit (1-based)."""
+        return int(self.L.sonde_batch_ticket(self.h))
+
+    def frames_of(self, ticket: int) -> np.ndarray:
+        """Frames of submit `ticket` (one of the last two): waits for that submit only, not for later ones."""
+        out = np.zeros(self.n_channels * 64, dtype=FRAME_DTYPE)
+        got = self._chk(self.L.sonde_batch_frames_of(self.h, ticket, out.ctypes.data_as(C.c_void_p), len(out)))
+        return out[:got]
+
+    def overflow(self) -> int:
+        return self._chk(self.L.sonde_batch_overflow(self.h))
+
     def poll(self, cap: int = 4096):
         """SondeData fragments of the last submit with their channels: list of (channel, SondeData)."""
         out = (_lib.SondeData * cap)()

@@ -102,14 +102,18 @@ struct SondeBatch {
 	SdFramerState *d_fstates = nullptr;
 	float *d_hist = nullptr;
 	uint32_t *d_bitring = nullptr;
-	SondeFrame *d_frames = nullptr;
-	uint32_t *d_counts = nullptr;
+	// frame slots, per-channel frame counts and the demod kernel's framer descriptor exist TWICE: submit k writes set k & 1, so
+	// the frames of submit k stay readable while submit k + 1 is queued or running (sonde_batch_frames_of)
+	SondeFrame *d_frames2[2] = {};
+	uint32_t *d_counts2[2] = {};
+	hipEvent_t ev_done[2] = {};            // recorded behind the last kernel of each submit
+	uint64_t tickets = 0;                  // submits so far; submit number t (1-based) used set (t - 1) & 1
 	float *d_taps = nullptr;
 	SdModem *d_modems = nullptr;
 	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_g64 = nullptr;
 	uint16_t *d_m10tab = nullptr;          // Meteomodem checksum as a GF(2) matrix product: rows A^k B, sd_fixed.h
 	uint32_t fuse_fec = 1;                 // RS41 FEC in the demod kernel's epilogue (default) or as its own kernel (SONDE_FLAG_SPLIT_FEC)
-	SdFramerOut *d_fo = nullptr;           // where the demod kernel's in-kernel sync search keeps its state (device copy)
+	SdFramerOut *d_fo2[2] = {};            // where the demod kernel's in-kernel sync search keeps its state and lists frames (device copies)
 	uint32_t *d_gfswar = nullptr;          // byte-slice tables of the 24 syndrome multipliers alpha^(4j), framer_kernel.hip
 	void *d_descs = nullptr;
 	uint32_t *d_chlist[SONDE_NTYPES] = {};
@@ -136,10 +140,11 @@ struct SondeBatch {
 	unsigned long n_submits = 0;
 	bool ev_has_framer[kEvSlots] = {};
 	hipStream_t last_stream = nullptr;
-	bool pending = false, have_counts = false;
-	std::vector<uint32_t> h_counts;
+	bool pending = false;
+	bool have_counts2[2] = { false, false };
+	std::vector<uint32_t> h_counts2[2];
+	long n_frames2[2] = { 0, 0 }, n_overflow2[2] = { 0, 0 };
 	std::vector<SondeFrame> h_slots;
-	long n_frames = 0;
 	// sonde_batch_poll: per-channel parsers (created on first use), fragments waiting to be fetched
 	std::vector<std::unique_ptr<SondeParser>> parsers;
 	std::deque<std::pair<uint32_t, SondeData>> frags;
@@ -154,11 +159,12 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	(void)hipSetDevice(b->device);
 	if (b->pending) (void)hipStreamSynchronize(b->last_stream);
 	(void)hipFree(b->d_states); (void)hipFree(b->d_fstates); (void)hipFree(b->d_hist); (void)hipFree(b->d_bitring);
-	(void)hipFree(b->d_frames); (void)hipFree(b->d_counts); (void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
+	for (int k = 0; k < 2; k++) { (void)hipFree(b->d_frames2[k]); (void)hipFree(b->d_counts2[k]); (void)hipFree(b->d_fo2[k]); if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]); }
+	(void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
 	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
 	for (int k = 0; k < 3; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_fo); (void)hipFree(b->d_g64); (void)hipFree(b->d_m10tab); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
+	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_g64); (void)hipFree(b->d_m10tab); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	delete b;
@@ -215,14 +221,16 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_fstates, C * sizeof(SdFramerState));
 	ALLOC(b->d_hist, C * SD_HIST * sizeof(float));
 	ALLOC(b->d_bitring, C * (size_t)b->ring_words * sizeof(uint32_t));
-	ALLOC(b->d_frames, C * (size_t)b->max_frames * sizeof(SondeFrame));
-	ALLOC(b->d_counts, C * sizeof(uint32_t));
+	for (int k = 0; k < 2; k++) {
+		ALLOC(b->d_frames2[k], C * (size_t)b->max_frames * sizeof(SondeFrame));
+		ALLOC(b->d_counts2[k], C * sizeof(uint32_t));
+		ALLOC(b->d_fo2[k], sizeof(SdFramerOut));
+	}
 	ALLOC(b->d_taps, (size_t)SONDE_NTYPES * SD_NPHASE * SD_NTAPS * sizeof(float));
 	ALLOC(b->d_modems, SONDE_NTYPES * sizeof(SdModem));
 	ALLOC(b->d_gfexp, 2304);      // zero-absorbing antilog table of the RS decoder (GF_EXP2 in framer_kernel.hip)
 	ALLOC(b->d_gflog, 512);       // 256 x u16 logarithms, log 0 = 768
 	ALLOC(b->d_gfswar, 24 * 8 * sizeof(uint32_t));
-	ALLOC(b->d_fo, sizeof(SdFramerOut));
 	ALLOC(b->d_g64, 192);
 	ALLOC(b->d_m10tab, 99 * 8 * sizeof(uint16_t));
 	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
@@ -329,8 +337,11 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	}
 	{
 		b->fuse_fec = (cfg->flags & SONDE_FLAG_SPLIT_FEC) ? 0u : 1u;
-		const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts, b->max_frames, b->fuse_fec, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames };
-		CHK(hipMemcpy(b->d_fo, &fo, sizeof(fo), hipMemcpyHostToDevice));
+		for (int k = 0; k < 2; k++) {
+			const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts2[k], b->max_frames, b->fuse_fec, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames2[k] };
+			CHK(hipMemcpy(b->d_fo2[k], &fo, sizeof(fo), hipMemcpyHostToDevice));
+			CHK(hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming));
+		}
 	}
 	// initial channel state
 	std::vector<SdChanState> st(C);
@@ -346,7 +357,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	CHK(hipMemset(b->d_fstates, 0, C * sizeof(SdFramerState)));
 	CHK(hipMemset(b->d_hist, 0, C * SD_HIST * sizeof(float)));
 	CHK(hipMemset(b->d_bitring, 0, C * (size_t)b->ring_words * sizeof(uint32_t)));
-	CHK(hipMemset(b->d_counts, 0, C * sizeof(uint32_t)));
+	for (int k = 0; k < 2; k++) CHK(hipMemset(b->d_counts2[k], 0, C * sizeof(uint32_t)));
 	if (n_afsk) {
 		float wtab[2 * SD_AF_PER];
 		sonde_get_afsk_table(wtab);
@@ -367,7 +378,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		}
 	}
 #undef CHK
-	b->h_counts.assign(C, 0);
+	for (int k = 0; k < 2; k++) b->h_counts2[k].assign(C, 0);
 	*out = b;
 	return 0;
 }
@@ -389,7 +400,12 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	if (timed) HIPCHK(hipEventRecord(ev[0], stream));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
 	const bool iq = b->input_kind == SONDE_INPUT_IQ;
-	const SdFramerOut *fo = b->d_fo;    // RS41 channels: the demod kernel runs the sync search itself and lists complete frames there
+	const int slot = (int)(b->tickets & 1);
+	SondeFrame *const d_frames = b->d_frames2[slot];
+	uint32_t *const d_counts = b->d_counts2[slot];
+	const SdFramerOut *fo = b->d_fo2[slot];    // the demod kernel runs the sync search itself and lists complete frames there
+	// consecutive submits share the per-channel state: a submit on another stream waits for the previous one
+	if (b->tickets && stream != b->last_stream) HIPCHK(hipStreamWaitEvent(stream, b->ev_done[(b->tickets - 1) & 1], 0));
 	if (!n_afsk && b->n_classes == 1) {
 		sd_launch_demod(iq, b->only_class, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo);
@@ -423,21 +439,21 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	if (!b->chlist[SONDE_RS41].empty() && !b->fuse_fec) {
 		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
 			b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_descs,
-			b->d_frames, b->d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);
+			d_frames, d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);
 		HIPCHK(hipGetLastError());
 		framer_launched = true;
 	}
 	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10, SONDE_MRZN1 }) {
 		if (b->chlist[t].empty()) continue;
 		sd_launch_framer_other(t, (uint32_t)b->chlist[t].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-			t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, b->d_frames, b->d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],
+			t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, d_frames, d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],
 			/* with_sync = */ !b->fuse_fec);        // default: the demod kernel has run the sync search (K4) itself
 		HIPCHK(hipGetLastError());
 		framer_launched = true;
 	}
 	if (n_afsk) {
 		sd_launch_framer_imet((uint32_t)n_afsk, stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-			b->d_frames, b->d_counts, b->max_frames, b->d_chlist[SONDE_IMET4]);
+			d_frames, d_counts, b->max_frames, b->d_chlist[SONDE_IMET4]);
 		HIPCHK(hipGetLastError());
 		framer_launched = true;
 	}
@@ -446,9 +462,11 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		b->ev_has_framer[b->ev_used % SondeBatch::kEvSlots] = framer_launched;
 		b->ev_used++;
 	}
+	HIPCHK(hipEventRecord(b->ev_done[slot], stream));
+	b->tickets++;
 	b->last_stream = stream;
 	b->pending = true;
-	b->have_counts = false;
+	b->have_counts2[slot] = false;
 	b->polled = false;
 	return 0;
 }
@@ -472,41 +490,67 @@ extern "C" int sonde_batch_submit_host(SondeBatch *b, const void *samples, size_
 	return sonde_batch_submit(b, b->d_stage, n_samples, n_samples, nullptr);
 }
 
+// wait for submit number `ticket` (1-based) and read its per-channel frame counts; -1 if its slot set has been reused
+static long sync_ticket(SondeBatch *b, uint64_t ticket)
+{
+	if (ticket == 0 || ticket > b->tickets) return fail("sonde_batch: no such submit");
+	if (b->tickets - ticket >= 2) return fail("sonde_batch: the frames of that submit have been overwritten (two newer submits)");
+	if (hipSetDevice(b->device) != hipSuccess) return fail("hipSetDevice");
+	const int slot = (int)((ticket - 1) & 1);
+	if (!b->have_counts2[slot]) {
+		hipError_t e = hipEventSynchronize(b->ev_done[slot]);
+		if (e != hipSuccess) return fail("hipEventSynchronize", e);
+		if (ticket == b->tickets) b->pending = false;
+		e = hipMemcpy(b->h_counts2[slot].data(), b->d_counts2[slot], b->n_channels * sizeof(uint32_t), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return fail("hipMemcpy counts", e);
+		long n = 0, over = 0;
+		for (uint32_t c = 0; c < b->n_channels; c++) {
+			n += std::min(b->h_counts2[slot][c], b->max_frames);
+			if (b->h_counts2[slot][c] > b->max_frames) over += b->h_counts2[slot][c] - b->max_frames;
+		}
+		b->n_frames2[slot] = n;
+		b->n_overflow2[slot] = over;
+		b->have_counts2[slot] = true;
+	}
+	return b->n_frames2[slot];
+}
+
 extern "C" long sonde_batch_sync(SondeBatch *b)
 {
 	if (!b) return fail("sonde_batch_sync: null argument");
-	if (hipSetDevice(b->device) != hipSuccess) return fail("hipSetDevice");
-	if (b->pending) {
-		hipError_t e = hipStreamSynchronize(b->last_stream);
-		if (e != hipSuccess) return fail("hipStreamSynchronize", e);
-		b->pending = false;
-	}
-	if (!b->have_counts) {
-		hipError_t e = hipMemcpy(b->h_counts.data(), b->d_counts, b->n_channels * sizeof(uint32_t), hipMemcpyDeviceToHost);
-		if (e != hipSuccess) return fail("hipMemcpy counts", e);
-		long n = 0;
-		for (uint32_t c = 0; c < b->n_channels; c++) n += std::min(b->h_counts[c], b->max_frames);
-		b->n_frames = n;
-		b->have_counts = true;
-	}
-	return b->n_frames;
+	if (b->tickets == 0) return 0;
+	return sync_ticket(b, b->tickets);
 }
 
-extern "C" long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap)
+extern "C" uint64_t sonde_batch_ticket(SondeBatch *b) { return b ? b->tickets : 0; }
+
+extern "C" long sonde_batch_overflow(SondeBatch *b)
 {
-	const long n = sonde_batch_sync(b);
+	if (!b) return fail("sonde_batch_overflow: null argument");
+	if (b->tickets == 0) return 0;
+	if (sync_ticket(b, b->tickets) < 0) return -1;
+	return b->n_overflow2[(b->tickets - 1) & 1];
+}
+
+extern "C" long sonde_batch_frames_of(SondeBatch *b, uint64_t ticket, SondeFrame *out, size_t cap)
+{
+	if (!b) return fail("sonde_batch_frames_of: null argument");
+	const long n = sync_ticket(b, ticket);
 	if (n < 0) return n;
 	if (n == 0 || !out || cap == 0) return 0;
+	const int slot = (int)((ticket - 1) & 1);
+	const std::vector<uint32_t> &h_counts = b->h_counts2[slot];
+	const SondeFrame *d_frames = b->d_frames2[slot];
 	// frames sit in per-channel slot groups (ordered by channel, then time): one bulk copy of the slot
 	// array when it is small, else one copy per channel that has frames
 	size_t k = 0;
 	const size_t all = (size_t)b->n_channels * b->max_frames;
 	if (all * sizeof(SondeFrame) <= (64u << 20)) {
 		b->h_slots.resize(all);
-		hipError_t e = hipMemcpy(b->h_slots.data(), b->d_frames, all * sizeof(SondeFrame), hipMemcpyDeviceToHost);
+		hipError_t e = hipMemcpy(b->h_slots.data(), d_frames, all * sizeof(SondeFrame), hipMemcpyDeviceToHost);
 		if (e != hipSuccess) return fail("hipMemcpy frames", e);
 		for (uint32_t c = 0; c < b->n_channels && k < cap; c++) {
-			const uint32_t cnt = std::min(b->h_counts[c], b->max_frames);
+			const uint32_t cnt = std::min(h_counts[c], b->max_frames);
 			const size_t take = std::min((size_t)cnt, cap - k);
 			if (take) memcpy(out + k, b->h_slots.data() + (size_t)c * b->max_frames, take * sizeof(SondeFrame));
 			k += take;
@@ -514,14 +558,21 @@ extern "C" long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap)
 		return (long)k;
 	}
 	for (uint32_t c = 0; c < b->n_channels && k < cap; c++) {
-		const uint32_t cnt = std::min(b->h_counts[c], b->max_frames);
+		const uint32_t cnt = std::min(h_counts[c], b->max_frames);
 		if (!cnt) continue;
 		const size_t take = std::min((size_t)cnt, cap - k);
-		hipError_t e = hipMemcpy(out + k, b->d_frames + (size_t)c * b->max_frames, take * sizeof(SondeFrame), hipMemcpyDeviceToHost);
+		hipError_t e = hipMemcpy(out + k, d_frames + (size_t)c * b->max_frames, take * sizeof(SondeFrame), hipMemcpyDeviceToHost);
 		if (e != hipSuccess) return fail("hipMemcpy frames", e);
 		k += take;
 	}
 	return (long)k;
+}
+
+extern "C" long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap)
+{
+	if (!b) return fail("sonde_batch_frames: null argument");
+	if (b->tickets == 0) return 0;
+	return sonde_batch_frames_of(b, b->tickets, out, cap);
 }
 
 extern "C" long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t cap)

@@ -1,0 +1,38 @@
+// iq_stream_test.cpp -- drives sonde::IqStreamDecoder (B3: complex IQ stream in, FullData callback out) on a GPU:
+//   iq_stream_test <iq.bin> <sonde_type> <chunk>      iq.bin: float32 [n][2] at 48 kS/s; fed in buffers of <chunk> samples
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "sonde_decoder.hpp"
+
+static void on_data(sonde::FullData *d, void *ctx)
+{
+	(*(long *)ctx)++;
+	printf("CB seq=%d serial=%s lat=%.5f lon=%.5f alt=%.1f spd=%.2f temp=%.2f rh=%.2f pressure=%a time=%ld\n", d->seq, d->serial.c_str(),
+	       (double)d->lat, (double)d->lon, (double)d->alt, (double)d->spd, (double)d->temp, (double)d->rh, (double)d->pressure, (long)d->time);
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 4) return 2;
+	std::vector<float> x;
+	FILE *f = fopen(argv[1], "rb");
+	if (!f) return 3;
+	float tmp[4096];
+	size_t n;
+	while ((n = fread(tmp, sizeof(float), 4096, f)) > 0) x.insert(x.end(), tmp, tmp + n);
+	fclose(f);
+	const int chunk = atoi(argv[3]);
+	long calls = 0;
+	sonde::IqStreamDecoder dec;
+	if (dec.init(0, 44100, on_data, &calls)) { printf("ERROR accepted 44100\n"); return 1; }
+	if (!dec.init(atoi(argv[2]), 48000, on_data, &calls)) { printf("ERROR init: %s\n", sonde_last_error()); return 1; }
+	long fired = 0;
+	for (size_t off = 0; off < x.size() / 2; off += (size_t)chunk) {
+		const int k = dec.process(x.data() + 2 * off, (int)std::min((size_t)chunk, x.size() / 2 - off));
+		if (k < 0) { printf("ERROR process: %s\n", sonde_last_error()); return 1; }
+		fired += k;
+	}
+	printf("DONE fired=%ld calls=%ld seq=%d\n", fired, calls, dec.data().seq);
+	return 0;
+}

@@ -196,3 +196,39 @@ def test_mrzn1_b1_fields(oracle):
     import calendar
     times = [f["time"] for f in frags if f["fields"] & _lib.DATA_TIME]
     assert len(times) >= 3 and all(0 <= t - calendar.timegm((2024, 6, 15, 12, 34, 56)) < 200 for t in times)
+
+
+@pytest.mark.parametrize("chunk", [4800, 1000])
+def test_b3_iq_stream_decoder_cpp(tmp_path, oracle, chunk):
+    """sonde::IqStreamDecoder (B3, `dsp::stream<dsp::complex_t>` in): complex IQ at 48 kS/s in arbitrary buffer sizes ->
+    the same frames the batch API decodes from the same samples -> merged FullData callbacks."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "iq_stream_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "iq_stream_test.cpp"), "-o", exe,
+                           "-L", libdir, "-l:libsonde_mi355.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    n = 2048 * 96
+    sb = synth.make_rs41_batch(1, n, seed=77, ebn0_db=25.0)
+    path = str(tmp_path / "iq.bin")
+    sb.iq.numpy()[0].tofile(path)
+    out = subprocess.check_output([exe, path, "0", str(chunk)], text=True)
+    assert "ERROR" not in out, out[-1500:]
+    cbs = [l for l in out.splitlines() if l.startswith("CB ")]
+    # reference: the oracle's frames of the same IQ through the stateful parser: one callback per fragment with fields
+    ch = oracle.Channel(0, 0)
+    ch.feed(sb.iq.numpy()[0])
+    L = _lib.load()
+    h = L.sonde_parser_create(0)
+    o = (_lib.SondeData * 8)()
+    nfrag = 0
+    for f in ch.frames():
+        fr = _lib.SondeFrame.from_buffer_copy(f.tobytes())
+        nfrag += L.sonde_parser_feed(h, C.byref(fr), o, 8)
+    L.sonde_parser_destroy(h)
+    assert len(cbs) == nfrag >= 12
+    assert re.search(r"serial=(\S+)", cbs[-1]).group(1) == "S0000000"
+    assert abs(float(re.search(r"lat=(\S+)", cbs[-1]).group(1)) - 47.0) < 0.01

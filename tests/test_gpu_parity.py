@@ -286,3 +286,37 @@ def test_split_fec_kernel_equals_fused_epilogue(oracle):
     assert len(ref) >= 3 * C and (ref["nerr"] > 0).any()
     assert key(outs[0]).tobytes() == key(ref).tobytes()
     assert key(outs[1]).tobytes() == key(ref).tobytes()
+
+
+def test_pipelined_submits_tickets_and_stream_changes(oracle):
+    """A real-time host queues submit t + 1 before it fetches the frames of submit t (frame slots exist twice), and may
+    alternate HIP streams: the library orders the submits itself.  Frames per ticket == the sequential run's."""
+    from sdrpp_radiosonde_amd.batch import SondeError
+    C, n, parts = 6, TILE * 72, 3
+    sb = synth.make_rs41_batch(C, n, seed=23, ebn0_db=18.0)
+    iq = _dev(sb.iq)
+    chunks = [iq[:, p * (n // parts): (p + 1) * (n // parts)].contiguous() for p in range(parts)]
+    seq = SondeBatch(C, n // parts)
+    want = []
+    for ch in chunks:
+        seq.submit(ch)
+        want.append(seq.frames())
+    assert sum(len(w) for w in want) >= 2 * C and seq.overflow() == 0
+    pipe = SondeBatch(C, n // parts)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    pipe.submit(chunks[0], s1.cuda_stream)
+    t0 = pipe.ticket()
+    pipe.submit(chunks[1], s2.cuda_stream)              # queued before anything of submit 1 was fetched, on another stream
+    t1 = pipe.ticket()
+    assert (t0, t1) == (1, 2)
+    assert pipe.frames_of(t0).tobytes() == want[0].tobytes()
+    pipe.submit(chunks[2], s1.cuda_stream)
+    assert pipe.frames_of(t1).tobytes() == want[1].tobytes()
+    assert pipe.frames().tobytes() == want[2].tobytes()
+    with pytest.raises(SondeError):
+        pipe.frames_of(t0)                              # two newer submits: its slot set has been reused
+    ref = np.concatenate([ch.frames() for ch in _oracle_channels(oracle, sb.iq.numpy())])
+    got = np.concatenate(want)
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    assert key(got).tobytes() == key(ref).tobytes()
