@@ -139,7 +139,9 @@ long sonde_batch_sync(SondeBatch *b);
 long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap);
 /* Pipelined hosts: frame slots exist twice, so the frames of submit t stay readable while submit t + 1 is queued or running.
  * sonde_batch_ticket: the number of the last submit (1-based; 0 = none yet).  sonde_batch_frames_of waits for THAT submit only
- * (not for the stream) and copies its frames; valid for the last two tickets, a negative error for older ones. */
+ * (not for the stream) and copies its frames; valid for the last two tickets, a negative error for older ones.  Per-submit
+ * completion events (a few microseconds of command-stream bubble each) are recorded from the first sonde_batch_ticket call on;
+ * a submit queued before that call is waited for through its stream. */
 uint64_t sonde_batch_ticket(SondeBatch *b);
 long sonde_batch_frames_of(SondeBatch *b, uint64_t ticket, SondeFrame *out, size_t cap);
 /* Frames of the last submit that found no slot (more than the per-channel maximum, which is sized from max_samples and the

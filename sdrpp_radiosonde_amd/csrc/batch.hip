@@ -106,7 +106,10 @@ struct SondeBatch {
 	// the frames of submit k stay readable while submit k + 1 is queued or running (sonde_batch_frames_of)
 	SondeFrame *d_frames2[2] = {};
 	uint32_t *d_counts2[2] = {};
-	hipEvent_t ev_done[2] = {};            // recorded behind the last kernel of each submit
+	hipEvent_t ev_done[2] = {};            // recorded behind the last kernel of each submit once the host works with tickets
+	bool ev_valid[2] = { false, false };   // (an event record is a bubble in the command stream: not paid by hosts that sync every submit)
+	bool ticketing = false;
+	hipEvent_t ev_xs = nullptr;            // orders a submit behind the previous one when the host changes streams
 	uint64_t tickets = 0;                  // submits so far; submit number t (1-based) used set (t - 1) & 1
 	float *d_taps = nullptr;
 	SdModem *d_modems = nullptr;
@@ -160,6 +163,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	if (b->pending) (void)hipStreamSynchronize(b->last_stream);
 	(void)hipFree(b->d_states); (void)hipFree(b->d_fstates); (void)hipFree(b->d_hist); (void)hipFree(b->d_bitring);
 	for (int k = 0; k < 2; k++) { (void)hipFree(b->d_frames2[k]); (void)hipFree(b->d_counts2[k]); (void)hipFree(b->d_fo2[k]); if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]); }
+	if (b->ev_xs) (void)hipEventDestroy(b->ev_xs);
 	(void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
 	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
 	for (int k = 0; k < 3; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
@@ -342,6 +346,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			CHK(hipMemcpy(b->d_fo2[k], &fo, sizeof(fo), hipMemcpyHostToDevice));
 			CHK(hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming));
 		}
+		CHK(hipEventCreateWithFlags(&b->ev_xs, hipEventDisableTiming));
 	}
 	// initial channel state
 	std::vector<SdChanState> st(C);
@@ -405,7 +410,10 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	uint32_t *const d_counts = b->d_counts2[slot];
 	const SdFramerOut *fo = b->d_fo2[slot];    // the demod kernel runs the sync search itself and lists complete frames there
 	// consecutive submits share the per-channel state: a submit on another stream waits for the previous one
-	if (b->tickets && stream != b->last_stream) HIPCHK(hipStreamWaitEvent(stream, b->ev_done[(b->tickets - 1) & 1], 0));
+	if (b->tickets && stream != b->last_stream) {
+		HIPCHK(hipEventRecord(b->ev_xs, b->last_stream));
+		HIPCHK(hipStreamWaitEvent(stream, b->ev_xs, 0));
+	}
 	if (!n_afsk && b->n_classes == 1) {
 		sd_launch_demod(iq, b->only_class, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo);
@@ -462,7 +470,8 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		b->ev_has_framer[b->ev_used % SondeBatch::kEvSlots] = framer_launched;
 		b->ev_used++;
 	}
-	HIPCHK(hipEventRecord(b->ev_done[slot], stream));
+	b->ev_valid[slot] = b->ticketing;
+	if (b->ticketing) HIPCHK(hipEventRecord(b->ev_done[slot], stream));
 	b->tickets++;
 	b->last_stream = stream;
 	b->pending = true;
@@ -498,9 +507,10 @@ static long sync_ticket(SondeBatch *b, uint64_t ticket)
 	if (hipSetDevice(b->device) != hipSuccess) return fail("hipSetDevice");
 	const int slot = (int)((ticket - 1) & 1);
 	if (!b->have_counts2[slot]) {
-		hipError_t e = hipEventSynchronize(b->ev_done[slot]);
+		// with an event: wait for that submit only; without (the host did not ask for tickets before it): for the stream
+		hipError_t e = b->ev_valid[slot] ? hipEventSynchronize(b->ev_done[slot]) : hipStreamSynchronize(b->last_stream);
 		if (e != hipSuccess) return fail("hipEventSynchronize", e);
-		if (ticket == b->tickets) b->pending = false;
+		if (ticket == b->tickets || !b->ev_valid[slot]) b->pending = false;
 		e = hipMemcpy(b->h_counts2[slot].data(), b->d_counts2[slot], b->n_channels * sizeof(uint32_t), hipMemcpyDeviceToHost);
 		if (e != hipSuccess) return fail("hipMemcpy counts", e);
 		long n = 0, over = 0;
@@ -522,7 +532,12 @@ extern "C" long sonde_batch_sync(SondeBatch *b)
 	return sync_ticket(b, b->tickets);
 }
 
-extern "C" uint64_t sonde_batch_ticket(SondeBatch *b) { return b ? b->tickets : 0; }
+extern "C" uint64_t sonde_batch_ticket(SondeBatch *b)
+{
+	if (!b) return 0;
+	b->ticketing = true;        // from the next submit on, every submit records its own completion event
+	return b->tickets;
+}
 
 extern "C" long sonde_batch_overflow(SondeBatch *b)
 {
