@@ -79,7 +79,7 @@ SONDE_B1_DECL(DFM09Decoder,  dfm09)   /* main.hpp:37 */
 SONDE_B1_DECL(IMS100Decoder, ims100)  /* main.hpp:38 */
 SONDE_B1_DECL(M10Decoder,    m10)     /* main.hpp:39 */
 SONDE_B1_DECL(IMET4Decoder,  imet4)   /* main.hpp:40 */
-SONDE_B1_DECL(C50Decoder,    c50)     /* main.hpp:41 -- not implemented: init succeeds, decode always answers PROCEED */
+SONDE_B1_DECL(C50Decoder,    c50)     /* main.hpp:41 */
 SONDE_B1_DECL(MRZN1Decoder,  mrzn1)   /* main.hpp:42 */
 
 /* ------------------------------------------------------------------ B0: batch API */

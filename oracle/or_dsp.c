@@ -103,7 +103,7 @@ static OrModem g_modems[OR_NTYPES] = {
 	{ OR_IMS100, 4800.0, 0, 0.65f, 2, 1 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
 	{ OR_M10,    9600.0, 0, 0.65f, 1, 1 },  /* M10/M20: 9600 chips/s Manchester: stays at 48 kS/s (5 samples/chip) */
 	{ OR_IMET4,  1200.0, 0, 0.65f, 1, 8 },  /* iMet-1/4: Bell-202 AFSK 1200 Bd; tone demodulator in front, 6 kS/s behind it */
-	{ OR_C50,    2400.0, 0, 0.65f, 2, 1 },  /* placeholder */
+	{ OR_C50,    2400.0, 0, 0.65f, 1, 8 },  /* SRS-C50: AFSK 2400 Bd (2900 / 4700 Hz); tone demodulator in front, 6 kS/s behind it */
 	{ OR_MRZN1,  4800.0, 0, 0.65f, 2, 1 },  /* MRZ-N1: 2400 bit/s Manchester => 4800 chips/s */
 };
 static OrModem g_modem_rt[OR_NTYPES];
@@ -290,25 +290,48 @@ void or_afsk_table(float *w)
 	}
 }
 
+/* SRS-C50: tones 2900 / 4700 Hz at 2400 Bd: mixer at 3800 Hz (19 cycles in 240 samples), boxcar over the last two
+ * 8-sample blocks (a symbol is 20 samples), the rest as for iMet.  [RECALL: public C34/C50 decoder notes.] */
+#define OR_C50_PER 240
+#define OR_C50_WIN 2
+static void mixer_table(float *w, int cycles, int per)
+{
+	for (int k = 0; k < per; k++) {
+		const double a = 2.0 * OR_PI_D * (double)cycles * (double)k / (double)per;
+		w[2 * k] = (float)cos(a);
+		w[2 * k + 1] = (float)(-sin(a));
+	}
+}
+
 /* n_in input samples (a multiple of 8) -> n_in/8 samples of q */
 static void afsk_front(OrDemod *d, const float *src, size_t n_in, int is_iq, float *q)
 {
-	static float W[2 * OR_AF_PER];
+	static float W17[2 * OR_AF_PER], W19[2 * OR_C50_PER];
 	static int have;
-	if (!have) { or_afsk_table(W); have = 1; }
+	if (!have) { or_afsk_table(W17); mixer_table(W19, 19, OR_C50_PER); have = 1; }
+	const int c50 = d->m->type == OR_C50;
+	const float *W = c50 ? W19 : W17;
+	const unsigned per = c50 ? OR_C50_PER : OR_AF_PER;
+	const int win = c50 ? OR_C50_WIN : OR_AF_WIN;
 	for (size_t m = 0; m < n_in / OR_AF_DEC; m++) {
 		float dv[OR_AF_DEC];
 		if (is_iq) or_discriminate(src + 2 * OR_AF_DEC * m, OR_AF_DEC, dv, d->iq_last);
 		else memcpy(dv, src + OR_AF_DEC * m, sizeof(dv));
 		float br = 0.0f, bi = 0.0f;
 		for (int i = 0; i < OR_AF_DEC; i++) {
-			const unsigned k = (unsigned)((d->af_n + OR_AF_DEC * m + (size_t)i) % OR_AF_PER);
+			const unsigned k = (unsigned)((d->af_n + OR_AF_DEC * m + (size_t)i) % per);
 			br = fmaf(dv[i], W[2 * k], br);
 			bi = fmaf(dv[i], W[2 * k + 1], bi);
 		}
-		/* boxcar over the last five block sums, oldest first */
-		const float zr = (((d->af_b[0][0] + d->af_b[1][0]) + d->af_b[2][0]) + d->af_b[3][0]) + br;
-		const float zi = (((d->af_b[0][1] + d->af_b[1][1]) + d->af_b[2][1]) + d->af_b[3][1]) + bi;
+		/* boxcar over the last `win` block sums (the current one included), oldest first */
+		float zr, zi;
+		if (win == OR_AF_WIN) {
+			zr = (((d->af_b[0][0] + d->af_b[1][0]) + d->af_b[2][0]) + d->af_b[3][0]) + br;
+			zi = (((d->af_b[0][1] + d->af_b[1][1]) + d->af_b[2][1]) + d->af_b[3][1]) + bi;
+		} else {
+			zr = d->af_b[3][0] + br;
+			zi = d->af_b[3][1] + bi;
+		}
 		for (int h = 0; h < OR_AF_WIN - 2; h++) { d->af_b[h][0] = d->af_b[h + 1][0]; d->af_b[h][1] = d->af_b[h + 1][1]; }
 		d->af_b[OR_AF_WIN - 2][0] = br;
 		d->af_b[OR_AF_WIN - 2][1] = bi;

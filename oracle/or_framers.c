@@ -448,6 +448,42 @@ static int mrzn1_run(OrFramerPub *f, const uint8_t *bits, uint64_t wpos)
 	return produced;
 }
 
+/* ------------------------------------------------------------------ SRS-C50 (SPEC 3.3e)
+ * 8N1 characters at 2400 Bd, LSB first, idle = mark = 1.  Packet: 00 FF <type> <4 value bytes, big-endian> <c1> <c2>,
+ * c1 = sum of type and value bytes mod 256, c2 = sum of the running c1 values mod 256.  [RECALL: public C34/C50 notes.]
+ * Sync = the 21 bits  1 | 0 00000000 1 | 0 11111111 1, exact match in either polarity; candidates with a wrong start or
+ * stop bit are dropped (search resumes one bit later); checksum failures are recorded, not dropped. */
+#define C50_LEN 9
+static int c50_run(OrFramerPub *f, const uint8_t *bits, uint64_t wpos)
+{
+	static const uint8_t sync[21] = { 1, 0, 0,0,0,0,0,0,0,0, 1, 0, 1,1,1,1,1,1,1,1, 1 };
+	int added = 0;
+	while (f->rpos + 21 <= wpos) {
+		int hd = 0;
+		for (int i = 0; i < 21; i++) hd += bits[f->rpos + i] ^ sync[i];
+		if (hd != 0 && hd != 21) { f->rpos++; continue; }
+		const int inv = hd == 21;
+		const uint64_t c0 = f->rpos + 1;                 /* start bit of the 00 character */
+		if (c0 + 10 * C50_LEN > wpos) break;             /* wait for the rest */
+		uint8_t pkt[C50_LEN];
+		int ok = 1;
+		for (int j = 0; j < C50_LEN; j++) ok &= imet_char(bits, c0 + 10 * (uint64_t)j, inv, &pkt[j]);
+		if (!ok) { f->rpos++; continue; }
+		OrFrame *fr = push_frame(f);
+		fr->len = C50_LEN;
+		memcpy(fr->data, pkt, C50_LEN);
+		unsigned c1 = 0, c2 = 0;
+		for (int j = 2; j < 7; j++) { c1 = (c1 + pkt[j]) & 0xFF; c2 = (c2 + c1) & 0xFF; }
+		fr->nerr[0] = (c1 == pkt[7] && c2 == pkt[8]) ? 0 : -1;
+		fr->nerr[1] = 0;
+		fr->flags = inv ? 1u : 0u;
+		fr->bitpos = c0;
+		f->rpos = c0 + 10 * (uint64_t)C50_LEN - 1;      /* the last stop bit may open the next sync */
+		added++;
+	}
+	return added;
+}
+
 int or_framer_run_other(void *fp, const uint8_t *bits, uint64_t wpos)
 {
 	OrFramerPub *f = fp;
@@ -457,6 +493,7 @@ int or_framer_run_other(void *fp, const uint8_t *bits, uint64_t wpos)
 	case OR_IMS100: return ims100_run(f, bits, wpos);
 	case OR_IMET4:  return imet4_run(f, bits, wpos);
 	case OR_MRZN1:  return mrzn1_run(f, bits, wpos);
+	case OR_C50:    return c50_run(f, bits, wpos);
 	default: return 0;
 	}
 }

@@ -28,7 +28,7 @@ struct SondeB1Decoder {
 
 static const uint32_t kB1MaxSamples = 16 * SONDE_TILE;
 // submit granule: one tile, or one tile behind the 8:1 tone demodulator for the AFSK sondes
-static size_t b1_granule(int type) { return type == SONDE_IMET4 ? 8 * (size_t)SONDE_TILE : (size_t)SONDE_TILE; }
+static size_t b1_granule(int type) { return (type == SONDE_IMET4 || type == SONDE_C50) ? 8 * (size_t)SONDE_TILE : (size_t)SONDE_TILE; }
 
 static SondeB1Decoder *b1_init(int type, int samplerate, bool implemented)
 {
@@ -106,5 +106,5 @@ SONDE_B1_DEF(DFM09Decoder,  dfm09,  SONDE_DFM09,  true)
 SONDE_B1_DEF(IMS100Decoder, ims100, SONDE_IMS100, true)
 SONDE_B1_DEF(M10Decoder,    m10,    SONDE_M10,    true)
 SONDE_B1_DEF(IMET4Decoder,  imet4,  SONDE_IMET4,  true)    // Bell-202 AFSK: tone demodulator in front (SPEC 3.6)
-SONDE_B1_DEF(C50Decoder,    c50,    SONDE_C50,    false)
+SONDE_B1_DEF(C50Decoder,    c50,    SONDE_C50,    true)     // AFSK 2400 Bd: the same tone demodulator, other mixer (SPEC 3.6)
 SONDE_B1_DEF(MRZN1Decoder,  mrzn1,  SONDE_MRZN1,  true)

@@ -41,7 +41,7 @@ static const ModemDef k_modems[SONDE_NTYPES] = {
 	{ 4800.0, 0.65f, 2, 1 },   // iMS100 2400 bit/s biphase    -> 4800 chips/s
 	{ 9600.0, 0.65f, 1, 1 },   // M10    9600 chips/s Manchester: stays at 48 kS/s (5 samples per chip)
 	{ 1200.0, 0.65f, 1, 8 },   // iMet-1/4 Bell-202 AFSK 1200 Bd: tone demodulator, then 6 kS/s through the same loop
-	{ 2400.0, 0.65f, 2, 1 },   // SRS-C50 (AFSK, not implemented)
+	{ 2400.0, 0.65f, 1, 8 },   // SRS-C50 AFSK 2400 Bd (2900 / 4700 Hz): tone demodulator, then 6 kS/s (2.5 samples per symbol)
 	{ 4800.0, 0.65f, 2, 1 },   // MRZ-N1  2400 bit/s Manchester -> 4800 chips/s
 };
 
@@ -69,15 +69,19 @@ static void make_taps(const ModemDef *md, int type, float *out /* [32][32] */)
 }
 
 // mixer table of the AFSK tone demodulator: (cos, -sin) of 2 pi 17 k / 480 (1700 Hz at 48 kS/s), SPEC 3.6
-extern "C" int sonde_get_afsk_table(float *out /* [480][2] */)
+static void make_mixer(float *out, int cycles, int per)
 {
-	if (!out) return fail("sonde_get_afsk_table: null argument");
 	const double PI = 3.14159265358979323846;
-	for (int k = 0; k < SD_AF_PER; k++) {
-		const double a = 2.0 * PI * 17.0 * (double)k / (double)SD_AF_PER;
+	for (int k = 0; k < per; k++) {
+		const double a = 2.0 * PI * (double)cycles * (double)k / (double)per;
 		out[2 * k] = (float)cos(a);
 		out[2 * k + 1] = (float)(-sin(a));
 	}
+}
+extern "C" int sonde_get_afsk_table(float *out /* [480][2] */)
+{
+	if (!out) return fail("sonde_get_afsk_table: null argument");
+	make_mixer(out, 17, SD_AF_PER);         // iMet: 1700 Hz
 	return 0;
 }
 
@@ -124,7 +128,7 @@ struct SondeBatch {
 	size_t stage_bytes = 0;
 	// AFSK sondes (iMet): tone-demodulator state, mixer table, 6 kS/s scratch rows; the other channels' list for kernel A
 	SdAfskState *d_astates = nullptr;
-	float *d_wtab = nullptr, *d_afq = nullptr;
+	float *d_wtab = nullptr, *d_wtab_c50 = nullptr, *d_afq = nullptr;
 	// kernel A runs once per decimation class (1, 2, 4) of the non-AFSK channels: one class in the batch = one plain
 	// launch over all channels; several = one launch per class over its channel list
 	uint32_t *d_cls[3] = {};
@@ -165,7 +169,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	for (int k = 0; k < 2; k++) { (void)hipFree(b->d_frames2[k]); (void)hipFree(b->d_counts2[k]); (void)hipFree(b->d_fo2[k]); if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]); }
 	if (b->ev_xs) (void)hipEventDestroy(b->ev_xs);
 	(void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
-	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
+	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_wtab_c50); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
 	for (int k = 0; k < 3; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
 	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_g64); (void)hipFree(b->d_m10tab); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
@@ -207,7 +211,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	b->ring_words = pow2ceil((uint32_t)((max_bits + 8 * SONDE_FRAME_MAX + 1024 + 31) / 32));
 	b->max_frames = 2;
 	{	// frames per submit per type: submit bits (at that type's fastest period) / shortest frame of the type, + carry-over
-		static const uint32_t min_frame_bits[SONDE_NTYPES] = { 320 * 8, 560, 1152, 1648, 140, 1u << 30, 768 };
+		static const uint32_t min_frame_bits[SONDE_NTYPES] = { 320 * 8, 560, 1152, 1648, 140, 90, 768 };
 		for (int t = 0; t < SONDE_NTYPES; t++) {
 			if (b->chlist[t].empty()) continue;
 			const int32_t p = modem_period0(md, t) - (modem_period0(md, t) >> 8);
@@ -240,10 +244,10 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	ALLOC(b->d_descs, C * (size_t)b->max_frames * SD_DESC_BYTES);
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
-	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
+	const size_t n_afsk = b->chlist[SONDE_IMET4].size() + b->chlist[SONDE_C50].size();      // tone-demodulated sondes
 	std::vector<uint32_t> cls[3];               // index: 0 -> decim 1, 1 -> decim 2, 2 -> decim 4
 	for (uint32_t c = 0; c < b->n_channels; c++) {
-		if (b->types[c] == SONDE_IMET4) continue;
+		if (b->types[c] == SONDE_IMET4 || b->types[c] == SONDE_C50) continue;
 		const int d = md[b->types[c]].decim;
 		cls[d == 4 ? 2 : d - 1].push_back(c);
 	}
@@ -259,6 +263,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		b->granule = SONDE_TILE * SD_AF_DEC;
 		ALLOC(b->d_astates, C * sizeof(SdAfskState));
 		ALLOC(b->d_wtab, SD_AF_PER * 2 * sizeof(float));
+		ALLOC(b->d_wtab_c50, SD_C50_PER * 2 * sizeof(float));
 		ALLOC(b->d_afq, n_afsk * (size_t)(cfg->max_samples / SD_AF_DEC) * sizeof(float));
 	}
 #undef ALLOC
@@ -277,7 +282,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		modems[t].decim = md[t].decim;
 		modems[t].itile = SD_TILE / md[t].decim;      // AFSK: kernel A sees the 6 kS/s stream as plain real input
 		modems[t].nt = SD_NT(md[t].decim);
-		modems[t].rounds = ((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 > SD_ROUND_MAX) ? 2 : 1;
+		modems[t].rounds = (int32_t)(((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 + SD_ROUND_MAX - 1) / SD_ROUND_MAX);   // 1; 2: M10, iMet; 4: C50
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
 	CHK(hipMemcpy(b->d_modems, modems, sizeof(modems), hipMemcpyHostToDevice));
@@ -367,6 +372,9 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		float wtab[2 * SD_AF_PER];
 		sonde_get_afsk_table(wtab);
 		CHK(hipMemcpy(b->d_wtab, wtab, sizeof(wtab), hipMemcpyHostToDevice));
+		float wc[2 * SD_C50_PER];
+		make_mixer(wc, 19, SD_C50_PER);       // C50: 3800 Hz, midway between the 2900 / 4700 Hz tones
+		CHK(hipMemcpy(b->d_wtab_c50, wc, sizeof(wc), hipMemcpyHostToDevice));
 		CHK(hipMemset(b->d_astates, 0, C * sizeof(SdAfskState)));
 	}
 	for (int k = 0; k < 3; k++)
@@ -403,7 +411,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	b->n_submits++;
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	if (timed) HIPCHK(hipEventRecord(ev[0], stream));
-	const size_t n_afsk = b->chlist[SONDE_IMET4].size();
+	const size_t n_afsk = b->chlist[SONDE_IMET4].size() + b->chlist[SONDE_C50].size();
 	const bool iq = b->input_kind == SONDE_INPUT_IQ;
 	const int slot = (int)(b->tickets & 1);
 	SondeFrame *const d_frames = b->d_frames2[slot];
@@ -431,13 +439,20 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 			used++;
 		}
 		if (n_afsk) {
-			// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows
-			// (one kernel-A tile = 2048 scratch samples = 16384 input samples)
+			// AFSK channels: tone demodulator into 6 kS/s scratch rows (iMet's first, then C50's), then kernel A's real-input
+			// path over those rows (one kernel-A tile = 2048 scratch samples = 16384 input samples)
 			const size_t nq = n_samples / SD_AF_DEC;
-			sd_launch_afsk(iq, (uint32_t)n_afsk, stream, (const float *)samples, channel_stride, n_tiles,
-				b->d_chlist[SONDE_IMET4], b->d_astates, b->d_wtab, b->d_afq, nq);
-			sd_launch_demod(false, 1, (uint32_t)n_afsk, stream, b->d_afq, nq, (int)(nq / SONDE_TILE),
-				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[SONDE_IMET4], true, fo);
+			size_t row0 = 0;
+			for (int t : { SONDE_IMET4, SONDE_C50 }) {
+				const size_t nt = b->chlist[t].size();
+				if (!nt) continue;
+				float *rows = b->d_afq + row0 * (size_t)(b->max_samples / SD_AF_DEC);
+				sd_launch_afsk(t, iq, (uint32_t)nt, stream, (const float *)samples, channel_stride, n_tiles,
+					b->d_chlist[t], b->d_astates, t == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
+				sd_launch_demod(false, 1, (uint32_t)nt, stream, rows, nq, (int)(nq / SONDE_TILE),
+					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[t], true, fo);
+				row0 += nt;
+			}
 		}
 	}
 	HIPCHK(hipGetLastError());
@@ -459,8 +474,14 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		HIPCHK(hipGetLastError());
 		framer_launched = true;
 	}
-	if (n_afsk) {
-		sd_launch_framer_imet((uint32_t)n_afsk, stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
+	if (!b->chlist[SONDE_C50].empty()) {
+		sd_launch_framer_c50((uint32_t)b->chlist[SONDE_C50].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
+			d_frames, d_counts, b->max_frames, b->d_chlist[SONDE_C50]);
+		HIPCHK(hipGetLastError());
+		framer_launched = true;
+	}
+	if (!b->chlist[SONDE_IMET4].empty()) {
+		sd_launch_framer_imet((uint32_t)b->chlist[SONDE_IMET4].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
 			d_frames, d_counts, b->max_frames, b->d_chlist[SONDE_IMET4]);
 		HIPCHK(hipGetLastError());
 		framer_launched = true;

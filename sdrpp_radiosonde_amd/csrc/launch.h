@@ -21,9 +21,11 @@ void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t str
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */);
 
-void sd_launch_afsk(bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
+void sd_launch_afsk(int type /* SONDE_IMET4 or SONDE_C50 */, bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
 	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride);
 void sd_launch_framer_imet(uint32_t n_list, hipStream_t stream, const SdChanState *states, SdFramerState *fstates,
+	const uint32_t *bitring, uint32_t ring_words, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist);
+void sd_launch_framer_c50(uint32_t n_list, hipStream_t stream, const SdChanState *states, SdFramerState *fstates,
 	const uint32_t *bitring, uint32_t ring_words, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist);
 
 #define SD_DESC_BYTES 16   // sizeof(SdFrameDesc)

@@ -602,6 +602,54 @@ void SondeParser::feed_mrzn1(const SondeFrame &f, std::vector<SondeData> &out)
 	out.push_back(sd);
 }
 
+// SRS-C50 (README.md:17: GPS + temperature).  One value per 9-byte packet 00 FF <type> <value, 4 bytes big-endian> <c1> <c2>
+// ([RECALL]: the packet shape and the Fletcher sum are the public C34/C50 decoders'; the type numbers and scalings below
+// are this repo's -- the reference's are in the absent sondedump):
+//   0x03 air temperature (float32) | 0x10 sonde number | 0x14 latitude, 0x15 longitude (i32, 1e-6 deg) |
+//   0x16 altitude (i32, cm) | 0x17 UTC time as the decimal number hhmmss | 0x18 date as the decimal number ddmmyy
+void SondeParser::feed_c50(const SondeFrame &f, std::vector<SondeData> &out)
+{
+	if (f.len != 9 || f.nerr[0] != 0) return;
+	const uint8_t *d = f.data;
+	const uint32_t v = ((uint32_t)d[3] << 24) | ((uint32_t)d[4] << 16) | ((uint32_t)d[5] << 8) | d[6];
+	SondeData sd;
+	memset(&sd, 0, sizeof(sd));
+	switch (d[2]) {
+	case 0x03: {
+		float t;
+		memcpy(&t, &v, 4);
+		if (t > -120.0f && t < 80.0f) { sd.fields = DATA_PTU; sd.temp = t; sd.calib_percent = 100.0f; }
+		break;
+	}
+	case 0x10:
+		sd.fields = DATA_SERIAL;
+		snprintf(sd.serial, sizeof(sd.serial), "C50-%u", (unsigned)v);
+		break;
+	case 0x14: m_c50_lat = (int32_t)v * 1e-6; m_c50_have |= 1; break;
+	case 0x15: m_c50_lon = (int32_t)v * 1e-6; m_c50_have |= 2; break;
+	case 0x16:
+		if ((m_c50_have & 3) == 3) {
+			sd.fields = DATA_POS;
+			sd.lat = (float)m_c50_lat; sd.lon = (float)m_c50_lon; sd.alt = (float)((int32_t)v * 1e-2);
+		}
+		break;
+	case 0x17:
+		if ((m_c50_have & 4) && v < 240000u && (v / 100) % 100 < 60 && v % 100 < 61) {
+			sd.fields = DATA_TIME;
+			sd.time = (time_t)(m_c50_date + (long long)(v / 10000) * 3600 + (long long)((v / 100) % 100) * 60 + (long long)(v % 100));
+		}
+		break;
+	case 0x18: {
+		const int day = (int)(v / 10000), mon = (int)((v / 100) % 100), yr = (int)(v % 100);
+		if (day >= 1 && day <= 31 && mon >= 1 && mon <= 12) { m_c50_date = days_from_civil(2000 + yr, mon, day) * 86400LL; m_c50_have |= 4; }
+		break;
+	}
+	default:
+		break;
+	}
+	if (sd.fields) out.push_back(sd);
+}
+
 void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
 {
 	switch (f.type) {
@@ -611,6 +659,7 @@ void SondeParser::feed(const SondeFrame &f, std::vector<SondeData> &out)
 	case SONDE_IMET4: feed_imet(f, out); break;
 	case SONDE_IMS100: feed_ims100(f, out); break;
 	case SONDE_MRZN1: feed_mrzn1(f, out); break;
+	case SONDE_C50: feed_c50(f, out); break;
 	default: break;
 	}
 }

@@ -17,6 +17,7 @@ private:
 	void feed_imet(const SondeFrame &f, std::vector<SondeData> &out);
 	void feed_ims100(const SondeFrame &f, std::vector<SondeData> &out);
 	void feed_mrzn1(const SondeFrame &f, std::vector<SondeData> &out);
+	void feed_c50(const SondeFrame &f, std::vector<SondeData> &out);
 	int m_type;
 	uint64_t m_calib_mask = 0;         // RS41: which of the 51 calibration fragments have been seen
 	uint8_t m_calib[51 * 16] = {};
@@ -27,6 +28,10 @@ private:
 	float m_dfm_meas[5] = {};         // CONF measurement channels 0..4
 	unsigned m_dfm_meas_mask = 0;
 	// iMS-100 / RS-11G: the calibration words arrive one per frame (frame counter mod 4)
+	// SRS-C50: one value per packet
+	double m_c50_lat = 0, m_c50_lon = 0;
+	int m_c50_have = 0;               // bit0 lat, bit1 lon, bit2 date
+	long long m_c50_date = 0;         // seconds since epoch of the date
 	uint32_t m_ims_cal[4] = {};
 	unsigned m_ims_cal_mask = 0;
 };

@@ -30,7 +30,8 @@ struct SdModem {            // per sonde type, built on the host
 };
 
 #define SD_AF_DEC 8        // AFSK tone demodulator (SPEC 3.6): 48 kS/s -> 6 kS/s
-#define SD_AF_PER 480      // mixer table period: 17 cycles of 1700 Hz at 48 kS/s
+#define SD_AF_PER 480      // iMet mixer table period: 17 cycles of 1700 Hz at 48 kS/s
+#define SD_C50_PER 240     // SRS-C50 mixer table period: 19 cycles of 3800 Hz at 48 kS/s
 struct SdAfskState {        // tone-demodulator state, one per channel (64 B)
 	float    iq_last[2];    // previous IQ sample of the first discriminator
 	float    b[4][2];       // the four 8-sample block sums before the next one, oldest first

@@ -819,9 +819,11 @@ def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 
                device: str | torch.device = "cpu", first_channel: int = 0, invert: bool = False, m20: bool = False,
                **mod_kw) -> SynthBatch:
     """Synthetic batch of any supported sonde type (0 RS41, 1 DFM09, 2 iMS-100, 3 M10 (m20=True: M20 frames), 4 iMet-4,
-    6 MRZ-N1)."""
+    5 SRS-C50, 6 MRZ-N1)."""
     if sonde_type == 4:
         return make_imet_batch(n_channels, n_samples, seed=seed, snr_db=ebn0_db, device=device, first_channel=first_channel)
+    if sonde_type == 5:
+        return make_c50_batch(n_channels, n_samples, seed=seed, snr_db=ebn0_db, device=device, first_channel=first_channel)
     if sonde_type == 0:
         return make_rs41_batch(n_channels, n_samples, seed=seed, ebn0_db=ebn0_db, device=device,
                                first_channel=first_channel, invert=invert, **mod_kw)
@@ -917,11 +919,12 @@ def imet_bitstreams(seed: int, channels: np.ndarray, nbits: int, xdata: bool = F
 
 
 def afsk_modulate(bits: np.ndarray, n_samples: int, *, seed: int = 0, snr_db: float = 30.0, fm_dev_hz: float = 3000.0,
-                  cfo_max_hz: float = 500.0, amp_range=(0.25, 1.0), device: str | torch.device = "cpu", fs: float = FS):
+                  cfo_max_hz: float = 500.0, amp_range=(0.25, 1.0), device: str | torch.device = "cpu", fs: float = FS,
+                  baud: float = 1200.0, mark_hz: float = 1200.0, space_hz: float = 2200.0):
     """bits (1 = mark) -> audio tones (phase-continuous 1200/2200 Hz at 1200 Bd) -> FM -> IQ [C, n_samples, 2].
     snr_db: carrier-to-noise ratio in the full fs bandwidth."""
     C, nbits = bits.shape
-    sps = fs / IMET_BAUD
+    sps = fs / baud
     assert nbits >= int(n_samples / sps) + 4
     rng = np.random.Generator(np.random.Philox(key=(seed * 104723 + 7) & 0xFFFFFFFFFFFFFFFF))
     cfo = rng.uniform(-cfo_max_hz, cfo_max_hz, size=C)
@@ -934,7 +937,7 @@ def afsk_modulate(bits: np.ndarray, n_samples: int, *, seed: int = 0, snr_db: fl
     for c in range(C):
         idx = torch.clamp(torch.floor(n / sps - tau[c]).to(torch.int64), 0, nbits - 1)
         b = torch.from_numpy(bits[c].astype(np.float64)).to(device)[idx]
-        f_tone = b * IMET_MARK_HZ + (1.0 - b) * IMET_SPACE_HZ
+        f_tone = b * mark_hz + (1.0 - b) * space_hz
         audio = torch.cos(torch.cumsum(f_tone, dim=0) * (2.0 * math.pi / fs))
         ph = torch.cumsum(fm_dev_hz * audio + cfo[c], dim=0) * (2.0 * math.pi / fs)
         sig = amp[c] / math.sqrt(2.0 * 10.0 ** (snr_db / 10.0))
@@ -978,3 +981,60 @@ def make_wideband_rs41(bins_active, n_samples: int, *, seed: int = 1, ebn0_db: f
         total[:, 0] += iq[0, :, 0] * c - iq[0, :, 1] * s_
         total[:, 1] += iq[0, :, 0] * s_ + iq[0, :, 1] * c
     return total, {k: frames[i] for i, k in enumerate(bins_active)}
+
+
+# ================================================================ SRS-C50 (AFSK 2400 Bd, one value per packet)
+C50_BAUD, C50_MARK_HZ, C50_SPACE_HZ = 2400.0, 4700.0, 2900.0
+
+
+def c50_true_temp(channel: int, k: int) -> float:
+    return 13.0 - 0.05 * k - 0.01 * (channel % 40)
+
+
+def c50_packet(ptype: int, value: int) -> np.ndarray:
+    body = bytes([ptype]) + int(value & 0xFFFFFFFF).to_bytes(4, "big")
+    c1 = c2 = 0
+    for b in body:
+        c1 = (c1 + b) & 0xFF
+        c2 = (c2 + c1) & 0xFF
+    return np.frombuffer(bytes([0x00, 0xFF]) + body + bytes([c1, c2]), dtype=np.uint8)
+
+
+def c50_build_packets(channel: int, k: int):
+    """The seven packets of second k: id, date, time, latitude, longitude, altitude, temperature."""
+    tod = (k + 45296) % 86400
+    t32 = int(np.frombuffer(np.float32(c50_true_temp(channel, k)).tobytes(), dtype="<u4")[0])
+    return [c50_packet(0x10, 3000000 + channel), c50_packet(0x18, 150624),
+            c50_packet(0x17, (tod // 3600) * 10000 + ((tod // 60) % 60) * 100 + tod % 60),
+            c50_packet(0x14, int(round((47.0 + 1e-3 * channel) * 1e6))), c50_packet(0x15, int(round((8.0 + 1e-4 * k) * 1e6))),
+            c50_packet(0x16, int(round((1200.0 + 5.0 * k) * 100))), c50_packet(0x03, t32)]
+
+
+def c50_bitstreams(seed: int, channels: np.ndarray, nbits: int):
+    channels = np.asarray(channels, dtype=np.int64)
+    rng = np.random.Generator(np.random.Philox(key=(seed * 7927 + 31) & 0xFFFFFFFFFFFFFFFF))
+    bits = np.ones((len(channels), nbits + 4096), dtype=np.uint8)
+    frames = []
+    for ci, c in enumerate(channels):
+        pos = int(rng.integers(40, 200))
+        lst, k = [], 0
+        while pos < nbits:
+            for pkt in c50_build_packets(int(c), k):
+                ub = uart_bits(pkt)
+                bits[ci, pos: pos + len(ub)] = ub
+                if pos + len(ub) <= nbits:
+                    lst.append((pos, pkt))
+                pos += len(ub) + int(rng.integers(4, 40))      # short idle gaps: the transmitter sends packets back to back
+            k += 1
+        frames.append(lst)
+    return bits[:, :nbits], frames
+
+
+def make_c50_batch(n_channels: int, n_samples: int, *, seed: int = 1, snr_db: float = 30.0,
+                   device: str | torch.device = "cpu", first_channel: int = 0, **mod_kw) -> SynthBatch:
+    nbits = int(n_samples * C50_BAUD / FS) + 16
+    channels = np.arange(first_channel, first_channel + n_channels)
+    bits, frames = c50_bitstreams(seed, channels, nbits)
+    iq, cfo, tau, amp = afsk_modulate(bits, n_samples, seed=seed + first_channel, snr_db=snr_db, device=device, baud=C50_BAUD,
+                                      mark_hz=C50_MARK_HZ, space_hz=C50_SPACE_HZ, fm_dev_hz=4000.0, **mod_kw)
+    return SynthBatch(iq=iq, frames=frames, bits=bits, cfo_hz=cfo, tau=tau, amp=amp)

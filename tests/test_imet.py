@@ -158,3 +158,96 @@ def test_b1_imet_decoder(oracle):
                 poss += 1
     L.imet4_decoder_deinit(h)
     assert len(seqs) >= 5 and seqs == sorted(seqs) and poss >= 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("snr", [30.0, 16.0])
+def test_c50_gpu_bit_exact(oracle, snr):
+    """SRS-C50 (c50_decode slot, main.hpp:41): AFSK 2400 Bd through the 3800 Hz tone demodulator, four timing-loop rounds
+    per tile, 8N1 packet framer with the Fletcher check -- bits and frame records equal to the oracle's."""
+    import torch
+    from sdrpp_radiosonde_amd.batch import SondeBatch
+    Cn, n = 4, 16384 * 8
+    sb = synth.make_batch(5, Cn, n, seed=61, ebn0_db=snr)
+    b = SondeBatch(Cn, n, types=np.full(Cn, 5, dtype=np.uint8))
+    b.submit(sb.iq.to("cuda:0"))
+    got = b.frames()
+    ref = oracle.batch_run(5, sb.iq.numpy(), nthreads=4, cap_per_channel=400)
+    assert len(ref) >= 40 * Cn and got.tobytes() == ref.tobytes()
+    for c in range(Cn):
+        ch = oracle.Channel(5, c)
+        ch.feed(sb.iq.numpy()[c])
+        nb = len(ch.bits())
+        assert b.nbits(c) == nb and np.array_equal(b.read_bits(c, 0, nb), ch.bits())
+    sent = sum(len(f) for f in sb.frames)
+    exact = sum(any(np.array_equal(tx, f["data"][:9]) for _, tx in sb.frames[f["channel"]]) for f in got)
+    assert exact >= 0.9 * sent
+    # two submits = one submit
+    b2 = SondeBatch(Cn, n // 2, types=np.full(Cn, 5, dtype=np.uint8))
+    parts = []
+    for lo in (0, n // 2):
+        b2.submit(sb.iq[:, lo: lo + n // 2].contiguous().to("cuda:0"))
+        parts.append(b2.frames())
+    g2 = np.concatenate(parts)
+    assert g2[np.lexsort((g2["bitpos"], g2["channel"]))].tobytes() == ref.tobytes()
+
+
+@pytest.mark.gpu
+def test_b1_c50_decoder(oracle):
+    """c50_decoder_init / c50_decode (main.hpp:41; README.md:17: GPS + temperature)."""
+    import calendar
+    L = _lib.load()
+    n = 16384 * 10
+    sb = synth.make_c50_batch(1, n, seed=71, snr_db=28.0)
+    d = np.zeros(n, dtype=np.float32)
+    last = np.zeros(2, dtype=np.float32)
+    oracle.lib().or_discriminate(oracle.fptr(np.ascontiguousarray(sb.iq.numpy()[0].reshape(-1))), n, oracle.fptr(d), oracle.fptr(last))
+    h = L.c50_decoder_init(48000)
+    assert h
+    frag = _lib.SondeData()
+    pos, temps, times, serial = [], [], [], None
+    for off in range(0, len(d), 4800):
+        buf = np.ascontiguousarray(d[off: off + 4800])
+        while L.c50_decode(h, C.byref(frag), buf.ctypes.data_as(C.c_void_p), len(buf)) != 0:
+            if frag.fields & _lib.DATA_POS:
+                pos.append((frag.lat, frag.lon, frag.alt))
+            if frag.fields & _lib.DATA_PTU:
+                temps.append(frag.temp)
+            if frag.fields & _lib.DATA_TIME:
+                times.append(frag.time)
+            if frag.fields & _lib.DATA_SERIAL:
+                serial = frag.serial
+    L.c50_decoder_deinit(h)
+    assert serial == b"C50-3000000" and len(pos) >= 5 and len(temps) >= 5 and len(times) >= 5
+    assert all(abs(p[0] - 47.0) < 1e-4 and abs(p[1] - 8.0) < 0.01 and 1195.0 <= p[2] < 1300.0 for p in pos)
+    assert all(11.0 < t <= 13.0 for t in temps)
+    assert all(0 <= t - calendar.timegm((2024, 6, 15, 12, 34, 56)) < 60 for t in times)
+
+
+def test_c50_parser_fields():
+    lib = _lib.load()
+    h = lib.sonde_parser_create(5)
+    out = (_lib.SondeData * 4)()
+    got = []
+    for pkt in synth.c50_build_packets(9, 3):
+        f = _lib.SondeFrame()
+        f.type, f.len = 5, 9
+        C.memmove(f.data, pkt.ctypes.data, 9)
+        for i in range(lib.sonde_parser_feed(h, C.byref(f), out, 4)):
+            d = _lib.SondeData()
+            C.memmove(C.byref(d), C.byref(out[i]), C.sizeof(d))
+            got.append(d)
+    lib.sonde_parser_destroy(h)
+    kinds = [d.fields for d in got]
+    assert kinds == [_lib.DATA_SERIAL, _lib.DATA_TIME, _lib.DATA_POS, _lib.DATA_PTU]
+    assert got[0].serial == b"C50-3000009"
+    import calendar
+    assert got[1].time == calendar.timegm((2024, 6, 15, 12, 34, 59))
+    assert abs(got[2].lat - 47.009) < 1e-5 and abs(got[2].lon - 8.0003) < 1e-5 and abs(got[2].alt - 1215.0) < 0.01
+    assert abs(got[3].temp - synth.c50_true_temp(9, 3)) < 1e-5
+    bad = synth.c50_packet(0x14, 1).copy()
+    f = _lib.SondeFrame()
+    f.type, f.len = 5, 9
+    f.nerr[0] = -1
+    C.memmove(f.data, bad.ctypes.data, 9)
+    assert lib.sonde_parser_feed(h if False else lib.sonde_parser_create(5), C.byref(f), out, 4) == 0
