@@ -49,6 +49,7 @@ struct FramerLds {                 // one per wave (= per frame)
 	int     pos[2][RS_T];
 	int     L[2];
 	int     status[2];     // 0 clean, >0 errors to fix, -1 fail
+	int     done[2];       // the single-error fast path has settled this codeword
 };
 
 __device__ __forceinline__ uint32_t gmul(const FramerTabs &s, uint32_t a, uint32_t b)
@@ -101,20 +102,54 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 {
 	// ---- syndromes: lane = 24*c + j, byte-sliced Horner from the highest position down (the codeword buffer is
 	// zero-padded to 256 bytes, so the last word may be read whole)
-	uint32_t syn = 0;
+	uint32_t syn = 0, lsyn = GF_LZ;
 	if (lane < 2 * RS_R) {
 		const int c = lane / RS_R, j = lane % RS_R;
 		syn = syndrome_swar(tb, s.cw[c], (n + 3) >> 2, j, swar);
-		s.logS[c][j] = tb.log2[syn];
+		lsyn = tb.log2[syn];
+		s.logS[c][j] = (uint16_t)lsyn;
 	}
 	const unsigned long long nzm = __ballot(syn != 0);
-	if (lane < 2) {
-		const bool nz = (nzm >> (RS_R * lane)) & 0xFFFFFFull;
-		s.status[lane] = nz ? 1 : 0;
-		s.L[lane] = 0;
+	if (nzm == 0ull) {                          // both codewords clean (wave-uniform): nothing to correct
+		if (lane < 2) { s.status[lane] = 0; s.L[lane] = 0; s.done[lane] = 0; }
+		WAVE_SYNC();
+		return;
+	}
+	// ---- one byte error (the usual case of a codeword that needs the corrector at all): S_j = e X^j for every j, i.e. all
+	// 24 syndromes are non-zero and consecutive ones have the same ratio X = alpha^p.  Then Lambda = 1 + X x is the unique
+	// shortest recurrence (2 L <= 24), its root is position p, Omega = S_0 and the Forney value e = S_0: exactly what
+	// Berlekamp-Massey, Chien and Forney below arrive at after 24 dependent iterations -- including the verdict "uncorrectable"
+	// when p lies in the padding of the shortened code (SPEC 3.3).
+	bool settled[2];
+	{
+		const int c = lane >= RS_R ? 1 : 0, j = lane - RS_R * c;
+		const int nx = __shfl_down((int)lsyn, 1, 64);
+		int diff = nx - (int)lsyn;
+		if (diff < 0) diff += 255;
+		const int p0 = __builtin_amdgcn_readlane(diff, 0), p1 = __builtin_amdgcn_readlane(diff, RS_R);
+		const bool good = lane < 2 * RS_R && lsyn < 255u && (j == RS_R - 1 || (nx < 255 && diff == (c ? p1 : p0)));
+		const unsigned long long gm = __ballot(good);
+		const bool one0 = (gm & 0xFFFFFFull) == 0xFFFFFFull, one1 = ((gm >> RS_R) & 0xFFFFFFull) == 0xFFFFFFull;
+		const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)syn, 0), e1 = (uint32_t)__builtin_amdgcn_readlane((int)syn, RS_R);
+		const bool dirty0 = (nzm & 0xFFFFFFull) != 0ull, dirty1 = ((nzm >> RS_R) & 0xFFFFFFull) != 0ull;
+		settled[0] = !dirty0 || one0;
+		settled[1] = !dirty1 || one1;
+		if (lane < 2) {
+			const bool one = lane ? one1 : one0, dirty = lane ? dirty1 : dirty0;
+			const int p = lane ? p1 : p0;
+			const uint32_t e = lane ? e1 : e0;
+			int st = dirty ? 1 : 0;
+			if (one) {
+				if (p < n) s.cw[lane][p] ^= (uint8_t)e;
+				else st = -1;
+			}
+			s.status[lane] = st;
+			s.L[lane] = one ? 1 : 0;
+			s.done[lane] = one ? 1 : 0;
+		}
 	}
 	WAVE_SYNC();
-	if (nzm == 0ull) return;                    // both codewords clean (wave-uniform): nothing to correct
+	if (settled[0] && settled[1]) return;       // wave-uniform
 
 	// ---- Berlekamp-Massey, one coefficient per lane: half-wave h handles codeword h, lane idx = lane&31 holds
 	// lam[idx] and (the logarithm of) Bp[idx] where Bp = x^m * B.  Same recurrence as the sequential form (delta,
@@ -122,7 +157,7 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 	// discrepancy term is one antilog read, the update one more, plus the logarithm of the new coefficient.
 	{
 		const int h = lane >> 5, idx = lane & 31;
-		const bool live = s.status[h] > 0;
+		const bool live = s.status[h] > 0 && !s.done[h];
 		uint32_t lam = (idx == 0) ? 1u : 0u;
 		uint32_t loglam = (idx == 0) ? 0u : (uint32_t)GF_LZ;
 		uint32_t logBp = (idx == 1) ? 0u : (uint32_t)GF_LZ;
@@ -169,7 +204,7 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 	// codeword after the other: 7 of the 18 us this stage cost at the end of the demod kernel).
 	{
 		const int h = lane >> 5, idx = lane & 31;
-		const bool live = s.status[h] > 0;
+		const bool live = s.status[h] > 0 && !s.done[h];
 		const int L = live ? s.L[h] : 0;
 		const uint16_t *ll = s.loglam[h];
 		// Chien search over the n positions of the shortened codeword, position i = idx + 32*it.
@@ -258,6 +293,13 @@ __device__ __forceinline__ void sd_rs41_decode_frame(const FramerTabs &tabs, Fra
 	const uint32_t *__restrict__ ring, uint32_t mask, const SdFrameDesc d, SondeFrame *__restrict__ fr, uint32_t ch, int lane)
 {
 	const int flen = d.flen;
+#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
+	const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+	unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
+#define SD_TS(x) do { __builtin_amdgcn_s_waitcnt(0); x = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SD_TS(x)
+#endif
 	// K5: extract + de-whiten, four bytes per lane and step (the frame lengths are even, the word past the end
 	// is written whole and never read beyond flen)
 	{
@@ -280,18 +322,30 @@ __device__ __forceinline__ void sd_rs41_decode_frame(const FramerTabs &tabs, Fra
 		}
 	}
 	WAVE_SYNC();
-	// K6: de-interleave into two shortened codewords
+	SD_TS(ts1);
+	// K6: de-interleave into two shortened codewords, a word at a time: codeword c holds its 24 parity bytes (frame bytes
+	// 8 + 24c ..) at positions 0..23 and the message bytes frame[56 + 2i + c] at position 24 + i, i.e. word 6 + m of codeword c
+	// gathers bytes c, 2 + c of frame word 14 + 2m and of frame word 15 + 2m (one v_perm_b32 each; the byte-wise loop cost a
+	// quarter of this stage's instructions).  Bytes behind the message (the odd length of the extended frame) are zeroed;
+	// nothing reads a codeword beyond word (n + 3) / 4.
 	const int msglen = (flen - 56) / 2;
 	const int n = RS_R + msglen;
-	for (int i = lane; i < 2 * 256; i += 64) {
-		const int c = i >> 8, kk = i & 255;
-		uint8_t v = 0;
-		if (kk < RS_R) v = s.frame[8 + RS_R * c + kk];
-		else if (kk < n) v = s.frame[56 + 2 * (kk - RS_R) + c];
-		s.cw[c][kk] = v;
+	{
+		const uint32_t *frame32 = reinterpret_cast<const uint32_t *>(s.frame);
+		uint32_t *cw0 = reinterpret_cast<uint32_t *>(s.cw[0]), *cw1 = reinterpret_cast<uint32_t *>(s.cw[1]);
+		if (lane < RS_R / 4) { cw0[lane] = frame32[2 + lane]; cw1[lane] = frame32[2 + RS_R / 4 + lane]; }
+		const int valid = msglen - 4 * lane;                      // message bytes in this lane's word
+		if (valid > 0) {
+			const uint32_t f0 = frame32[14 + 2 * lane], f1 = frame32[15 + 2 * lane];
+			const uint32_t keep = valid >= 4 ? 0xFFFFFFFFu : (1u << (8 * valid)) - 1u;
+			cw0[RS_R / 4 + lane] = __builtin_amdgcn_perm(f1, f0, 0x06040200u) & keep;
+			cw1[RS_R / 4 + lane] = __builtin_amdgcn_perm(f1, f0, 0x07050301u) & keep;
+		}
 	}
 	WAVE_SYNC();
+	SD_TS(ts2);
 	rs255_decode_pair(tabs, s, n, lane, swar);
+	SD_TS(ts3);
 	for (int c = 0; c < 2; c++) {
 		if (s.status[c] > 0) {
 			for (int kk = lane; kk < n; kk += 64) {
@@ -316,5 +370,16 @@ __device__ __forceinline__ void sd_rs41_decode_frame(const FramerTabs &tabs, Fra
 		if (rem > 0 && rem < 4) wd &= (1u << (8 * rem)) - 1u;
 		reinterpret_cast<uint32_t *>(fr->data)[i] = wd;
 	}
+#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
+	{
+		unsigned long long ts4;
+		SD_TS(ts4);
+		if (lane == 0) {
+			uint32_t *dbg = reinterpret_cast<uint32_t *>(fr->data) + 124;      // bytes 496..527: behind any frame but the extended one
+			dbg[0] = (uint32_t)(ts1 - ts0); dbg[1] = (uint32_t)(ts2 - ts1); dbg[2] = (uint32_t)(ts3 - ts2); dbg[3] = (uint32_t)(ts4 - ts3);
+			dbg[4] = (uint32_t)ts0; dbg[5] = (uint32_t)ts4;
+		}
+	}
+#endif
 	WAVE_SYNC();       // the next frame of this wave reuses s
 }

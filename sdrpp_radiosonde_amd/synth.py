@@ -329,6 +329,47 @@ def rs41_bitstreams(seed: int, channels: np.ndarray, nbits: int, extended: bool 
     return bits[:, :nbits], out_frames
 
 
+def rs41_cyclic_bitstreams(seed: int, channels: np.ndarray, n_frames: int = 32, preamble_bytes: int = 64):
+    """A bit stream per channel that can be repeated end to end without a seam: n_frames x [preamble | whitened frame],
+    rotated by a per-channel offset that lies inside the first preamble, so that the wrap point falls between two frames.
+    Returns (bits [C, n_frames * 8 * (320 + preamble_bytes)], per channel [(bit offset, unscrambled frame)])."""
+    channels = np.asarray(channels, dtype=np.int64)
+    C = channels.shape[0]
+    flen = RS41_STD_LEN
+    stride = 8 * (flen + preamble_bytes)
+    rng = np.random.Generator(np.random.Philox(key=(seed * 7919 + 23) & 0xFFFFFFFFFFFFFFFF))
+    lead = rng.integers(64, 8 * preamble_bytes + 1, size=C)               # bits of preamble in front of the first frame
+    frames = rs41_build_frames(seed, np.repeat(channels, n_frames), np.tile(np.arange(n_frames), C)).reshape(C, n_frames, flen)
+    fbits = bytes_to_bits_lsb(rs41_scramble(frames.reshape(C * n_frames, flen))).reshape(C, n_frames, 8 * flen)
+    bits = np.zeros((C, n_frames * stride), dtype=np.uint8)
+    bits[:, 1::2] = 1                                                     # alternating preamble everywhere ...
+    out_frames = []
+    for c in range(C):
+        lst = []
+        for f in range(n_frames):
+            pos = int(lead[c]) + f * stride
+            bits[c, pos: pos + 8 * flen] = fbits[c, f]                    # ... the frames on top
+            lst.append((pos, frames[c, f].copy()))
+        out_frames.append(lst)
+    return bits, out_frames
+
+
+def make_rs41_cyclic(n_channels: int, n_block: int, n_blocks: int = 5, *, seed: int = 1, ebn0_db: float = 30.0,
+                     device: str | torch.device = "cpu", first_channel: int = 0, **mod_kw) -> SynthBatch:
+    """n_blocks consecutive blocks of n_block samples of ONE continuous RS41 signal per channel whose bit stream repeats
+    after exactly n_blocks blocks: cycling through the blocks feeds a decoder a stream without junk frames at the wrap
+    (with the default 5 x 196 608 samples = 98 304 symbols = 32 frames of 320 + 64 bytes).  iq: [C, n_blocks * n_block, 2]."""
+    baud = 4800.0
+    total = n_blocks * n_block
+    nb = total * baud / FS
+    assert abs(nb - round(nb)) < 1e-9 and int(round(nb)) % (8 * 384) == 0, "the cycle must hold a whole number of frame periods"
+    channels = np.arange(first_channel, first_channel + n_channels)
+    bits, frames = rs41_cyclic_bitstreams(seed, channels, n_frames=int(round(nb)) // (8 * 384))
+    ext = np.concatenate([bits, bits[:, :32]], axis=1)                       # the modulator looks two symbols ahead
+    iq, cfo, tau, amp = gfsk_modulate(ext, total, baud, seed=seed + first_channel, ebn0_db=ebn0_db, device=device, **mod_kw)
+    return SynthBatch(iq=iq, frames=frames, bits=bits, cfo_hz=cfo, tau=tau, amp=amp)
+
+
 def gfsk_modulate(bits: np.ndarray, n_samples: int, baud: float, *, seed: int = 0, ebn0_db: float = 30.0,
                   h: float = 1.0, bt: float = 0.5, cfo_max_hz: float = 500.0, amp_range=(0.25, 1.0),
                   device: str | torch.device = "cpu", chunk: int = 256, invert: bool = False, fs: float = FS):
