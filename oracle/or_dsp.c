@@ -204,17 +204,20 @@ static void push_bit(OrDemod *d, int b)
 }
 
 /* One tile's worth of symbols.  The number of symbols is fixed when the tile arrives
- * (K_total, from the timing state at that moment) and is split into rounds of at most 256;
+ * (K_total, from the timing state at that moment) and is split into rounds of at most 256 -- 512 for the
+ * streams that are not decimated (M10 at 48 kS/s and the 6 kS/s AFSK streams: up to 410 / 822 symbols per tile), so
+ * that M10 and iMet update the loop once per tile like every other sonde (every 42.7 ms of signal);
  * the loop filter is updated after every round.  OR_LOOKAHEAD_MARGIN samples of slack keep the
  * FIR support inside the data when a mid-tile correction moves the instants later. */
 static void run_rounds(OrDemod *d)
 {
 	const int64_t limit = (((d->n0 - 1 - OR_NT(d->m) / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
-	float y[OR_ROUND_MAX], m[OR_ROUND_MAX];
+	float y[2 * OR_ROUND_MAX], m[2 * OR_ROUND_MAX];
+	const int rmax = d->m->decim == 1 ? 2 * OR_ROUND_MAX : OR_ROUND_MAX;
 	int64_t K_total = (d->t_next <= limit) ? (limit - d->t_next) / d->period + 1 : 0;
 
 	while (K_total > 0) {
-		const int K = K_total > OR_ROUND_MAX ? OR_ROUND_MAX : (int)K_total;
+		const int K = K_total > rmax ? rmax : (int)K_total;
 		int32_t E = 0, S1 = 0, S0 = 0, C1 = 0;
 		K_total -= K;
 

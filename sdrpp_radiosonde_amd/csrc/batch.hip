@@ -282,7 +282,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		modems[t].decim = md[t].decim;
 		modems[t].itile = SD_TILE / md[t].decim;      // AFSK: kernel A sees the 6 kS/s stream as plain real input
 		modems[t].nt = SD_NT(md[t].decim);
-		modems[t].rounds = (int32_t)(((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 + SD_ROUND_MAX - 1) / SD_ROUND_MAX);   // 1; 2: M10, iMet; 4: C50
+		const int rmax = SD_ROUND_MAX * SD_ROUND_SPL(modems[t].decim);
+		modems[t].rounds = (int32_t)(((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 + rmax - 1) / rmax);   // 1; 2: C50
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
 	CHK(hipMemcpy(b->d_modems, modems, sizeof(modems), hipMemcpyHostToDevice));

@@ -62,7 +62,7 @@ struct DemodLds {
 	float B[2][SD_BUF];
 	float taps[SD_NPHASE * SD_TAPS_LD];     // rows padded to 36 floats: 16-byte aligned ds_read_b128
 	int4 red[2][4];                         // [round parity][wave]: (E, S1, S0, C1)
-	uint32_t chunk[2][10];                  // [round parity]: the round's bits, one ballot per wave, zero-padded
+	uint32_t chunk[2][18];                  // [round parity]: the round's bits, one ballot per wave (and half), zero-padded
 	uint32_t partial[2];                    // bits already in the ring word that wpos points into (ping-pong)
 	float iq_last[2];
 	// what the lead round wave (wave 0) computes once per round and the other round waves pick up:
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 
 	SdChanState st = states[ch];
 	const SdModem md = modems[st.type];
-	const int rounds = md.rounds;          // sub-phases (= barriers) per tile: 1, or 2 for M10
+	const int rounds = md.rounds;          // sub-phases (= barriers) per tile: 1, or 2 for the SRS-C50 6 kS/s stream
 	const int IT = md.itile;               // internal samples per input tile: 1024 after 2:1 decimation, else 2048
 	constexpr bool dec2 = DEC == 2, dec4 = DEC == 4;
 	const float *taps_g = taps_all + (size_t)st.type * SD_NPHASE * SD_NTAPS;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	uint32_t *ring_g = bitring + (size_t)ch * ring_words;
 	const uint32_t ring_mask = ring_words - 1;
 	if (tid == 0) {
-		s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0;
+		s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
 		s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
 		s.pub.flag = 0;
 		s.pub.wpos = st.wpos;
@@ -309,37 +309,45 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	float bias = st.bias;
 
 	// FIR at this lane's symbol + Gardner term + slicer, integer statistics of the round -> LDS
+	// SPL symbols per lane: symbol k = 256 h + t of the round, h < SPL (the undecimated streams hold up to 410 / 822 symbols per tile)
+	constexpr int SPL = SD_ROUND_SPL(DEC);
 	auto round_front = [&](int K, int b, int par) {
-		float y = 0.0f, m = 0.0f;
-		if (t < K) {
-			const int64_t base = (n0 - IT - SD_LH) << 16;
-			const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)t * (uint32_t)period;
-			if (dec4) {                                       // 2.5 samples per symbol: 8 taps = 3.2 symbols
-				y = interp<8>(s.A[b], s.B[b], s.taps, rel);
-				m = interp<8>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
-			} else {
-				y = interp<16>(s.A[b], s.B[b], s.taps, rel);
-				m = interp<16>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+		int Ei = 0, S1i = 0, S0i = 0, C1 = 0;
+#pragma unroll
+		for (int h = 0; h < SPL; h++) {
+			const int k = t + SD_WG * h;
+			const bool act = k < K;
+			float y = 0.0f, m = 0.0f;
+			if (act) {
+				const int64_t base = (n0 - IT - SD_LH) << 16;
+				const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)k * (uint32_t)period;
+				if (dec4) {                                       // 2.5 samples per symbol: 8 taps = 3.2 symbols
+					y = interp<8>(s.A[b], s.B[b], s.taps, rel);
+					m = interp<8>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+				} else {
+					y = interp<16>(s.A[b], s.B[b], s.taps, rel);
+					m = interp<16>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+				}
+			}
+			const float yprev = __shfl_up(y, 1, 64);
+			float e = (yprev - y) * (m - bias);
+			e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
+			Ei += (act && lane != 0) ? __float2int_rn(e) : 0;        // first symbol of a 64-group: no term (SPEC 3.2)
+			const bool bit = act && (y > bias);
+			const int Y = __float2int_rn(sd_clamp(y, -8.0f, 8.0f) * 4096.0f);
+			S1i += bit ? Y : 0;
+			S0i += (act && !bit) ? Y : 0;
+			const unsigned long long bal = __ballot(bit);
+			C1 += __popcll(bal);
+			if (lane == 0) {
+				s.chunk[par][1 + 2 * rwave + 8 * h] = (uint32_t)bal;
+				s.chunk[par][2 + 2 * rwave + 8 * h] = (uint32_t)(bal >> 32);
 			}
 		}
-		const float yprev = __shfl_up(y, 1, 64);
-		const bool act = t < K;
-		float e = (yprev - y) * (m - bias);
-		e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
-		int Ei = (act && lane != 0) ? __float2int_rn(e) : 0;     // first symbol of a 64-group: no term (SPEC 3.2)
-		const bool bit = act && (y > bias);
-		const int Y = __float2int_rn(sd_clamp(y, -8.0f, 8.0f) * 4096.0f);
-		int S1i = bit ? Y : 0;
-		int S0i = (act && !bit) ? Y : 0;
-		const unsigned long long bal = __ballot(bit);
 		Ei = wave_sum(Ei);
 		S1i = wave_sum(S1i);
 		S0i = wave_sum(S0i);
-		if (lane == 0) {
-			s.red[par][rwave] = make_int4(Ei, S1i, S0i, __popcll(bal));
-			s.chunk[par][1 + 2 * rwave] = (uint32_t)bal;
-			s.chunk[par][2 + 2 * rwave] = (uint32_t)(bal >> 32);
-		}
+		if (lane == 0) s.red[par][rwave] = make_int4(Ei, S1i, S0i, C1);
 	};
 	// lead wave, after the barrier: append the round's bits, update slicer levels and the PI loop filter
 	auto round_back = [&](int K, int par) {
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		const int S0 = r0.z + r1.z + r2.z + r3.z;
 		const int C1 = r0.w + r1.w + r2.w + r3.w;
 		const int C0 = K - C1;
-		if (t < 9) {
+		if (t < 8 * SPL + 1) {
 			const uint32_t sh = (uint32_t)st.wpos & 31u;
 			const uint32_t w0 = (uint32_t)(st.wpos >> 5);
 			uint32_t vv = 0;
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 						const int64_t limit = (((n0 - 1 - md.nt / 2 - SD_MARGIN) << 16) | 0xFFFF);
 						K_total = (st.t_next <= limit) ? (int)((uint32_t)(limit - st.t_next) / (uint32_t)st.period) + 1 : 0;
 					}
-					K = K_total > SD_ROUND_MAX ? SD_ROUND_MAX : K_total;
+					K = K_total > SPL * SD_ROUND_MAX ? SPL * SD_ROUND_MAX : K_total;
 					K_total -= K;
 					t_next = st.t_next; period = st.period; bias = st.bias;
 					if (lane == 0) {

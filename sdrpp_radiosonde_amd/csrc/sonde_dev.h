@@ -13,7 +13,8 @@
 #define SD_NT(decim)  ((decim) == 4 ? 8 : 16)   // taps in use per row: 3.2 symbols (SPEC 3.2)
 #define SD_NPHASE     32
 #define SD_TAPS_LD    36          // padded leading dimension of the tap table in LDS (16-B aligned rows)
-#define SD_ROUND_MAX  256         // = workgroup size of the demod kernel
+#define SD_ROUND_MAX  256         // symbols per timing-loop round = round lanes of the demod kernel; streams that are not decimated
+#define SD_ROUND_SPL(decim) ((decim) == 1 ? 2 : 1)   // (M10, the 6 kS/s AFSK streams) take two symbols per lane: rounds of <= 512
 #define SD_HIST       64          // discriminator samples carried between submits
 #define SD_MARGIN     4           // look-ahead slack (samples) behind the newest sample, SPEC 3.2
 #define SD_WG         256
@@ -23,7 +24,7 @@ struct SdModem {            // per sonde type, built on the host
 	float   kp;             // proportional gain, Q16 samples per unit error
 	float   ki;             // integral gain
 	int32_t pmin, pmax;     // period clamp
-	int32_t rounds;         // timing-loop rounds per tile: 1, or 2 when a tile can hold > 256 symbols (M10)
+	int32_t rounds;         // timing-loop rounds per tile: 1; 2 for the SRS-C50 6 kS/s stream (822 symbols per tile, rounds of <= 512)
 	int32_t decim;          // IQ boxcar-decimated decim:1 before the discriminator: 4 RS41 (12 kS/s), 2 DFM / iMS-100, 1 M10 (SPEC 3.0)
 	int32_t itile;          // internal samples per 2048-sample input tile = 2048 / decim
 	int32_t nt;             // taps in use per polyphase row: 3.2 symbols = 8 (2.5 samples per symbol) or 16 (5)
