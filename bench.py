@@ -72,7 +72,7 @@ def parse_args():
     ap.add_argument("--ramp-ms", type=float, default=250.0,
                     help="untimed submits for this long before the warmup steps: the GPU idles at 157 MHz and needs ~0.1 s of load "
                          "to reach its 2.35 GHz working clock; a 3-step warmup (1 ms) measures the ramp, not the kernel")
-    ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: 1024, BASELINE configs[1]; with --mix 4096, configs[2])")
     ap.add_argument("--blocks", type=int, default=5, help="headline workload: consecutive blocks of a continuous, seamlessly repeating signal "
                     "held in HBM and cycled through (1: the same block every step; 5 x 96 tiles = 32 frame periods)")
     ap.add_argument("--tiles", type=int, default=96, help="2048-sample tiles per channel per step (96 = 4.096 s)")
@@ -234,6 +234,8 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
     from sdrpp_radiosonde_amd.shard import scatter_iq
     import ctypes
 
+    if args.channels is None:
+        args.channels = 4096 if args.mix else 1024
     C, n = args.channels, args.tiles * 2048
     scatter_ms = None
     types = None

@@ -423,19 +423,52 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		HIPCHK(hipEventRecord(b->ev_xs, b->last_stream));
 		HIPCHK(hipStreamWaitEvent(stream, b->ev_xs, 0));
 	}
-	if (!n_afsk && b->n_classes == 1) {
+	// the framers of one sonde type, behind the demod launch that produced its bits, on that launch's stream
+	// (d_counts: zeroed at creation; every sync kernel rewrites the entry of each channel it owns on every submit)
+	bool framer_launched = false;
+	auto launch_framers = [&](int t, hipStream_t sk) -> int {
+		if (b->chlist[t].empty()) return 0;
+		const uint32_t nch = (uint32_t)b->chlist[t].size();
+		if (t == SONDE_RS41) {
+			if (b->fuse_fec) return 0;             // sync search and FEC ran inside the demod kernel
+			sd_launch_framer_rs41(nch, sk, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_descs,
+				d_frames, d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);
+		} else if (t == SONDE_C50) {
+			sd_launch_framer_c50(nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words, d_frames, d_counts, b->max_frames, b->d_chlist[t]);
+		} else if (t == SONDE_IMET4) {
+			sd_launch_framer_imet(nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words, d_frames, d_counts, b->max_frames, b->d_chlist[t]);
+		} else {
+			sd_launch_framer_other(t, nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
+				t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, d_frames, d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],
+				/* with_sync = */ !b->fuse_fec);        // default: the demod kernel has run the sync search (K4) itself
+		}
+		HIPCHK(hipGetLastError());
+		framer_launched = true;
+		return 0;
+	};
+	const bool one_launch = !n_afsk && b->n_classes == 1;
+	if (one_launch) {
 		sd_launch_demod(iq, b->only_class, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo);
+		HIPCHK(hipGetLastError());
+		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
+		for (int t = 0; t < SONDE_NTYPES; t++) if (launch_framers(t, stream)) return -1;
 	} else {
-		// fork: the class launches are independent (disjoint channels), let them share the GPU
+		// fork: the class launches are independent (disjoint channels), let them share the GPU; each class's frame decoders
+		// follow its demod kernel on the same stream, so that they overlap the other classes' demodulators instead of
+		// waiting for the slowest one (a mixed RS41/M10/DFM batch: 0.368 -> see profiles/r2_notes.md)
 		HIPCHK(hipEventRecord(b->ev_fork, stream));
 		int used = 0;
 		for (int k = 0; k < 3; k++) {
 			if (!b->n_cls[k]) continue;
 			hipStream_t sk = used == 0 ? stream : b->aux[k];
 			if (sk != stream) HIPCHK(hipStreamWaitEvent(sk, b->ev_fork, 0));
-			sd_launch_demod(iq, k == 2 ? 4 : k + 1, b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
+			const int decim = k == 2 ? 4 : k + 1;
+			sd_launch_demod(iq, decim, b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
 				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_cls[k], false, fo);
+			HIPCHK(hipGetLastError());
+			for (int t = 0; t < SONDE_NTYPES; t++)
+				if (t != SONDE_IMET4 && t != SONDE_C50 && b->md[t].decim == decim && launch_framers(t, sk)) return -1;
 			if (sk != stream) { HIPCHK(hipEventRecord(b->ev_join[k], sk)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[k], 0)); }
 			used++;
 		}
@@ -452,40 +485,13 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 					b->d_chlist[t], b->d_astates, t == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
 				sd_launch_demod(false, 1, (uint32_t)nt, stream, rows, nq, (int)(nq / SONDE_TILE),
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[t], true, fo);
+				HIPCHK(hipGetLastError());
+				if (launch_framers(t, stream)) return -1;
 				row0 += nt;
 			}
 		}
-	}
-	HIPCHK(hipGetLastError());
-	if (timed) HIPCHK(hipEventRecord(ev[1], stream));
-	bool framer_launched = false;
-	// d_counts: zeroed at creation; every sync kernel rewrites the entry of each channel it owns on every submit
-	if (!b->chlist[SONDE_RS41].empty() && !b->fuse_fec) {
-		sd_launch_framer_rs41((uint32_t)b->chlist[SONDE_RS41].size(), stream,
-			b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_descs,
-			d_frames, d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);
-		HIPCHK(hipGetLastError());
-		framer_launched = true;
-	}
-	for (int t : { SONDE_DFM09, SONDE_IMS100, SONDE_M10, SONDE_MRZN1 }) {
-		if (b->chlist[t].empty()) continue;
-		sd_launch_framer_other(t, (uint32_t)b->chlist[t].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-			t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, d_frames, d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],
-			/* with_sync = */ !b->fuse_fec);        // default: the demod kernel has run the sync search (K4) itself
-		HIPCHK(hipGetLastError());
-		framer_launched = true;
-	}
-	if (!b->chlist[SONDE_C50].empty()) {
-		sd_launch_framer_c50((uint32_t)b->chlist[SONDE_C50].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-			d_frames, d_counts, b->max_frames, b->d_chlist[SONDE_C50]);
-		HIPCHK(hipGetLastError());
-		framer_launched = true;
-	}
-	if (!b->chlist[SONDE_IMET4].empty()) {
-		sd_launch_framer_imet((uint32_t)b->chlist[SONDE_IMET4].size(), stream, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-			d_frames, d_counts, b->max_frames, b->d_chlist[SONDE_IMET4]);
-		HIPCHK(hipGetLastError());
-		framer_launched = true;
+		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
+		framer_launched = false;               // inside the fork/join region: timed with the demodulators
 	}
 	if (timed) {
 		if (framer_launched) HIPCHK(hipEventRecord(ev[2], stream));     // nothing behind the demod kernel: no third bubble
