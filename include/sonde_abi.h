@@ -213,6 +213,25 @@ int         sonde_chan_read(SondeChannelizer *c, float *bins, float *out48);    
 int         sonde_chan_kernel_ms(SondeChannelizer *c, float *pfb_ms, float *disc_resamp_ms, float *demod_ms, float *framer_ms);
 int         sonde_chan_tables(float *h, float *tw, float *g);
 
+/* ------------------------------------------------------------------ VFO front-end (SURVEY section 8 rows a1 + a2)
+ * The stage between the SDR++ VFO and the decoder in /root/reference/src/main.cpp:55-60, for a batch of channels of one
+ * rate: complex IQ at the sonde type's VFO bandwidth (supportedTypes[], main.hpp:44-52: 10 000 RS41, 15 000 DFM, 20 000
+ * iMS-100 / iMet-4 / SRS-C50 / MRZ-N1, 50 000 M10/M20; 40 000 = a channelizer bin) -> dsp::demod::FM -> dsp::RationalResampler
+ * (24/5, 16/5, 12/5, 24/25, 6/5) -> 48 kS/s FM audio rows, which are the rows sonde_batch_submit() takes from a batch
+ * created with SONDE_INPUT_REAL.  n_in: complex samples per channel, a multiple of the ratio's denominator (5; 25 at
+ * 50 kS/s); a row of n_in samples yields n_in * up / down output samples (sonde_vfo_out_samples). */
+typedef struct SondeVfo SondeVfo;
+int    sonde_vfo_create(uint32_t n_channels, int rate_in, size_t max_in, int device, SondeVfo **out);
+void   sonde_vfo_destroy(SondeVfo *v);
+int    sonde_vfo_ratio(int rate_in, int *up, int *down);
+size_t sonde_vfo_out_samples(const SondeVfo *v, size_t n_in);
+int    sonde_vfo_process(SondeVfo *v, const void *iq_dev, size_t n_in, size_t channel_stride /* complex samples */,
+                         float *out48_dev, size_t out_stride /* floats */, void *stream);
+/* host rows in; the 48 kS/s rows stay on the device (internal buffer, valid until the next call) */
+int    sonde_vfo_process_host(SondeVfo *v, const void *iq_host, size_t n_in, size_t channel_stride,
+                              const float **out48_dev, size_t *out_stride);
+int    sonde_vfo_taps(int rate_in, float *g /* up * 16 */);      /* parity-test introspection */
+
 /* post-FEC derived quantities, as /root/reference/src/decode/decoder.hpp:132-174 computes them */
 float sonde_dewpt(float temp, float rh);
 float sonde_altitude_to_pressure(float alt);

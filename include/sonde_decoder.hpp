@@ -173,8 +173,12 @@ private:
 // BASELINE.json's north_star names ("dsp::stream<dsp::complex_t> in, SondeData callback out"): in the reference the
 // VFO hands complex IQ to dsp::demod::FM, whose output goes through the resampler into the decoder block
 // (/root/reference/src/main.cpp:55-68); here FM discriminator, timing recovery, framing and FEC all run on the GPU, so
-// the host only forwards the VFO's samples.  The VFO must run at 48 kS/s (createVFO(..., bandwidth = bw,
-// sampleRate = 48000, ...)); buffers may have any length, samples are interleaved I, Q.
+// the host only forwards the VFO's samples.  Two input rates are taken: 48 kS/s (createVFO(..., bandwidth = bw,
+// sampleRate = 48000, ...), INTEGRATION.md: the batch API's native input, the FM discriminator runs inside the demod
+// kernel), or the reference's own VFO rate for the sonde type (sampleRate = supportedTypes[i].bandwidth, main.hpp:44-52:
+// 10/15/20/50 kS/s), in which case the VFO front-end (sonde_vfo_*, vfo.hip: discriminator + rational resampler,
+// main.cpp:57-60) turns it into the 48 kS/s FM audio the decoder takes.  Buffers may have any length, samples are
+// interleaved I, Q.
 class IqStreamDecoder {
 public:
 	typedef void (*Callback)(FullData *data, void *ctx);
@@ -188,17 +192,32 @@ public:
 	bool init(int sonde_type, int samplerate, Callback cb, void *ctx, int device = 0, uint32_t flags = 0)
 	{
 		deinit();
-		if (samplerate != 48000) return false;
 		const uint8_t t = (uint8_t)sonde_type;
+		const bool afsk = sonde_type == SONDE_IMET4 || sonde_type == SONDE_C50;
 		SondeBatchConfig cfg = {};
 		cfg.n_channels = 1;
 		cfg.types = &t;
-		cfg.max_samples = kMaxSamples;
-		cfg.input_kind = SONDE_INPUT_IQ;
 		cfg.device = device;
 		cfg.flags = flags;
-		if (sonde_batch_create(&cfg, &m_batch) != 0) return false;
-		m_granule = (sonde_type == SONDE_IMET4 || sonde_type == SONDE_C50) ? 8 * (size_t)SONDE_TILE : (size_t)SONDE_TILE;
+		m_up = m_down = 1;
+		if (samplerate == 48000) {
+			cfg.max_samples = kMaxSamples;
+			cfg.input_kind = SONDE_INPUT_IQ;
+			m_granule = afsk ? 8 * (size_t)SONDE_TILE : (size_t)SONDE_TILE;
+			m_max_in = kMaxSamples;
+		} else {
+			// VFO-rate input: whole decoder tiles come out of input blocks of (3 tiles | 24 tiles with AFSK) * down / up samples
+			if (sonde_vfo_ratio(samplerate, &m_up, &m_down) != 0) return false;
+			const size_t out_granule = (afsk ? 24 : 3) * (size_t)SONDE_TILE;
+			m_granule = out_granule * (size_t)m_down / (size_t)m_up;
+			m_max_in = ((size_t)kMaxSamples / m_granule) * m_granule;
+			if (m_max_in == 0) m_max_in = m_granule;
+			if (m_max_in > kMaxSamples) return false;
+			cfg.max_samples = (uint32_t)(m_max_in / (size_t)m_down * (size_t)m_up);
+			cfg.input_kind = SONDE_INPUT_REAL;
+			if (sonde_vfo_create(1, samplerate, m_max_in, device, &m_vfo) != 0) return false;
+		}
+		if (sonde_batch_create(&cfg, &m_batch) != 0) { deinit(); return false; }
 		m_cb = cb;
 		m_ctx = ctx;
 		m_data = FullData();
@@ -210,6 +229,8 @@ public:
 	{
 		if (m_batch) sonde_batch_destroy(m_batch);
 		m_batch = nullptr;
+		if (m_vfo) sonde_vfo_destroy(m_vfo);
+		m_vfo = nullptr;
 	}
 
 	// One stream buffer of `count` complex samples (what dsp::stream<dsp::complex_t>::read() handed out; dsp::complex_t
@@ -218,14 +239,20 @@ public:
 	{
 		int fired = 0;
 		while (count > 0) {
-			const size_t take = std::min((size_t)count, (size_t)kMaxSamples - m_n);
+			const size_t take = std::min((size_t)count, m_max_in - m_n);
 			std::memcpy(m_buf + 2 * m_n, iq, take * 2 * sizeof(float));
 			m_n += take;
 			iq += 2 * take;
 			count -= (int)take;
 			const size_t n = (m_n / m_granule) * m_granule;
 			if (n == 0) continue;
-			if (sonde_batch_submit_host(m_batch, m_buf, n, n) != 0) { m_n = 0; return -1; }
+			if (m_vfo) {
+				const float *rows = nullptr;
+				size_t stride = 0;
+				if (sonde_vfo_process_host(m_vfo, m_buf, n, n, &rows, &stride) != 0 ||
+				    sonde_batch_submit(m_batch, rows, n / (size_t)m_down * (size_t)m_up, stride, nullptr) != 0) { m_n = 0; return -1; }
+				if (sonde_batch_sync(m_batch) < 0) { m_n = 0; return -1; }     // the rows are reused by the next block
+			} else if (sonde_batch_submit_host(m_batch, m_buf, n, n) != 0) { m_n = 0; return -1; }
 			std::memmove(m_buf, m_buf + 2 * n, (m_n - n) * 2 * sizeof(float));
 			m_n -= n;
 			long k;
@@ -249,6 +276,9 @@ public:
 private:
 	static const uint32_t kMaxSamples = 16 * SONDE_TILE;
 	SondeBatch *m_batch = nullptr;
+	SondeVfo *m_vfo = nullptr;          // VFO-rate input only
+	int m_up = 1, m_down = 1;
+	size_t m_max_in = kMaxSamples;
 	Callback m_cb = nullptr;
 	void *m_ctx = nullptr;
 	FullData m_data;

@@ -41,13 +41,14 @@ void or_chan_twiddles(float *tw /* 2*256, (re, im) */)
 	}
 }
 
-/* 6/5 resampler prototype: Blackman-windowed sinc at 240 kHz, cutoff 18 kHz, 16 taps per phase;
- * g[p][t] = 6 * proto[6 t + p] (unit DC gain per phase after normalisation) */
-void or_chan_resamp_taps(float *g /* 6*16 */)
+/* Rational resampler prototype (polyphase, `up` phases of OR_RS_T taps): Blackman-windowed sinc at up * rate_in with the
+ * given cutoff; g[p][t] = proto[up t + p], every phase normalised to unit DC gain.  The channelizer's 6/5 stage is
+ * (6, 240 kHz, 18 kHz); the VFO front-end's ratios follow below. */
+void or_resamp_taps(int up, double fs_up_hz, double cutoff_hz, float *g /* up * OR_RS_T */)
 {
-	const int N = OR_RS_L * OR_RS_T;
-	const double fc = 18000.0 / 240000.0;
-	double tmp[OR_RS_L * OR_RS_T];
+	const int N = up * OR_RS_T;
+	const double fc = cutoff_hz / fs_up_hz;
+	double *tmp = malloc((size_t)N * sizeof(double));
 	for (int i = 0; i < N; i++) {
 		const double t = (double)i - 0.5 * (double)(N - 1);
 		const double x = (double)i / (double)(N - 1);
@@ -55,11 +56,63 @@ void or_chan_resamp_taps(float *g /* 6*16 */)
 		const double s = (t == 0.0) ? 2.0 * fc : sin(2.0 * CH_PI * fc * t) / (CH_PI * t);
 		tmp[i] = s * w;
 	}
-	for (int p = 0; p < OR_RS_L; p++) {
+	for (int p = 0; p < up; p++) {
 		double sum = 0.0;
-		for (int t = 0; t < OR_RS_T; t++) sum += tmp[t * OR_RS_L + p];
-		for (int t = 0; t < OR_RS_T; t++) g[p * OR_RS_T + t] = (float)(tmp[t * OR_RS_L + p] / sum);
+		for (int t = 0; t < OR_RS_T; t++) sum += tmp[t * up + p];
+		for (int t = 0; t < OR_RS_T; t++) g[p * OR_RS_T + t] = (float)(tmp[t * up + p] / sum);
 	}
+	free(tmp);
+}
+void or_chan_resamp_taps(float *g /* 6*16 */) { or_resamp_taps(OR_RS_L, 240000.0, 18000.0, g); }
+
+/* ---- VFO front-end (SURVEY 8 rows a1 + a2 at the reference's own rates): what sits between the VFO and the decoder in
+ * /root/reference/src/main.cpp:55-60 -- IQ at the sonde type's VFO bandwidth (supportedTypes[], main.hpp:44-52: 10, 15, 20
+ * or 50 kS/s) -> dsp::demod::FM -> dsp::RationalResampler to 48 kS/s (24/5, 16/5, 12/5, 24/25).  Cutoff: 0.45 of the
+ * lower of the two rates.  One channel; n_in % down == 0; returns the output samples written (n_in * up / down). */
+struct OrVfo {
+	int up, down;
+	float *g;
+	float iq_last[2];
+	float dhist[OR_RS_T];
+};
+int or_vfo_ratio(int rate_in, int *up, int *down, int *cutoff_hz)
+{
+	switch (rate_in) {
+	case 10000: *up = 24; *down = 5;  *cutoff_hz = 4500;  return 0;
+	case 15000: *up = 16; *down = 5;  *cutoff_hz = 6750;  return 0;
+	case 20000: *up = 12; *down = 5;  *cutoff_hz = 9000;  return 0;
+	case 40000: *up = 6;  *down = 5;  *cutoff_hz = 18000; return 0;      /* a channelizer bin */
+	case 50000: *up = 24; *down = 25; *cutoff_hz = 21600; return 0;
+	}
+	return -1;
+}
+OrVfo *or_vfo_new(int rate_in)
+{
+	int up, down, fc;
+	if (or_vfo_ratio(rate_in, &up, &down, &fc)) return NULL;
+	OrVfo *v = calloc(1, sizeof(*v));
+	v->up = up; v->down = down;
+	v->g = malloc((size_t)up * OR_RS_T * sizeof(float));
+	or_resamp_taps(up, (double)rate_in * up, (double)fc, v->g);
+	return v;
+}
+void or_vfo_free(OrVfo *v) { if (v) { free(v->g); free(v); } }
+size_t or_vfo_process(OrVfo *v, const float *iq, size_t n_in, float *out48)
+{
+	const size_t n_out = n_in * (size_t)v->up / (size_t)v->down;
+	float *d = malloc((OR_RS_T + n_in) * sizeof(float));
+	memcpy(d, v->dhist, OR_RS_T * sizeof(float));
+	or_discriminate(iq, n_in, d + OR_RS_T, v->iq_last);
+	for (size_t j = 0; j < n_out; j++) {
+		const size_t i0 = (j * (size_t)v->down) / (size_t)v->up;
+		const int p = (int)((j * (size_t)v->down) % (size_t)v->up);
+		float acc = 0.0f;
+		for (int t = 0; t < OR_RS_T; t++) acc = fmaf(v->g[p * OR_RS_T + t], d[OR_RS_T + i0 - t], acc);
+		out48[j] = acc;
+	}
+	memcpy(v->dhist, d + n_in, OR_RS_T * sizeof(float));
+	free(d);
+	return n_out;
 }
 
 /* in-place radix-2 decimation-in-time FFT, 512 points, bit-reversed load; each butterfly:

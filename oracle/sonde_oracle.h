@@ -145,6 +145,13 @@ typedef struct OrChan OrChan;
 void    or_chan_proto(float *h);
 void    or_chan_twiddles(float *tw);
 void    or_chan_resamp_taps(float *g);
+void    or_resamp_taps(int up, double fs_up_hz, double cutoff_hz, float *g);
+/* VFO front-end: IQ at the sonde type's VFO rate -> discriminator -> rational resampler -> 48 kS/s (main.cpp:55-60) */
+typedef struct OrVfo OrVfo;
+int     or_vfo_ratio(int rate_in, int *up, int *down, int *cutoff_hz);
+OrVfo  *or_vfo_new(int rate_in);
+void    or_vfo_free(OrVfo *v);
+size_t  or_vfo_process(OrVfo *v, const float *iq, size_t n_in, float *out48);
 void    or_fft512(float *re, float *im, const float *tw);
 OrChan *or_chan_new(void);
 void    or_chan_free(OrChan *c);

@@ -60,6 +60,7 @@ ABI_SYMBOLS = [
     "sonde_ptu_open", "sonde_ptu_close", "sonde_ptu_add_point",
     "sonde_chan_create", "sonde_chan_destroy", "sonde_chan_samples_per_submit", "sonde_chan_submit", "sonde_chan_batch",
     "sonde_chan_read", "sonde_chan_tables", "sonde_chan_kernel_ms",
+    "sonde_vfo_create", "sonde_vfo_destroy", "sonde_vfo_ratio", "sonde_vfo_out_samples", "sonde_vfo_process", "sonde_vfo_process_host", "sonde_vfo_taps",
 ] + [f"{x}_{fn}" for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1")
      for fn in ("decoder_init", "decoder_deinit", "decode")]
 
@@ -153,6 +154,16 @@ def load() -> C.CDLL:
     L.sonde_chan_batch.restype = vp
     L.sonde_chan_read.argtypes = [vp, vp, vp]
     L.sonde_chan_tables.argtypes = [vp, vp, vp]
+    if hasattr(L, "sonde_vfo_create"):
+        L.sonde_vfo_create.argtypes = [C.c_uint32, C.c_int, C.c_size_t, C.c_int, C.POINTER(vp)]
+        L.sonde_vfo_destroy.argtypes = [vp]
+        L.sonde_vfo_destroy.restype = None
+        L.sonde_vfo_ratio.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.sonde_vfo_out_samples.argtypes = [vp, C.c_size_t]
+        L.sonde_vfo_out_samples.restype = C.c_size_t
+        L.sonde_vfo_process.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, vp]
+        L.sonde_vfo_process_host.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.sonde_vfo_taps.argtypes = [C.c_int, vp]
     f = C.c_float
     L.sonde_gpx_open.restype = vp
     L.sonde_gpx_open.argtypes = [C.c_char_p]

@@ -207,3 +207,59 @@ def get_taps(sonde_type: int) -> np.ndarray:
     if _lib.load().sonde_get_taps(sonde_type, out.ctypes.data_as(C.c_void_p)) != 0:
         raise SondeError(_lib.last_error())
     return out
+
+
+# the reference's VFO bandwidth = sample rate per sonde type (/root/reference/src/main.hpp:44-52)
+VFO_RATE = {0: 10000, 1: 15000, 2: 20000, 3: 50000, 4: 20000, 5: 20000, 6: 20000}
+
+
+class SondeVfo:
+    """VFO front-end (SURVEY 8 a1 + a2): IQ at the sonde type's VFO rate -> discriminator -> rational resampler -> 48 kS/s
+    FM audio rows for a SondeBatch created with INPUT_REAL (/root/reference/src/main.cpp:55-60)."""
+
+    def __init__(self, n_channels: int, rate_in: int, max_in: int, device: int = 0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        if self.L.sonde_vfo_create(n_channels, rate_in, max_in, device, C.byref(h)) != 0:
+            raise SondeError(_lib.last_error() or "sonde_vfo_create failed")
+        self.h = h
+        self.n_channels, self.rate_in, self.max_in = n_channels, rate_in, max_in
+        up, down = C.c_int(), C.c_int()
+        self.L.sonde_vfo_ratio(rate_in, C.byref(up), C.byref(down))
+        self.up, self.down = up.value, down.value
+
+    def out_samples(self, n_in: int) -> int:
+        return int(self.L.sonde_vfo_out_samples(self.h, n_in))
+
+    def process(self, iq, out=None, stream: int | None = None):
+        """iq: CUDA float32 tensor [C, n_in, 2] (rows may be strided); returns the [C, n_out] float32 rows."""
+        import torch
+        assert iq.is_cuda and iq.dtype == torch.float32 and iq.shape[0] == self.n_channels and iq.shape[2] == 2 and iq.stride(1) == 2
+        n_in = iq.shape[1]
+        n_out = self.out_samples(n_in)
+        if out is None:
+            out = torch.empty((self.n_channels, n_out), dtype=torch.float32, device=iq.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(iq.device).cuda_stream
+        if self.L.sonde_vfo_process(self.h, C.c_void_p(iq.data_ptr()), n_in, iq.stride(0) // 2, C.c_void_p(out.data_ptr()), out.stride(0),
+                                    C.c_void_p(stream)) != 0:
+            raise SondeError(_lib.last_error() or "sonde_vfo_process failed")
+        return out
+
+    def taps(self) -> np.ndarray:
+        g = np.zeros((self.up, 16), dtype=np.float32)
+        if self.L.sonde_vfo_taps(self.rate_in, g.ctypes.data_as(C.c_void_p)) != 0:
+            raise SondeError(_lib.last_error() or "sonde_vfo_taps failed")
+        return g
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sonde_vfo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

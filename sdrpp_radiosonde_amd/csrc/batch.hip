@@ -29,6 +29,7 @@ static int fail(const char *what, hipError_t e = hipSuccess)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(#x, e_); } while (0)
 
 extern "C" const char *sonde_last_error(void) { return g_err.c_str(); }
+int sd_fail(const char *what, hipError_t e) { return fail(what, e); }     // for the other host objects of the library (vfo.hip)
 extern "C" const char *sonde_version(void) { return "sonde_mi355 0.1 (gfx950)"; }
 
 // ---------------------------------------------------------------- modem table (SPEC)

@@ -37,3 +37,6 @@ void sd_launch_framer_other(int type, uint32_t n_list, hipStream_t stream,
 	const SdChanState *states, SdFramerState *fstates, const uint32_t *bitring, uint32_t ring_words,
 	const uint8_t *g64, void *descs, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist,
 	bool with_sync /* false: the demod kernel has listed the frames already */);
+
+// sets the text sonde_last_error() returns; returns -1
+int sd_fail(const char *what, hipError_t e = hipSuccess);

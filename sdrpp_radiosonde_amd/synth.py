@@ -417,7 +417,7 @@ def make_rs41_batch(n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: 
                     device: str | torch.device = "cpu", first_channel: int = 0, extended: bool = False,
                     invert: bool = False, sgp: bool = False, **mod_kw) -> SynthBatch:
     baud = 4800.0
-    nbits = int(n_samples * baud / FS) + 16
+    nbits = int(n_samples * baud / mod_kw.get("fs", FS)) + 16       # fs=...: IQ at another rate (the VFO front-end's input)
     channels = np.arange(first_channel, first_channel + n_channels)
     bits, frames = rs41_bitstreams(seed, channels, nbits, extended, sgp=sgp)
     iq, cfo, tau, amp = gfsk_modulate(bits, n_samples, baud, seed=seed + first_channel, ebn0_db=ebn0_db,
@@ -869,7 +869,7 @@ def make_batch(sonde_type: int, n_channels: int, n_samples: int, *, seed: int = 
         return make_rs41_batch(n_channels, n_samples, seed=seed, ebn0_db=ebn0_db, device=device,
                                first_channel=first_channel, invert=invert, **mod_kw)
     baud = SONDE_BAUD[sonde_type]
-    nchips = int(n_samples * baud / FS) + 16
+    nchips = int(n_samples * baud / mod_kw.get("fs", FS)) + 16
     channels = np.arange(first_channel, first_channel + n_channels)
     chips, frames = chip_streams(sonde_type, seed, channels, nchips, m20=m20)
     iq, cfo, tau, amp = gfsk_modulate(chips, n_samples, baud, seed=seed + first_channel + 1000 * sonde_type,
@@ -990,7 +990,7 @@ def afsk_modulate(bits: np.ndarray, n_samples: int, *, seed: int = 0, snr_db: fl
 
 def make_imet_batch(n_channels: int, n_samples: int, *, seed: int = 1, snr_db: float = 30.0,
                     device: str | torch.device = "cpu", first_channel: int = 0, xdata: bool = False, **mod_kw) -> SynthBatch:
-    nbits = int(n_samples * IMET_BAUD / FS) + 16
+    nbits = int(n_samples * IMET_BAUD / mod_kw.get("fs", FS)) + 16
     channels = np.arange(first_channel, first_channel + n_channels)
     bits, frames = imet_bitstreams(seed, channels, nbits, xdata)
     iq, cfo, tau, amp = afsk_modulate(bits, n_samples, seed=seed + first_channel, snr_db=snr_db, device=device, **mod_kw)

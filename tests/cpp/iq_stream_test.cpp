@@ -1,5 +1,6 @@
 // iq_stream_test.cpp -- drives sonde::IqStreamDecoder (B3: complex IQ stream in, FullData callback out) on a GPU:
-//   iq_stream_test <iq.bin> <sonde_type> <chunk>      iq.bin: float32 [n][2] at 48 kS/s; fed in buffers of <chunk> samples
+//   iq_stream_test <iq.bin> <sonde_type> <chunk> [rate]     iq.bin: float32 [n][2] at `rate` (48 kS/s, or the reference's VFO
+//   rate for the type: 10/15/20/50 kS/s); fed in buffers of <chunk> samples
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -26,7 +27,8 @@ int main(int argc, char **argv)
 	long calls = 0;
 	sonde::IqStreamDecoder dec;
 	if (dec.init(0, 44100, on_data, &calls)) { printf("ERROR accepted 44100\n"); return 1; }
-	if (!dec.init(atoi(argv[2]), 48000, on_data, &calls)) { printf("ERROR init: %s\n", sonde_last_error()); return 1; }
+	const int rate = argc > 4 ? atoi(argv[4]) : 48000;
+	if (!dec.init(atoi(argv[2]), rate, on_data, &calls)) { printf("ERROR init: %s\n", sonde_last_error()); return 1; }
 	long fired = 0;
 	for (size_t off = 0; off < x.size() / 2; off += (size_t)chunk) {
 		const int k = dec.process(x.data() + 2 * off, (int)std::min((size_t)chunk, x.size() / 2 - off));

@@ -76,6 +76,13 @@ def lib():
     L.or_chan_proto.argtypes = [f32p]
     L.or_chan_twiddles.argtypes = [f32p]
     L.or_chan_resamp_taps.argtypes = [f32p]
+    L.or_vfo_new.restype = C.c_void_p
+    L.or_vfo_new.argtypes = [C.c_int]
+    L.or_vfo_free.argtypes = [C.c_void_p]
+    L.or_vfo_process.restype = C.c_size_t
+    L.or_vfo_process.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p]
+    L.or_vfo_ratio.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.or_resamp_taps.argtypes = [C.c_int, C.c_double, C.c_double, f32p]
     L.or_fft512.argtypes = [f32p, f32p, f32p]
     L.or_dewpt.restype = C.c_float
     L.or_dewpt.argtypes = [C.c_float, C.c_float]
@@ -169,3 +176,35 @@ class Channel:
             self.L.or_channel_free(self.h)
         except Exception:
             pass
+
+
+class Vfo:
+    """One channel of the oracle's VFO front-end (or_chan.c or_vfo_*): IQ at the VFO rate -> 48 kS/s FM audio."""
+
+    def __init__(self, rate_in: int):
+        self.L = lib()
+        self.h = self.L.or_vfo_new(rate_in)
+        assert self.h, rate_in
+        up, down, fc = C.c_int(), C.c_int(), C.c_int()
+        self.L.or_vfo_ratio(rate_in, C.byref(up), C.byref(down), C.byref(fc))
+        self.up, self.down, self.cutoff = up.value, down.value, fc.value
+        self.rate_in = rate_in
+
+    def process(self, iq: np.ndarray) -> np.ndarray:
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        n_in = iq.shape[0]
+        out = np.zeros(n_in * self.up // self.down, dtype=np.float32)
+        n = self.L.or_vfo_process(self.h, fptr(iq), n_in, fptr(out))
+        assert n == out.shape[0]
+        return out
+
+    def taps(self) -> np.ndarray:
+        g = np.zeros((self.up, 16), dtype=np.float32)
+        self.L.or_resamp_taps(self.up, float(self.rate_in) * self.up, float(self.cutoff), fptr(g))
+        return g
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.or_vfo_free(self.h)
+            self.h = None
+

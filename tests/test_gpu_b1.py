@@ -232,3 +232,42 @@ def test_b3_iq_stream_decoder_cpp(tmp_path, oracle, chunk):
     assert len(cbs) == nfrag >= 12
     assert re.search(r"serial=(\S+)", cbs[-1]).group(1) == "S0000000"
     assert abs(float(re.search(r"lat=(\S+)", cbs[-1]).group(1)) - 47.0) < 0.01
+
+
+@pytest.mark.parametrize("stype,rate,chunk", [(0, 10000, 1000), (3, 50000, 4096), (1, 15000, 777)])
+def test_b3_iq_stream_decoder_vfo_rate_cpp(tmp_path, oracle, stype, rate, chunk):
+    """B3 at the reference's own VFO rate (sampleRate = supportedTypes[i].bandwidth, /root/reference/src/main.hpp:44-52,
+    main.cpp:55-60): IqStreamDecoder runs the VFO front-end (FM + rational resampler on the GPU) in front of the decoder.
+    Callbacks == fragments of the oracle chain or_vfo -> or_channel(real) through the stateful parser."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "iq_stream_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "iq_stream_test.cpp"), "-o", exe,
+                           "-L", libdir, "-l:libsonde_mi355.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    up, down = {10000: (24, 5), 15000: (16, 5), 50000: (24, 25)}[rate]
+    n_in = 6144 * 40 * down // up
+    sb = synth.make_batch(stype, 1, n_in, seed=91 + stype, ebn0_db=24.0, fs=float(rate), cfo_max_hz=300.0)
+    x = sb.iq.numpy()[0]
+    path = str(tmp_path / "iq.bin")
+    x.tofile(path)
+    out = subprocess.check_output([exe, path, str(stype), str(chunk), str(rate)], text=True)
+    assert "ERROR" not in out, out[-1500:]
+    cbs = [l for l in out.splitlines() if l.startswith("CB ")]
+    # the adaptor decodes whole input granules only (3 tiles of output); feed the oracle the same prefix
+    gran = 6144 * down // up
+    n_used = (n_in // gran) * gran
+    vo, ch = oracle.Vfo(rate), oracle.Channel(stype, 0)
+    ch.feed(vo.process(x[:n_used]), is_iq=False)
+    L = _lib.load()
+    h = L.sonde_parser_create(stype)
+    o = (_lib.SondeData * 8)()
+    nfrag = 0
+    for f in ch.frames():
+        fr = _lib.SondeFrame.from_buffer_copy(f.tobytes())
+        nfrag += L.sonde_parser_feed(h, C.byref(fr), o, 8)
+    L.sonde_parser_destroy(h)
+    assert len(cbs) == nfrag >= 3, (len(cbs), nfrag)
+
