@@ -80,11 +80,13 @@ def parse_args():
     ap.add_argument("--cpu-channels", type=int, default=0, help="channels of the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time spent on the all-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--mix", action="store_true", help="BASELINE configs[2]: sonde type = (RS41, M10, DFM09)[channel % 3] (not the headline workload)")
+    ap.add_argument("--mix", action="store_true", help="BASELINE configs[2]: sonde type = (RS41, M10, DFM09)[channel %% 3] (not the headline workload)")
     ap.add_argument("--sonde-type", type=int, default=0, help="all channels of this SONDE_* type (1 DFM09, 2 iMS-100, 3 M10; not the headline workload)")
     ap.add_argument("--wideband", action="store_true", help="BASELINE configs[3]: 10 MS/s IQ -> 512-bin channelizer -> per-bin demod+FEC")
     ap.add_argument("--wb-streams", type=int, default=1, help="--wideband: independent 10 MS/s streams processed per step")
-    ap.add_argument("--time-every", type=int, default=8, help="kernel-timing events on every n-th timed step (1: all)")
+    ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
+                    "4 for runs of fewer than 64 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
+                    "(profiles/r2_notes.md), inside the timed region: every 8th costs 0.6 %% of the step")
     ap.add_argument("--flags", type=int, default=0, help="SondeBatchConfig.flags (1: RS41 wide, 2: FEC as its own kernel)")
     ap.add_argument("--stride-pad", type=int, default=0, help="experiment: extra samples between channels in HBM")
     ap.add_argument("--scatter", action="store_true", help="ingest on rank 0 and scatter IQ shards over RCCL before timing")
@@ -236,6 +238,8 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
 
     if args.channels is None:
         args.channels = 4096 if args.mix else 1024
+    if args.time_every is None:
+        args.time_every = 8 if args.steps >= 64 else 4
     C, n = args.channels, args.tiles * 2048
     scatter_ms = None
     types = None
