@@ -19,6 +19,13 @@
 #include <deque>
 #include <memory>
 
+// Events that only order streams of this device, or time kernels on it, need no system-scope release (a cache write-back
+// towards the host): hipEventDisableSystemFence.  ev_done is what the host waits on before it reads frames: it keeps the fence.
+#ifndef SD_EV_FLAGS
+#define SD_EV_FLAGS hipEventDisableSystemFence
+#endif
+#define SD_EV_TIMING (SD_EV_FLAGS)
+#define SD_EV_ORDER  (hipEventDisableTiming | SD_EV_FLAGS)
 static thread_local std::string g_err;
 static int fail(const char *what, hipError_t e = hipSuccess)
 {
@@ -353,7 +360,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			CHK(hipMemcpy(b->d_fo2[k], &fo, sizeof(fo), hipMemcpyHostToDevice));
 			CHK(hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming));
 		}
-		CHK(hipEventCreateWithFlags(&b->ev_xs, hipEventDisableTiming));
+		CHK(hipEventCreateWithFlags(&b->ev_xs, SD_EV_ORDER));
 	}
 	// initial channel state
 	std::vector<SdChanState> st(C);
@@ -384,12 +391,12 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty())
 			CHK(hipMemcpy(b->d_chlist[t], b->chlist[t].data(), b->chlist[t].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) CHK(hipEventCreate(&b->ev[i]));
+	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) CHK(hipEventCreateWithFlags(&b->ev[i], SD_EV_TIMING));
 	if (need_lists) {
-		CHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+		CHK(hipEventCreateWithFlags(&b->ev_fork, SD_EV_ORDER));
 		for (int k = 0; k < 3; k++) {
 			CHK(hipStreamCreateWithFlags(&b->aux[k], hipStreamNonBlocking));
-			CHK(hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming));
+			CHK(hipEventCreateWithFlags(&b->ev_join[k], SD_EV_ORDER));
 		}
 	}
 #undef CHK

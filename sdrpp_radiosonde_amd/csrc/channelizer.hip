@@ -312,7 +312,7 @@ extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submi
 	     hipMemcpy(c->d_h, h.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_tw, tw.data(), CH_M * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_g, g.data(), RS_UP * RS_TAPS * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-	for (int i = 0; i < 3 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+	for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence) == hipSuccess;     // timing only, same device
 	if (!ok) { sonde_chan_destroy(c); return -1; }
 	*out = c;
 	return 0;
