@@ -199,7 +199,9 @@ float sonde_ims100_temp(uint32_t f, float c0, float c1, float c2);
  * 10 MS/s complex IQ -> 512-bin polyphase channelizer (19531.25 Hz spacing, 40 kS/s per bin) -> per-bin FM
  * discriminator -> 6/5 rational resampler -> 48 kS/s -> the decoder of the bin's sonde type: the reference's
  * VFO -> dsp::demod::FM -> RationalResampler -> Decoder chain (/root/reference/src/main.cpp:55-68) for every
- * bin at once.  One submit takes blocks_per_submit * 1 280 000 wideband samples (device pointer, complex64). */
+ * bin at once.  One submit takes blocks_per_submit * 1 280 000 wideband samples (device pointer, complex64, 16-byte
+ * aligned); the filter bank reads the block in place, so it must stay untouched until the submit's kernels have run
+ * (stream order, as for sonde_batch_submit). */
 typedef struct SondeChannelizer SondeChannelizer;
 int         sonde_chan_create(const uint8_t *types /* 512 entries or NULL = RS41 */, uint32_t blocks_per_submit /* 1..2 */,
                               int device, SondeChannelizer **out);

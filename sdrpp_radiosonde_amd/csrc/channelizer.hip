@@ -40,7 +40,7 @@
 #define PFB_FB   (CH_M + CH_M / 8)                    // FFT buffer per wave: one pad element per 8 (bank spread)
 #define PFB_OT   (PFB_S + 1)                          // output tile row stride (float2)
 static_assert(PFB_S * PFB_FB <= PFB_WIN && CH_M * PFB_OT <= PFB_WIN, "the FFT buffers and the output tile alias the window");
-static_assert(PFB_WIN % 2 == 0 && (CH_D * sizeof(float2)) % 16 == 0, "16-byte staging loads");
+static_assert(PFB_WIN % 2 == 0 && CH_H % 2 == 0 && (PFB_WIN - CH_H) % 2 == 0 && (CH_D * sizeof(float2)) % 16 == 0, "16-byte staging loads");
 
 __device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
 {
@@ -52,23 +52,31 @@ __device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
 }
 __device__ __forceinline__ int pfb_pad(int i) { return i + (i >> 3); }
 
-__global__ __launch_bounds__(64 * PFB_S) void sd_pfb_kernel(const float2 *__restrict__ wbuf, const float *__restrict__ h,
+// The stream in front of the block (the last CH_H samples of the previous submit) comes from hist_in; the last workgroup
+// saves this block's tail to hist_out (the other buffer of a ping-pong pair: the first workgroups of this launch still
+// read hist_in).  No staging copy of the block and no history roll: a submit is three kernels (was: copy, PFB,
+// discriminator + resampler, copy, decoder -- the two copies were 14 of 70 us).
+__global__ __launch_bounds__(64 * PFB_S) void sd_pfb_kernel(const float2 *__restrict__ iq, const float2 *__restrict__ hist_in,
+                                                         float2 *__restrict__ hist_out, const float *__restrict__ h,
                                                          const float2 *__restrict__ tw, float2 *__restrict__ bins, uint32_t n_steps)
 {
 	__shared__ __attribute__((aligned(16))) float2 s_x[PFB_WIN];
 	__shared__ float2 s_tw[CH_M / 2];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t m0 = blockIdx.x * PFB_S;
-	{	// 1. stage the window (16-byte loads; wbuf + m0*250 samples is 16-byte aligned) and the twiddles
+	{	// 1. stage the window (16-byte loads; iq + m0*250 samples is 16-byte aligned, CH_H is even) and the twiddles:
+		// window sample w is stream sample m0*250 + w - CH_H of this block, negative = history.
 		// all loads first, then all LDS stores: one memory round trip per workgroup instead of one per loop iteration
-		const float4 *src = reinterpret_cast<const float4 *>(wbuf + (size_t)m0 * CH_D);
+		const long p0 = (long)m0 * CH_D - CH_H;                       // stream position of window sample 0 (even)
+		const float4 *src_iq = reinterpret_cast<const float4 *>(iq) + p0 / 2;       // (p0 < 0: indexed only where p0/2 + i >= 0)
+		const float4 *src_h = reinterpret_cast<const float4 *>(hist_in) + (CH_H + p0) / 2;
 		float4 *dst = reinterpret_cast<float4 *>(s_x);
 		constexpr int NQ = (PFB_WIN / 2 + 64 * PFB_S - 1) / (64 * PFB_S);
 		float4 tmp[NQ];
 #pragma unroll
 		for (int q = 0; q < NQ; q++) {
 			const int i = tid + 64 * PFB_S * q;
-			tmp[q] = i < PFB_WIN / 2 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+			tmp[q] = i < PFB_WIN / 2 ? (p0 + 2 * (long)i < 0 ? src_h[i] : src_iq[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
 		}
 		const float2 twv = tid < CH_M / 2 ? tw[tid] : make_float2(0.f, 0.f);
 #pragma unroll
@@ -84,6 +92,11 @@ __global__ __launch_bounds__(64 * PFB_S) void sd_pfb_kernel(const float2 *__rest
 #pragma unroll
 	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
 	__syncthreads();
+	if (blockIdx.x == gridDim.x - 1) {     // the last CH_H samples of [history | block] are the next submit's history
+		const float4 *tail = reinterpret_cast<const float4 *>(s_x + (PFB_WIN - CH_H));
+		float4 *ho = reinterpret_cast<float4 *>(hist_out);
+		for (int i = tid; i < CH_H / 2; i += 64 * PFB_S) ho[i] = tail[i];
+	}
 	float2 v[PFB_S / 2];
 #pragma unroll
 	for (int q = 0; q < PFB_S / 2; q++) {
@@ -218,11 +231,11 @@ struct SondeChannelizer {
 	int device = 0;
 	uint32_t n_steps = 0;
 	SondeBatch *batch = nullptr;
-	float2 *d_wbuf = nullptr, *d_bins = nullptr, *d_tw = nullptr, *d_iqlast = nullptr;
+	float2 *d_hist[2] = {}, *d_bins = nullptr, *d_tw = nullptr, *d_iqlast = nullptr;
 	float *d_h = nullptr, *d_g = nullptr, *d_dhist = nullptr, *d_out48 = nullptr;
 	// kernel timing (HIP events on the submit stream), sampled: every 8th submit
 	hipEvent_t ev[3] = {};
-	unsigned long n_submits = 0;
+	unsigned long n_submits = 0, n_blocks = 0;
 	double acc_ms[2] = { 0.0, 0.0 };
 	int n_timed = 0;
 	bool ev_pending = false;
@@ -275,7 +288,7 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 	(void)hipSetDevice(c->device);
 	sonde_batch_destroy(c->batch);
 	for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-	(void)hipFree(c->d_wbuf); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_iqlast);
+	(void)hipFree(c->d_hist[0]); (void)hipFree(c->d_hist[1]); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_iqlast);
 	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48);
 	delete c;
 }
@@ -298,8 +311,7 @@ extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submi
 	if (sonde_batch_create(&cfg, &c->batch) != 0) { delete c; return -1; }
 	std::vector<float> h, tw, g;
 	make_tables(h, tw, g);
-	const size_t wn = (size_t)CH_H + (size_t)c->n_steps * CH_D;
-	bool ok = hipMalloc((void **)&c->d_wbuf, wn * sizeof(float2)) == hipSuccess &&
+	bool ok = hipMalloc((void **)&c->d_hist[0], (size_t)CH_H * sizeof(float2)) == hipSuccess && hipMalloc((void **)&c->d_hist[1], (size_t)CH_H * sizeof(float2)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_bins, (size_t)CH_M * c->n_steps * sizeof(float2)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_out48, (size_t)CH_M * n_out * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_h, CH_L * sizeof(float)) == hipSuccess &&
@@ -307,7 +319,7 @@ extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submi
 	          hipMalloc((void **)&c->d_g, RS_UP * RS_TAPS * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_iqlast, CH_M * sizeof(float2)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dhist, CH_M * RS_TAPS * sizeof(float)) == hipSuccess;
-	ok = ok && hipMemset(c->d_wbuf, 0, wn * sizeof(float2)) == hipSuccess && hipMemset(c->d_iqlast, 0, CH_M * sizeof(float2)) == hipSuccess &&
+	ok = ok && hipMemset(c->d_hist[0], 0, (size_t)CH_H * sizeof(float2)) == hipSuccess && hipMemset(c->d_hist[1], 0, (size_t)CH_H * sizeof(float2)) == hipSuccess && hipMemset(c->d_iqlast, 0, CH_M * sizeof(float2)) == hipSuccess &&
 	     hipMemset(c->d_dhist, 0, CH_M * RS_TAPS * sizeof(float)) == hipSuccess &&
 	     hipMemcpy(c->d_h, h.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_tw, tw.data(), CH_M * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
@@ -336,16 +348,15 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		c->ev_pending = false;
 	}
 	const bool timed = !c->ev_pending && (c->n_submits++ % 8) == 0;
-	// [history | block]: the block lands behind the 7942 samples carried from the previous submit
-	if (hipMemcpyAsync(c->d_wbuf + CH_H, iq_dev, n_samples * sizeof(float2), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
+	if ((uintptr_t)iq_dev & 15u) return -1;       // 16-byte loads straight from the caller's block
 	if (timed) (void)hipEventRecord(c->ev[0], stream);
-	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(64 * PFB_S), 0, stream, c->d_wbuf, c->d_h, c->d_tw, c->d_bins, c->n_steps);
+	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(64 * PFB_S), 0, stream, (const float2 *)iq_dev, c->d_hist[c->n_blocks & 1],
+	                   c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
+	c->n_blocks++;
 	if (timed) (void)hipEventRecord(c->ev[1], stream);
 	hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
 	                   c->d_bins, c->n_steps, c->d_g, c->d_iqlast, c->d_dhist, c->d_out48);
 	if (timed) { (void)hipEventRecord(c->ev[2], stream); c->ev_pending = true; }
-	// roll the history: the last 7942 samples of [history | block] move to the front (regions do not overlap)
-	if (hipMemcpyAsync(c->d_wbuf, c->d_wbuf + n_samples, (size_t)CH_H * sizeof(float2), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
 	if (hipGetLastError() != hipSuccess) return -1;
 	return sonde_batch_submit(c->batch, c->d_out48, n_out, n_out, stream_);
 }
