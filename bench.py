@@ -90,6 +90,7 @@ def parse_args():
     ap.add_argument("--flags", type=int, default=0, help="SondeBatchConfig.flags (1: RS41 wide, 2: FEC as its own kernel)")
     ap.add_argument("--stride-pad", type=int, default=0, help="experiment: extra samples between channels in HBM")
     ap.add_argument("--scatter", action="store_true", help="ingest on rank 0 and scatter IQ shards over RCCL before timing")
+    ap.add_argument("--scatter-torch", action="store_true", help="--scatter through torch.distributed instead of libsonde_rccl.so")
     return ap.parse_args()
 
 
@@ -251,7 +252,16 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                               for r in range(world)])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        iq = scatter_iq(full, C, n, dev, src=0)
+        # the native scatter (csrc/shard_rccl.cpp: grouped ncclSend / ncclRecv); --scatter-torch: dist.scatter
+        if args.scatter_torch:
+            iq = scatter_iq(full, C, n, dev, src=0)
+        else:
+            from sdrpp_radiosonde_amd.shard import NativeShard
+            ns = NativeShard(local_rank)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            iq = ns.scatter_iq(full, (C, n, 2), root=0)
         torch.cuda.synchronize()
         scatter_ms = (time.perf_counter() - t0) * 1e3
         del full

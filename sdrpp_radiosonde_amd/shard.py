@@ -43,3 +43,87 @@ def gather_frames(frames: np.ndarray, dst: int = 0, group=None) -> np.ndarray | 
         return None
     allf = np.concatenate(objs)
     return allf[np.lexsort((allf["bitpos"], allf["channel"]))]
+
+
+# ---------------------------------------------------------------- native path (libsonde_rccl.so, include/sonde_shard.h)
+class NativeShard:
+    """The node-level scatter / gather in native code: grouped ncclSend / ncclRecv over xGMI (csrc/shard_rccl.cpp).
+    The 128-byte communicator id travels through the torch.distributed group that launched the ranks (any backend)."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import ctypes as C
+            import os
+            from . import _lib as main
+            main.load()                                  # builds both libraries on a fresh checkout
+            L = C.CDLL(os.path.join(main.PKG_DIR, "libsonde_rccl.so"))
+            vp = C.c_void_p
+            L.sonde_shard_unique_id.argtypes = [vp]
+            L.sonde_shard_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+            L.sonde_shard_destroy.argtypes = [vp]
+            L.sonde_shard_destroy.restype = None
+            L.sonde_shard_range.argtypes = [C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+            L.sonde_shard_range.restype = None
+            L.sonde_shard_scatter.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
+            L.sonde_shard_gather.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
+            L.sonde_shard_last_error.restype = C.c_char_p
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, device: int, group=None, rank: int | None = None, world: int | None = None):
+        import ctypes as C
+        L = self.lib()
+        if world is None:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.rank, self.world, self.device = rank, world, device
+        ident = C.create_string_buffer(128)
+        if rank == 0 and L.sonde_shard_unique_id(ident) != 0:
+            raise RuntimeError(L.sonde_shard_last_error().decode())
+        if world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        if L.sonde_shard_create(ident, world, rank, device, C.byref(h)) != 0:
+            raise RuntimeError(L.sonde_shard_last_error().decode())
+        self.h = h
+
+    @staticmethod
+    def channel_range(n_channels: int, rank: int, world: int) -> tuple[int, int]:
+        import ctypes as C
+        f, c = C.c_uint32(), C.c_uint32()
+        NativeShard.lib().sonde_shard_range(n_channels, world, rank, C.byref(f), C.byref(c))
+        return f.value, f.value + c.value
+
+    def scatter_iq(self, full: torch.Tensor | None, shard_shape, root: int = 0) -> torch.Tensor:
+        """root holds `full` = world consecutive shards ([world * C, n, 2] float32); returns this rank's [C, n, 2]."""
+        import ctypes as C
+        out = torch.empty(tuple(shard_shape), dtype=torch.float32, device=f"cuda:{self.device}")
+        nbytes = out.numel() * 4
+        if self.rank == root:
+            assert full is not None and full.is_contiguous() and full.numel() * 4 == nbytes * self.world
+        st = torch.cuda.current_stream(out.device).cuda_stream
+        if self.lib().sonde_shard_scatter(self.h, C.c_void_p(full.data_ptr() if self.rank == root else 0), C.c_void_p(out.data_ptr()),
+                                          nbytes, root, C.c_void_p(st)) != 0:
+            raise RuntimeError(self.lib().sonde_shard_last_error().decode())
+        return out
+
+    def gather_bytes(self, part: torch.Tensor, root: int = 0) -> torch.Tensor | None:
+        """Every rank contributes the same number of bytes (a padded frame block); root gets [world, nbytes] uint8."""
+        import ctypes as C
+        part = part.contiguous().view(torch.uint8).reshape(-1)
+        out = torch.empty((self.world, part.numel()), dtype=torch.uint8, device=part.device) if self.rank == root else None
+        st = torch.cuda.current_stream(part.device).cuda_stream
+        if self.lib().sonde_shard_gather(self.h, C.c_void_p(part.data_ptr()), part.numel(), C.c_void_p(out.data_ptr() if out is not None else 0),
+                                         root, C.c_void_p(st)) != 0:
+            raise RuntimeError(self.lib().sonde_shard_last_error().decode())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib().sonde_shard_destroy(self.h)
+            self.h = None
+

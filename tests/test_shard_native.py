@@ -1,0 +1,44 @@
+"""libsonde_rccl.so (include/sonde_shard.h, csrc/shard_rccl.cpp): the node-level scatter / gather of SURVEY 8(e) in native
+code.  CPU: the library loads, exports every declared symbol, and its range arithmetic equals the Python sharder's.
+GPU (one device here; the N-GPU run is the driver's): a communicator of one rank scatters to / gathers from itself through
+the same grouped ncclSend / ncclRecv calls the N-rank case makes."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sdrpp_radiosonde_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_and_range_arithmetic():
+    L = shard.NativeShard.lib()
+    hdr = open(os.path.join(ROOT, "include", "sonde_shard.h")).read()
+    declared = set(re.findall(r"\b(sonde_shard_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) == 9
+    for s in declared:
+        assert hasattr(L, s), s
+    for n in (0, 1, 7, 1024, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard.NativeShard.channel_range(n, r, world) for r in range(world)]
+            assert spans == [shard.channel_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+    bad = C.c_void_p()
+    assert L.sonde_shard_create(None, 1, 0, 0, C.byref(bad)) != 0 and b"bad argument" in L.sonde_shard_last_error()
+
+
+@pytest.mark.gpu
+def test_single_rank_scatter_gather_on_device():
+    import torch
+    ns = shard.NativeShard(0, rank=0, world=1)
+    x = torch.randn((6, 4096, 2), device="cuda:0")
+    got = ns.scatter_iq(x, x.shape, root=0)
+    torch.cuda.synchronize()
+    assert torch.equal(got, x) and got.data_ptr() != x.data_ptr()
+    back = ns.gather_bytes(got, root=0)
+    torch.cuda.synchronize()
+    assert back.shape == (1, x.numel() * 4) and torch.equal(back.view(-1).view(torch.float32).reshape(x.shape), x)
+    ns.close()
