@@ -1,0 +1,86 @@
+"""-m gpu: differential test at low and medium SNR, where the decision paths that a clean signal never takes are busy
+(false sync hits, frames cut off by a later sync, RS codewords with 1 .. 12 errors and uncorrectable ones, Hamming / BCH
+corrections and failures, checksum rejects, one-sided slicer rounds).  Every sonde type, mixed in ONE batch, several seeds:
+bits, timing-loop state and frame records must equal the oracle's bit for bit, submit after submit."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib
+from sdrpp_radiosonde_amd import synth
+from sdrpp_radiosonde_amd.batch import SondeBatch
+
+pytestmark = pytest.mark.gpu
+TILE = 2048
+
+
+@pytest.mark.parametrize("ebn0,seed", [(5.0, 1), (7.5, 2), (10.0, 3), (12.5, 4)])
+def test_mixed_batch_low_snr_bit_exact(ebn0, seed):
+    types_cycle = (0, 1, 2, 3, 6)                       # the GFSK family (the AFSK sondes need 16384-sample submits: below)
+    per, n_sub, n = 10, 3, TILE * 32
+    parts, types = [], []
+    for t in types_cycle:
+        sb = synth.make_batch(t, per, n * n_sub, seed=100 * seed + t, ebn0_db=ebn0 + (2.0 if t else 0.0), invert=(t == 1 and seed % 2 == 0))
+        parts.append(sb.iq)
+        types += [t] * per
+    iq = torch.cat(parts)
+    types = np.array(types, dtype=np.uint8)
+    # interleave the types so that every class list of the batch is scattered over the rows
+    perm = np.random.default_rng(seed).permutation(len(types))
+    iq, types = iq[torch.from_numpy(perm)].contiguous(), types[perm]
+    C = len(types)
+    b = SondeBatch(C, n, types=types)
+    dev = iq.cuda()
+    chs = [oracle_lib.Channel(int(types[c]), c) for c in range(C)]
+    x = iq.numpy()
+    total = 0
+    for k in range(n_sub):
+        b.submit(dev[:, k * n:(k + 1) * n])
+        b.sync()
+        got = b.frames()
+        n_before = [len(ch.frames()) for ch in chs]
+        for c, ch in enumerate(chs):
+            ch.feed(x[c, k * n:(k + 1) * n])
+        ref = np.concatenate([ch.frames()[n_before[c]:] for c, ch in enumerate(chs)])
+        got = got[np.lexsort((got["bitpos"], got["channel"]))]
+        ref = ref[np.lexsort((ref["bitpos"], ref["channel"]))]
+        assert len(got) == len(ref), (k, len(got), len(ref))
+        assert got.tobytes() == ref.tobytes(), k
+        total += len(got)
+        for c, ch in enumerate(chs):
+            st, rs = b.state(c), ch.state()
+            assert st["t_next"] == rs["t_next"] and st["period"] == rs["period"], (k, c)
+            assert np.float32(st["bias"]).tobytes() == np.float32(rs["bias"]).tobytes()
+            assert b.nbits(c) == len(ch.bits())
+    assert total > 0
+    # the interesting paths were taken: failed and corrected frames both occur somewhere in the sweep
+    allf = np.concatenate([ch.frames() for ch in chs])
+    if ebn0 <= 7.5:
+        assert (allf["nerr"] < 0).any()
+    if ebn0 >= 10.0:
+        assert (allf["nerr"] > 0).any() and (allf["nerr"] >= 0).all(axis=1).any()
+    b.close()
+
+
+@pytest.mark.parametrize("snr", [8.0, 14.0])
+def test_afsk_low_snr_bit_exact(snr):
+    per, n = 6, 16384 * 6
+    a = synth.make_imet_batch(per, 2 * n, seed=41, snr_db=snr)
+    c5 = synth.make_c50_batch(per, 2 * n, seed=42, snr_db=snr)
+    iq = torch.cat([a.iq, c5.iq])
+    types = np.array([4] * per + [5] * per, dtype=np.uint8)
+    b = SondeBatch(2 * per, n, types=types)
+    dev = iq.cuda()
+    chs = [oracle_lib.Channel(int(types[c]), c) for c in range(2 * per)]
+    for k in range(2):
+        b.submit(dev[:, k * n:(k + 1) * n])
+        b.sync()
+        got = b.frames()
+        nb = [len(ch.frames()) for ch in chs]
+        for c, ch in enumerate(chs):
+            ch.feed(iq.numpy()[c, k * n:(k + 1) * n])
+        ref = np.concatenate([ch.frames()[nb[c]:] for c, ch in enumerate(chs)])
+        got = got[np.lexsort((got["bitpos"], got["channel"]))]
+        ref = ref[np.lexsort((ref["bitpos"], ref["channel"]))]
+        assert len(got) == len(ref) and got.tobytes() == ref.tobytes(), k
+    b.close()
