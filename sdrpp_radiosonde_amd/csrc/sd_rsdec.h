@@ -49,7 +49,7 @@ struct FramerLds {                 // one per wave (= per frame)
 	int     pos[2][RS_T];
 	int     L[2];
 	int     status[2];     // 0 clean, >0 errors to fix, -1 fail
-	int     done[2];       // the single-error fast path has settled this codeword
+	int     done[2];       // 1: the single-error fast path has settled this codeword; 2: Lambda known in closed form (two errors)
 };
 
 __device__ __forceinline__ uint32_t gmul(const FramerTabs &s, uint32_t a, uint32_t b)
@@ -151,11 +151,56 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 	WAVE_SYNC();
 	if (settled[0] && settled[1]) return;       // wave-uniform
 
+	// ---- two byte errors: Lambda = 1 + L1 x + L2 x^2 in closed form from S0..S3 (Cramer over the first two recurrence
+	// equations: D = S1^2 + S0 S2, L1 = (S1 S2 + S0 S3) / D, L2 = (S2^2 + S1 S3) / D), accepted when D != 0, L2 != 0 and all
+	// 22 equations S_{j+2} = L1 S_{j+1} + L2 S_j hold (one per lane).  D != 0 rules out a recurrence of length 1, so this is
+	// THE shortest recurrence (2 L <= 24: unique), i.e. the polynomial Berlekamp-Massey ends with; Chien, omega and Forney
+	// below then run as for any other Lambda.  At the SNRs where the corrector works at all, three or more byte errors in one
+	// 156-byte codeword are rare: the 24 dependent iterations of the general algorithm (~ 24 k cycles, the tail of the whole
+	// launch whenever one frame of one workgroup needed them) are skipped for nearly every frame.
+	bool lam_known[2] = { false, false };
+	{
+		const int c = lane >= RS_R ? 1 : 0, j = lane - RS_R * c;
+		uint32_t l[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)lsyn, q), b = (uint32_t)__builtin_amdgcn_readlane((int)lsyn, RS_R + q);
+			l[q] = c ? b : a;
+		}
+		const uint32_t D = (uint32_t)tb.exp2[2u * l[1]] ^ (uint32_t)tb.exp2[l[0] + l[2]];
+		const uint32_t N1 = (uint32_t)tb.exp2[l[1] + l[2]] ^ (uint32_t)tb.exp2[l[0] + l[3]];
+		const uint32_t N2 = (uint32_t)tb.exp2[2u * l[2]] ^ (uint32_t)tb.exp2[l[1] + l[3]];
+		const uint32_t lD = D ? (uint32_t)tb.log2[D] : 0u;                       // (D == 0: nothing below is used)
+		const uint32_t L1 = tb.exp2[(uint32_t)tb.log2[N1] + 255u - lD], L2 = tb.exp2[(uint32_t)tb.log2[N2] + 255u - lD];
+		const uint32_t lL1 = tb.log2[L1], lL2 = tb.log2[L2];
+		const uint32_t n1 = (uint32_t)__shfl_down((int)lsyn, 1, 64), s2 = (uint32_t)__shfl_down((int)syn, 2, 64);
+		const uint32_t rhs = (uint32_t)tb.exp2[lL1 + n1] ^ (uint32_t)tb.exp2[lL2 + lsyn];
+		const bool okj = lane < 2 * RS_R && D != 0u && L2 != 0u && (j >= RS_R - 2 || rhs == s2);
+		const unsigned long long gm = __ballot(okj);
+		lam_known[0] = !settled[0] && (gm & 0xFFFFFFull) == 0xFFFFFFull;
+		lam_known[1] = !settled[1] && ((gm >> RS_R) & 0xFFFFFFull) == 0xFFFFFFull;
+		// lanes c*24 + i, i < 26 would be needed for lam[0..25]: codeword 0 from lanes 0.., codeword 1 from lanes 32..
+		const int h = lane >> 5, idx = lane & 31;
+		const uint32_t L1h = (uint32_t)__builtin_amdgcn_readlane((int)L1, 0), L1g = (uint32_t)__builtin_amdgcn_readlane((int)L1, RS_R);
+		const uint32_t L2h = (uint32_t)__builtin_amdgcn_readlane((int)L2, 0), L2g = (uint32_t)__builtin_amdgcn_readlane((int)L2, RS_R);
+		const uint32_t lL1h = (uint32_t)__builtin_amdgcn_readlane((int)lL1, 0), lL1g = (uint32_t)__builtin_amdgcn_readlane((int)lL1, RS_R);
+		const uint32_t lL2h = (uint32_t)__builtin_amdgcn_readlane((int)lL2, 0), lL2g = (uint32_t)__builtin_amdgcn_readlane((int)lL2, RS_R);
+		if (lam_known[h] && idx < RS_R + 2) {
+			const uint32_t v = idx == 0 ? 1u : idx == 1 ? (h ? L1g : L1h) : idx == 2 ? (h ? L2g : L2h) : 0u;
+			const uint32_t lv = idx == 0 ? 0u : idx == 1 ? (h ? lL1g : lL1h) : idx == 2 ? (h ? lL2g : lL2h) : (uint32_t)GF_LZ;
+			s.lam[h][idx] = (uint8_t)v;
+			s.loglam[h][idx] = (uint16_t)lv;
+			if (idx == 0) { s.L[h] = 2; s.done[h] = 2; }       // 2: Lambda is known, the root search is still to do
+		}
+	}
+	WAVE_SYNC();
+	const bool need_bm = !((settled[0] || lam_known[0]) && (settled[1] || lam_known[1]));      // wave-uniform
+
 	// ---- Berlekamp-Massey, one coefficient per lane: half-wave h handles codeword h, lane idx = lane&31 holds
 	// lam[idx] and (the logarithm of) Bp[idx] where Bp = x^m * B.  Same recurrence as the sequential form (delta,
 	// then lam -= delta/b * x^m B, length change iff 2L <= r), so the same Lambda comes out.  Log domain: the
 	// discrepancy term is one antilog read, the update one more, plus the logarithm of the new coefficient.
-	{
+	if (need_bm) {
 		const int h = lane >> 5, idx = lane & 31;
 		const bool live = s.status[h] > 0 && !s.done[h];
 		uint32_t lam = (idx == 0) ? 1u : 0u;
@@ -187,7 +232,7 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 			logBp = (uint32_t)up;
 			if (change) { L = r + 1 - L; logbb = logd; }
 		}
-		if (idx < RS_R + 2) { s.lam[h][idx] = (uint8_t)lam; s.loglam[h][idx] = (uint16_t)loglam; }
+		if (live && idx < RS_R + 2) { s.lam[h][idx] = (uint8_t)lam; s.loglam[h][idx] = (uint16_t)loglam; }
 		const unsigned long long nzl = __ballot(lam != 0);
 		const uint32_t halfmask = (uint32_t)(h ? (nzl >> 32) : nzl);
 		const int deg = halfmask ? 31 - __clz(halfmask) : 0;
@@ -204,7 +249,7 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 	// codeword after the other: 7 of the 18 us this stage cost at the end of the demod kernel).
 	{
 		const int h = lane >> 5, idx = lane & 31;
-		const bool live = s.status[h] > 0 && !s.done[h];
+		const bool live = s.status[h] > 0 && s.done[h] != 1;
 		const int L = live ? s.L[h] : 0;
 		const uint16_t *ll = s.loglam[h];
 		// Chien search over the n positions of the shortened codeword, position i = idx + 32*it.
