@@ -539,9 +539,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	}
 
 	// ---- K5/K6 (RS41 channels): the frames K4 listed in this submit, one per wave
-#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
-	const unsigned long long ts_epi = __builtin_amdgcn_s_memtime();
-#endif
 	if (fec_here) {
 		__syncthreads();           // (F) K4's catch-up is done (nout in LDS, descriptors in HBM); the tile buffers are dead
 		const uint32_t max_frames = fo->max_frames;
@@ -569,9 +566,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);
 				d.inv = __builtin_amdgcn_readfirstlane((int)(d1 >> 32));
 				sd_rs41_decode_frame<true>(et.tabs, wl, swar, ring_g, ring_mask, d, fout + k, ch, lane);
-#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
-				if (lane == 0) reinterpret_cast<uint32_t *>((fout + k)->data)[130] = (uint32_t)ts_epi;
-#endif
 			}
 		}
 	}

@@ -20,15 +20,11 @@ for k in range(20):
     fr.append(b.frames())
 fr = np.concatenate(fr)
 d = fr["data"].view(np.uint32).reshape(len(fr), -1)
-dbg = d[:, 124:131].astype(np.int64)
-names = ["extract", "cwbuild", "decode_pair", "writeback+record"]
+dbg = d[:, 124:132].astype(np.int64)
+names = ["extract", "cwbuild", "decode_pair", "writeback+record", "  syndromes", "  fast paths", "  locator (RiBM)", "  roots+values"]
 for i, nm in enumerate(names):
     v = dbg[:, i]
     print(f"{nm:18s} cycles: median {np.median(v):8.0f}  p90 {np.percentile(v,90):8.0f}  max {v.max():8.0f}")
-ts0, ts4, tse = dbg[:, 4], dbg[:, 5], dbg[:, 6]
-print("wait from epilogue start (before barrier F) to decode start: median", np.median((ts0 - tse) & 0xFFFFFFFF), "max", ((ts0 - tse) & 0xFFFFFFFF).max())
-print("epilogue start spread over all frames (cycles):", (tse.max() - tse.min()) & 0xFFFFFFFF, " decode end spread:", (ts4.max() - ts4.min()) & 0xFFFFFFFF)
-print("last decode end - first epilogue start:", (ts4.max() - tse.min()) & 0xFFFFFFFF, " median end - median start:", np.median(ts4) - np.median(tse))
 dirty = (fr["nerr"] > 0).any(axis=1)
 print("dirty frames:", dirty.mean(), " decode_pair median clean/dirty:", np.median(dbg[~dirty, 2]), np.median(dbg[dirty, 2]) if dirty.any() else None)
 dp = dbg[:, 2]
