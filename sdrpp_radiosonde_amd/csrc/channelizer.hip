@@ -23,24 +23,29 @@
 #define RS_DN 5
 #define RS_TAPS 16
 
-// ---- PFB: one 1024-thread workgroup per PFB_S = 16 consecutive output time steps.
-//   1. the 8192 + 15*250 wideband samples the 16 windows cover are staged in LDS ONCE (95.5 KB; a workgroup per step
+// ---- PFB: one 1024-thread workgroup per PFB_S = 20 consecutive output time steps: a 1.28 M-sample block is 5120 steps =
+// 256 workgroups = ONE round on the 256 CUs (the window needs 104 KB of LDS: one workgroup per CU; with 16 steps per
+// workgroup the 320 workgroups took two rounds, the second a quarter full).
+//   1. the 8192 + 19*250 wideband samples the 20 windows cover are staged in LDS ONCE (a workgroup per step
 //      re-read a 64 KB window per 250 new samples: 32.8x through L2);
-//   2. fold: thread (r, g) accumulates the 16 taps of bin residue r for the 8 steps of group g, taps in registers,
+//   2. fold: thread (r, g) accumulates the 16 taps of bin residue r for the 10 steps of group g, taps in registers,
 //      t ascending (SPEC 3.5: v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc));
-//   3. circular shift by (m*D mod 512) + bit reversal into a per-wave buffer (aliasing the dead window);
-//   4. 512-point radix-2 DIT FFT, one WAVE per time step: every lane keeps 8 points in registers and runs three stages
-//      on them, three times, with two transposes through the wave's own LDS buffer in between -- the butterflies, their
-//      operand order and the twiddles are exactly those of the stage-by-stage form (oracle/or_chan.c or_fft512), only
-//      the 18 workgroup barriers are gone;
-//   5. the 512 x 16 output tile is transposed through LDS so that every bin row receives one aligned 128-byte run
+//   3. circular shift by (m*D mod 512) + bit reversal into a per-step buffer (aliasing the dead window);
+//   4. 512-point radix-2 DIT FFT, one WAVE per time step (16 waves: steps 0..15, then waves 0..3 steps 16..19): every lane
+//      keeps 8 points in registers and runs three stages on them, three times, with two transposes through the step's own
+//      LDS buffer in between -- the butterflies, their operand order and the twiddles are exactly those of the
+//      stage-by-stage form (oracle/or_chan.c or_fft512), only the 18 workgroup barriers are gone;
+//   5. the 512 x 20 output tile is transposed through LDS so that every bin row receives one aligned 160-byte run
 //      (it was an 8-byte store per bin per step, 40 KB apart).
-#define PFB_S    16
-#define PFB_WIN  (CH_L + (PFB_S - 1) * CH_D)          // 11942 samples
-#define PFB_FB   (CH_M + CH_M / 8)                    // FFT buffer per wave: one pad element per 8 (bank spread)
+#define PFB_S    20
+#define PFB_NW   16                                    // waves per workgroup
+#define PFB_NT   (64 * PFB_NW)
+#define PFB_WIN  (CH_L + (PFB_S - 1) * CH_D)          // 12942 samples
+#define PFB_FB   (CH_M + CH_M / 8)                    // FFT buffer per step: one pad element per 8 (bank spread)
 #define PFB_OT   (PFB_S + 1)                          // output tile row stride (float2)
 static_assert(PFB_S * PFB_FB <= PFB_WIN && CH_M * PFB_OT <= PFB_WIN, "the FFT buffers and the output tile alias the window");
 static_assert(PFB_WIN % 2 == 0 && CH_H % 2 == 0 && (PFB_WIN - CH_H) % 2 == 0 && (CH_D * sizeof(float2)) % 16 == 0, "16-byte staging loads");
+static_assert(PFB_S % 4 == 0 && PFB_S <= 2 * PFB_NW && PFB_NT == 2 * CH_M, "fold: two groups of 512 bins; FFT: at most two passes; stores: 16-byte runs");
 
 __device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
 {
@@ -52,78 +57,9 @@ __device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
 }
 __device__ __forceinline__ int pfb_pad(int i) { return i + (i >> 3); }
 
-// The stream in front of the block (the last CH_H samples of the previous submit) comes from hist_in; the last workgroup
-// saves this block's tail to hist_out (the other buffer of a ping-pong pair: the first workgroups of this launch still
-// read hist_in).  No staging copy of the block and no history roll: a submit is three kernels (was: copy, PFB,
-// discriminator + resampler, copy, decoder -- the two copies were 14 of 70 us).
-__global__ __launch_bounds__(64 * PFB_S) void sd_pfb_kernel(const float2 *__restrict__ iq, const float2 *__restrict__ hist_in,
-                                                         float2 *__restrict__ hist_out, const float *__restrict__ h,
-                                                         const float2 *__restrict__ tw, float2 *__restrict__ bins, uint32_t n_steps)
+// 512-point FFT of the bit-reversed, padded buffer fb by one wave; the result stays in registers: e[j] = bin lane + 64 j
+__device__ __forceinline__ void pfb_fft512(float2 *fb, const float2 *s_tw, int lane, float2 (&e)[8])
 {
-	__shared__ __attribute__((aligned(16))) float2 s_x[PFB_WIN];
-	__shared__ float2 s_tw[CH_M / 2];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t m0 = blockIdx.x * PFB_S;
-	{	// 1. stage the window (16-byte loads; iq + m0*250 samples is 16-byte aligned, CH_H is even) and the twiddles:
-		// window sample w is stream sample m0*250 + w - CH_H of this block, negative = history.
-		// all loads first, then all LDS stores: one memory round trip per workgroup instead of one per loop iteration
-		const long p0 = (long)m0 * CH_D - CH_H;                       // stream position of window sample 0 (even)
-		const float4 *src_iq = reinterpret_cast<const float4 *>(iq) + p0 / 2;       // (p0 < 0: indexed only where p0/2 + i >= 0)
-		const float4 *src_h = reinterpret_cast<const float4 *>(hist_in) + (CH_H + p0) / 2;
-		float4 *dst = reinterpret_cast<float4 *>(s_x);
-		constexpr int NQ = (PFB_WIN / 2 + 64 * PFB_S - 1) / (64 * PFB_S);
-		float4 tmp[NQ];
-#pragma unroll
-		for (int q = 0; q < NQ; q++) {
-			const int i = tid + 64 * PFB_S * q;
-			tmp[q] = i < PFB_WIN / 2 ? (p0 + 2 * (long)i < 0 ? src_h[i] : src_iq[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-		}
-		const float2 twv = tid < CH_M / 2 ? tw[tid] : make_float2(0.f, 0.f);
-#pragma unroll
-		for (int q = 0; q < NQ; q++) {
-			const int i = tid + 64 * PFB_S * q;
-			if (i < PFB_WIN / 2) dst[i] = tmp[q];
-		}
-		if (tid < CH_M / 2) s_tw[tid] = twv;
-	}
-	// 2. fold: r = tid & 511, steps 8g .. 8g+7 with g = tid >> 9
-	const int r = tid & (CH_M - 1), g = tid >> 9;
-	float hr[CH_T];
-#pragma unroll
-	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
-	__syncthreads();
-	if (blockIdx.x == gridDim.x - 1) {     // the last CH_H samples of [history | block] are the next submit's history
-		const float4 *tail = reinterpret_cast<const float4 *>(s_x + (PFB_WIN - CH_H));
-		float4 *ho = reinterpret_cast<float4 *>(hist_out);
-		for (int i = tid; i < CH_H / 2; i += 64 * PFB_S) ho[i] = tail[i];
-	}
-	float2 v[PFB_S / 2];
-#pragma unroll
-	for (int q = 0; q < PFB_S / 2; q++) {
-		const float2 *xs = s_x + (8 * g + q) * CH_D + r;
-		float ar = 0.0f, ai = 0.0f;
-#pragma unroll
-		for (int t = 0; t < CH_T; t++) {
-			const float2 xv = xs[t * CH_M];
-			ar = __builtin_fmaf(hr[t], xv.x, ar);
-			ai = __builtin_fmaf(hr[t], xv.y, ai);
-		}
-		v[q] = make_float2(ar, ai);
-	}
-	__syncthreads();                       // the window is dead from here on
-	// 3. rotate + bit-reverse into the buffer of the wave that owns the step
-#pragma unroll
-	for (int q = 0; q < PFB_S / 2; q++) {
-		const int sidx = 8 * g + q;
-		const uint32_t shift = ((m0 + (uint32_t)sidx) * CH_D) & (CH_M - 1);
-		const uint32_t pos = ((uint32_t)r + shift) & (CH_M - 1);
-		const int rev = (int)(__brev(pos) >> 23);               // 9-bit reversal
-		s_x[sidx * PFB_FB + pfb_pad(rev)] = v[q];
-	}
-	__syncthreads();
-	// 4. FFT of step m0 + wave, by this wave alone
-	float2 *fb = s_x + wave * PFB_FB;
-	float2 e[8];
 	// stages 1-3 on elements 8*lane + j
 #pragma unroll
 	for (int j = 0; j < 8; j++) e[j] = fb[pfb_pad(8 * lane + j)];
@@ -162,19 +98,100 @@ __global__ __launch_bounds__(64 * PFB_S) void sd_pfb_kernel(const float2 *__rest
 	for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], s_tw[(lane + 64 * (j & 1)) * 2]);
 #pragma unroll
 	for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], s_tw[lane + 64 * j]);
-	__syncthreads();                       // every wave has left its FFT buffer: the output tile aliases them
-	// 5. tile[bin][step] (row stride 17), then one 64-byte run per thread: bin = tid >> 1, steps 8*(tid & 1) ..
+}
+
+// The stream in front of the block (the last CH_H samples of the previous submit) comes from hist_in; the last workgroup
+// saves this block's tail to hist_out (the other buffer of a ping-pong pair: the first workgroups of this launch still
+// read hist_in).  No staging copy of the block and no history roll: a submit is three kernels (was: copy, PFB,
+// discriminator + resampler, copy, decoder -- the two copies were 14 of 70 us).
+__global__ __launch_bounds__(PFB_NT) void sd_pfb_kernel(const float2 *__restrict__ iq, const float2 *__restrict__ hist_in,
+                                                         float2 *__restrict__ hist_out, const float *__restrict__ h,
+                                                         const float2 *__restrict__ tw, float2 *__restrict__ bins, uint32_t n_steps)
+{
+	__shared__ __attribute__((aligned(16))) float2 s_x[PFB_WIN];
+	__shared__ float2 s_tw[CH_M / 2];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t m0 = blockIdx.x * PFB_S;
+	{	// 1. stage the window (16-byte loads; iq + m0*250 samples is 16-byte aligned, CH_H is even) and the twiddles:
+		// window sample w is stream sample m0*250 + w - CH_H of this block, negative = history.
+		// all loads first, then all LDS stores: one memory round trip per workgroup instead of one per loop iteration
+		const long p0 = (long)m0 * CH_D - CH_H;                       // stream position of window sample 0 (even)
+		const float4 *src_iq = reinterpret_cast<const float4 *>(iq) + p0 / 2;       // (p0 < 0: indexed only where p0/2 + i >= 0)
+		const float4 *src_h = reinterpret_cast<const float4 *>(hist_in) + (CH_H + p0) / 2;
+		float4 *dst = reinterpret_cast<float4 *>(s_x);
+		constexpr int NQ = (PFB_WIN / 2 + PFB_NT - 1) / PFB_NT;
+		float4 tmp[NQ];
 #pragma unroll
-	for (int j = 0; j < 8; j++) s_x[(lane + 64 * j) * PFB_OT + wave] = e[j];
+		for (int q = 0; q < NQ; q++) {
+			const int i = tid + PFB_NT * q;
+			tmp[q] = i < PFB_WIN / 2 ? (p0 + 2 * (long)i < 0 ? src_h[i] : src_iq[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		const float2 twv = tid < CH_M / 2 ? tw[tid] : make_float2(0.f, 0.f);
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			const int i = tid + PFB_NT * q;
+			if (i < PFB_WIN / 2) dst[i] = tmp[q];
+		}
+		if (tid < CH_M / 2) s_tw[tid] = twv;
+	}
+	// 2. fold: r = tid & 511, steps (PFB_S/2) g .. with g = tid >> 9
+	constexpr int SPT = PFB_S / 2;          // steps per thread
+	const int r = tid & (CH_M - 1), g = tid >> 9;
+	float hr[CH_T];
+#pragma unroll
+	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
+	__syncthreads();
+	if (blockIdx.x == gridDim.x - 1) {     // the last CH_H samples of [history | block] are the next submit's history
+		const float4 *tail = reinterpret_cast<const float4 *>(s_x + (PFB_WIN - CH_H));
+		float4 *ho = reinterpret_cast<float4 *>(hist_out);
+		for (int i = tid; i < CH_H / 2; i += PFB_NT) ho[i] = tail[i];
+	}
+	float2 v[SPT];
+#pragma unroll
+	for (int q = 0; q < SPT; q++) {
+		const float2 *xs = s_x + (SPT * g + q) * CH_D + r;
+		float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+		for (int t = 0; t < CH_T; t++) {
+			const float2 xv = xs[t * CH_M];
+			ar = __builtin_fmaf(hr[t], xv.x, ar);
+			ai = __builtin_fmaf(hr[t], xv.y, ai);
+		}
+		v[q] = make_float2(ar, ai);
+	}
+	__syncthreads();                       // the window is dead from here on
+	// 3. rotate + bit-reverse into the buffer of the step
+#pragma unroll
+	for (int q = 0; q < SPT; q++) {
+		const int sidx = SPT * g + q;
+		const uint32_t shift = ((m0 + (uint32_t)sidx) * CH_D) & (CH_M - 1);
+		const uint32_t pos = ((uint32_t)r + shift) & (CH_M - 1);
+		const int rev = (int)(__brev(pos) >> 23);               // 9-bit reversal
+		s_x[sidx * PFB_FB + pfb_pad(rev)] = v[q];
+	}
+	__syncthreads();
+	// 4. FFT of step m0 + wave (and of step m0 + 16 + wave on the first PFB_S - 16 waves), each by one wave alone
+	float2 e0[8], e1[8];
+	pfb_fft512(s_x + wave * PFB_FB, s_tw, lane, e0);
+	const bool second = wave + PFB_NW < PFB_S;
+	if (second) pfb_fft512(s_x + (wave + PFB_NW) * PFB_FB, s_tw, lane, e1);
+	__syncthreads();                       // every wave has left its FFT buffers: the output tile aliases them
+	// 5. tile[bin][step] (row stride 21), then one 80-byte run per thread: bin = tid >> 1, steps 10*(tid & 1) ..
+#pragma unroll
+	for (int j = 0; j < 8; j++) s_x[(lane + 64 * j) * PFB_OT + wave] = e0[j];
+	if (second) {
+#pragma unroll
+		for (int j = 0; j < 8; j++) s_x[(lane + 64 * j) * PFB_OT + wave + PFB_NW] = e1[j];
+	}
 	__syncthreads();
 	{
-		const int k = tid >> 1, s0 = 8 * (tid & 1);
-		float2 o[8];
+		const int k = tid >> 1, s0 = SPT * (tid & 1);
+		float2 o[SPT];
 #pragma unroll
-		for (int j = 0; j < 8; j++) o[j] = s_x[k * PFB_OT + s0 + j];
+		for (int j = 0; j < SPT; j++) o[j] = s_x[k * PFB_OT + s0 + j];
 		float4 *dst = reinterpret_cast<float4 *>(bins + (size_t)k * n_steps + m0 + s0);
 #pragma unroll
-		for (int j = 0; j < 4; j++) dst[j] = make_float4(o[2 * j].x, o[2 * j].y, o[2 * j + 1].x, o[2 * j + 1].y);
+		for (int j = 0; j < SPT / 2; j++) dst[j] = make_float4(o[2 * j].x, o[2 * j].y, o[2 * j + 1].x, o[2 * j + 1].y);
 	}
 }
 
@@ -350,7 +367,7 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 	const bool timed = !c->ev_pending && (c->n_submits++ % 8) == 0;
 	if ((uintptr_t)iq_dev & 15u) return -1;       // 16-byte loads straight from the caller's block
 	if (timed) (void)hipEventRecord(c->ev[0], stream);
-	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(64 * PFB_S), 0, stream, (const float2 *)iq_dev, c->d_hist[c->n_blocks & 1],
+	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(PFB_NT), 0, stream, (const float2 *)iq_dev, c->d_hist[c->n_blocks & 1],
 	                   c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
 	c->n_blocks++;
 	if (timed) (void)hipEventRecord(c->ev[1], stream);
