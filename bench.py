@@ -84,6 +84,7 @@ def parse_args():
     ap.add_argument("--sonde-type", type=int, default=0, help="all channels of this SONDE_* type (1 DFM09, 2 iMS-100, 3 M10; not the headline workload)")
     ap.add_argument("--wideband", action="store_true", help="BASELINE configs[3]: 10 MS/s IQ -> 512-bin channelizer -> per-bin demod+FEC")
     ap.add_argument("--wb-streams", type=int, default=1, help="--wideband: independent 10 MS/s streams processed per step")
+    ap.add_argument("--wb-blocks", type=int, default=1, choices=(1, 2), help="--wideband: blocks of 1 280 000 samples (0.128 s) per submit")
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
                     "4 for runs of fewer than 64 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
                     "(profiles/r2_notes.md), inside the timed region: every 8th costs 0.6 %% of the step")
@@ -403,12 +404,12 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
 
     S = args.wb_streams
-    chans = [SondeChannelizer(device=local_rank) for _ in range(S)]
+    chans = [SondeChannelizer(blocks_per_submit=args.wb_blocks, device=local_rank) for _ in range(S)]
     nwb = chans[0].samples_per_submit
     bins_active = list(range(8, 504, 8))
     # a 1.024 s scene (8 blocks of 0.128 s) with 16 RS41 transmitters, cycled block by block so that the per-bin streams
     # are continuous (one discontinuity per wrap) and frames really decode
-    NB = 8
+    NB = 8 // args.wb_blocks
     scene, _ = synth.make_wideband_rs41(bins_active[:16], NB * nwb, seed=7 + rank, ebn0_db=30.0, device=dev)
     blocks = [scene[i * nwb: (i + 1) * nwb] for i in range(NB)]
     torch.cuda.synchronize()
