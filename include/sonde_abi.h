@@ -162,6 +162,9 @@ int  sonde_batch_set_timing(SondeBatch *b, int every_n);
 
 /* introspection for staged parity tests */
 int      sonde_batch_read_bits(SondeBatch *b, uint32_t channel, uint64_t from, size_t count, uint8_t *out /* one bit per byte */);
+/* parity-test introspection: the RS(255,231) corrector alone on n_pairs codeword pairs of [2][256] bytes (positions >= n zero),
+ * corrected in place; status[2 i + c] = 0 clean, > 0 corrected byte errors, -1 uncorrectable (word left as received) */
+int      sonde_batch_test_rs255(SondeBatch *b, uint8_t *cw_pairs, size_t n_pairs, int n, int32_t *status);
 uint64_t sonde_batch_nbits(SondeBatch *b, uint32_t channel);
 int      sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp,
                                 float *yprev /* reserved, reads 0 */);

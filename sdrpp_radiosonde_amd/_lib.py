@@ -52,7 +52,7 @@ FLAG_SPLIT_FEC = 2
 ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
     "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_read_bits",
-    "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
+    "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_test_rs255", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
     "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp", "sonde_rs41_pressure", "sonde_ozone_mpa",
     "sonde_m10_temp", "sonde_m10_rh", "sonde_m20_temp", "sonde_ims100_temp",
     "sonde_last_error", "sonde_version", "sonde_hbm_read_probe", "sonde_dewpt", "sonde_altitude_to_pressure",
@@ -111,6 +111,8 @@ def load() -> C.CDLL:
     L.sonde_batch_nbits.restype = C.c_uint64
     L.sonde_batch_read_state.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                          C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    if hasattr(L, "sonde_batch_test_rs255"):
+        L.sonde_batch_test_rs255.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
     L.sonde_get_taps.argtypes = [C.c_int, vp]
     L.sonde_parse_frame.argtypes = [vp, C.POINTER(SondeData), C.c_int]
     L.sonde_batch_poll.argtypes = [vp, C.POINTER(SondeData), C.POINTER(C.c_uint32), C.c_size_t]

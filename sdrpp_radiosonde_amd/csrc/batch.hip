@@ -688,6 +688,27 @@ extern "C" int sonde_batch_set_timing(SondeBatch *b, int every_n)
 }
 
 // ---------------------------------------------------------------- introspection (staged parity tests)
+// The RS(255,231) corrector alone: n_pairs codeword pairs of [2][256] bytes (positions >= n zero), corrected in place;
+// status[2 * i + c]: 0 clean, > 0 corrected byte errors, -1 uncorrectable (word left as received).
+extern "C" int sonde_batch_test_rs255(SondeBatch *b, uint8_t *cw_pairs, size_t n_pairs, int n, int32_t *status)
+{
+	if (!b || !cw_pairs || !status || !n_pairs || n < 25 || n > 255) return fail("sonde_batch_test_rs255: bad argument");
+	HIPCHK(hipSetDevice(b->device));
+	uint8_t *d_cw = nullptr;
+	int32_t *d_st = nullptr;
+	HIPCHK(hipMalloc((void **)&d_cw, n_pairs * 512));
+	if (hipMalloc((void **)&d_st, n_pairs * 2 * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d_cw); return fail("hipMalloc"); }
+	hipError_t e = hipMemcpy(d_cw, cw_pairs, n_pairs * 512, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		sd_launch_rs255_unit(d_cw, (uint32_t)n_pairs, n, d_st, b->d_gfexp, (const uint8_t *)b->d_gflog, b->d_gfswar, nullptr);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpy(cw_pairs, d_cw, n_pairs * 512, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(status, d_st, n_pairs * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+	(void)hipFree(d_cw); (void)hipFree(d_st);
+	return e == hipSuccess ? 0 : fail("sonde_batch_test_rs255", e);
+}
+
 extern "C" uint64_t sonde_batch_nbits(SondeBatch *b, uint32_t channel)
 {
 	if (!b || channel >= b->n_channels) { fail("sonde_batch_nbits: bad argument"); return 0; }

@@ -51,3 +51,36 @@ void sd_launch_framer_rs41(uint32_t n_list, hipStream_t stream, const uint32_t *
 	hipLaunchKernelGGL(sd_rsdec_rs41_kernel, dim3(n_list, (grid_frames + B2_WAVES - 1) / B2_WAVES), dim3(64 * B2_WAVES), 0, stream,
 		bitring, ring_words, gf_exp, gf_log, gf_swar, (const SdFrameDesc *)descs, counts, max_frames, frames, chlist);
 }
+
+// ---- parity-test introspection: the corrector alone on caller-supplied codeword pairs (sonde_batch_test_rs255).  One wave
+// per pair; cw_io holds [n_pairs][2][256] bytes (positions >= n must be zero, as the frame path builds them).
+__global__ __launch_bounds__(64 * B2_WAVES) void sd_rs255_unit_kernel(uint8_t *__restrict__ cw_io, uint32_t n_pairs, int n, int32_t *__restrict__ status,
+	const uint8_t *__restrict__ gf_exp, const uint8_t *__restrict__ gf_log, const uint32_t *__restrict__ gf_swar)
+{
+	__shared__ __attribute__((aligned(16))) FramerTabs tabs;
+	__shared__ __attribute__((aligned(16))) FramerLds wl[B2_WAVES];
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	GfSwar swar;
+	const uint32_t *sw = gf_swar + 8 * (lane % RS_R);
+	swar.a_lo = sw[0]; swar.a_hi = sw[1]; swar.b_lo = sw[2]; swar.b_hi = sw[3]; swar.c = sw[4];
+	for (int i = tid; i < GF_EXP2 / 16; i += 64 * B2_WAVES) reinterpret_cast<uint4 *>(tabs.exp2)[i] = reinterpret_cast<const uint4 *>(gf_exp)[i];
+	if (tid < 512 / 16) reinterpret_cast<uint4 *>(tabs.log2)[tid] = reinterpret_cast<const uint4 *>(gf_log)[tid];
+	__syncthreads();
+	const uint32_t k = B2_WAVES * blockIdx.x + (uint32_t)w;
+	if (k >= n_pairs) return;
+	FramerLds &s = wl[w];
+	uint32_t *io = reinterpret_cast<uint32_t *>(cw_io + (size_t)k * 512);
+	for (int i = lane; i < 128; i += 64) reinterpret_cast<uint32_t *>(s.cw[0])[i] = io[i];      // cw[0] and cw[1] are contiguous
+	WAVE_SYNC();
+	rs255_decode_pair(tabs, s, n, lane, swar);
+	for (int i = lane; i < 128; i += 64) io[i] = reinterpret_cast<uint32_t *>(s.cw[0])[i];
+	if (lane < 2) status[2 * k + lane] = s.status[lane];
+}
+
+void sd_launch_rs255_unit(uint8_t *cw_io, uint32_t n_pairs, int n, int32_t *status, const uint8_t *gf_exp, const uint8_t *gf_log,
+	const uint32_t *gf_swar, hipStream_t stream)
+{
+	hipLaunchKernelGGL(sd_rs255_unit_kernel, dim3((n_pairs + B2_WAVES - 1) / B2_WAVES), dim3(64 * B2_WAVES), 0, stream,
+		cw_io, n_pairs, n, status, gf_exp, gf_log, gf_swar);
+}
+

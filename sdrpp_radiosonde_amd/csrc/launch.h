@@ -38,5 +38,9 @@ void sd_launch_framer_other(int type, uint32_t n_list, hipStream_t stream,
 	const uint8_t *g64, void *descs, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, uint32_t grid_frames, const uint32_t *chlist,
 	bool with_sync /* false: the demod kernel has listed the frames already */);
 
+// parity-test introspection: the RS(255,231) corrector on caller-supplied codeword pairs ([n_pairs][2][256] bytes, device memory)
+void sd_launch_rs255_unit(uint8_t *cw_io, uint32_t n_pairs, int n, int32_t *status, const uint8_t *gf_exp, const uint8_t *gf_log,
+	const uint32_t *gf_swar, hipStream_t stream);
+
 // sets the text sonde_last_error() returns; returns -1
 int sd_fail(const char *what, hipError_t e = hipSuccess);
