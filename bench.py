@@ -228,8 +228,10 @@ def ramp_and_time(submit, sync, args, barrier, reset=None):
     for _ in range(args.steps):
         submit()
     sync()
-    barrier()
-    return time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0     # this rank's K steps; the caller takes the MAX over ranks, which is when the closing
+    barrier()                         # barrier would release -- without charging the barrier's own latency to the steps
+    return dt
 
 
 def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_sum):
