@@ -142,6 +142,10 @@ struct SondeBatch {
 	uint32_t *d_cls[3] = {};
 	uint32_t n_cls[3] = {};
 	int n_classes = 0, only_class = 0;
+	// launch order of the classes of a mixed batch (index: 0 -> decim 1, 1 -> 2, 2 -> 4): the class with the longest-running
+	// workgroups (M10, undecimated) first, RS41 (whose workgroups end with the FEC epilogue) before the 2:1 class; measured over
+	// all six orders for RS41 / M10 / DFM: 0.3537 ms per step, the worst order 0.3667 (profiles/r2_notes.md)
+	int cls_order[3] = { 0, 2, 1 };
 	hipStream_t aux[3] = {};               // side streams so that the per-class launches of a mixed batch overlap
 	hipEvent_t ev_fork = nullptr, ev_join[3] = {};
 	uint32_t granule = SONDE_TILE;         // submit sizes must be a multiple of this
@@ -467,7 +471,8 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		// waiting for the slowest one (a mixed RS41/M10/DFM batch: 0.368 -> see profiles/r2_notes.md)
 		HIPCHK(hipEventRecord(b->ev_fork, stream));
 		int used = 0;
-		for (int k = 0; k < 3; k++) {
+		for (int kk = 0; kk < 3; kk++) {
+			const int k = b->cls_order[kk];
 			if (!b->n_cls[k]) continue;
 			hipStream_t sk = used == 0 ? stream : b->aux[k];
 			if (sk != stream) HIPCHK(hipStreamWaitEvent(sk, b->ev_fork, 0));
