@@ -138,6 +138,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo)
 {
 	__shared__ __attribute__((aligned(16))) DemodLds s;
+#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: a workgroup's life: entry, first round, end of the tile loop
+	__shared__ unsigned long long s_life[3];
+	if (threadIdx.x == 0) s_life[0] = __builtin_amdgcn_s_memtime();
+#endif
 
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
@@ -485,6 +489,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		const bool k4 = framing && SD_K4_WAVE == 3 && rwave == 3;
 		if (k4 && lane == 0) k4_load();
 		__syncthreads();
+#ifdef SD_EPI_TIMESTAMPS
+		if (threadIdx.x == 0) s_life[1] = __builtin_amdgcn_s_memtime();
+#endif
 		int K_total = 0;
 		for (int tile = 0; tile < n_tiles; tile++) {
 			const int b = tile & 1;
@@ -524,6 +531,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		// ---- epilogue of the round role: the last round's update ...
 		if (lead && pendK >= 0) round_back(pendK, (int)((seq & 1u) ^ 1u));
 		if (lead && lane == 0) s.pub.wpos = st.wpos;
+#ifdef SD_EPI_TIMESTAMPS
+		if (threadIdx.x == 0) s_life[2] = __builtin_amdgcn_s_memtime();
+#endif
 		__syncthreads();                                   // (E) matched by the discriminator role's last barrier
 		if (k4) k4_finish();      // ... and K4's catch-up over the last rounds' bits
 	}
@@ -566,6 +576,13 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);
 				d.inv = __builtin_amdgcn_readfirstlane((int)(d1 >> 32));
 				sd_rs41_decode_frame<true>(et.tabs, wl, swar, ring_g, ring_mask, d, fout + k, ch, lane);
+#ifdef SD_EPI_TIMESTAMPS
+				if (lane == 0) {       // words 128..131 (the corrector's stage times, sd_rsdec.h) give way to the workgroup's life
+					uint32_t *dbg = reinterpret_cast<uint32_t *>((fout + k)->data) + 128;
+					const unsigned long long now = __builtin_amdgcn_s_memtime();
+					dbg[0] = (uint32_t)(s_life[1] - s_life[0]); dbg[1] = (uint32_t)(s_life[2] - s_life[1]); dbg[2] = (uint32_t)(now - s_life[2]); dbg[3] = n_tiles;
+				}
+#endif
 			}
 		}
 	}
