@@ -249,25 +249,39 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
     types = None
     blocks = None
     if args.scatter and world > 1:
-        full = None
+        # rank 0 ingests the IQ of ALL channels (the same seamless NB-block signal the rank-local mode generates) and scatters
+        # it block by block: the native scatter (csrc/shard_rccl.cpp: grouped ncclSend / ncclRecv), or
+        # --scatter-torch: dist.scatter.  scatter_ms = the time of all NB scatters, outside the timed region.
+        NB = args.blocks
+        shards = None
         if rank == 0:
-            full = torch.cat([synth.make_rs41_batch(C, n, seed=1000 + r, ebn0_db=args.ebn0, device=dev, first_channel=r * C).iq
-                              for r in range(world)])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        # the native scatter (csrc/shard_rccl.cpp: grouped ncclSend / ncclRecv); --scatter-torch: dist.scatter
-        if args.scatter_torch:
-            iq = scatter_iq(full, C, n, dev, src=0)
-        else:
+            shards = []
+            for r in range(world):
+                if NB > 1:
+                    f = synth.make_rs41_cyclic(C, n, NB, seed=1000 + r, ebn0_db=args.ebn0, device=dev, first_channel=r * C, chunk=128).iq
+                    shards.append([f[:, k * n: (k + 1) * n].contiguous() for k in range(NB)])
+                    del f
+                else:
+                    shards.append([synth.make_rs41_batch(C, n, seed=1000 + r, ebn0_db=args.ebn0, device=dev, first_channel=r * C).iq])
+        ns = None
+        if not args.scatter_torch:
             from sdrpp_radiosonde_amd.shard import NativeShard
             ns = NativeShard(local_rank)
+        blocks, scatter_ms = [], 0.0
+        for k in range(NB):
+            full = torch.cat([shards[r][k] for r in range(world)]) if rank == 0 else None
             torch.cuda.synchronize()
             barrier()
             t0 = time.perf_counter()
-            iq = ns.scatter_iq(full, (C, n, 2), root=0)
-        torch.cuda.synchronize()
-        scatter_ms = (time.perf_counter() - t0) * 1e3
-        del full
+            blk = ns.scatter_iq(full, (C, n, 2), root=0) if ns is not None else scatter_iq(full, C, n, dev, src=0)
+            torch.cuda.synchronize()
+            scatter_ms += (time.perf_counter() - t0) * 1e3
+            blocks.append(blk)
+            del full
+        del shards
+        iq = blocks[0]
+        if NB == 1:
+            blocks = None
     elif args.mix:
         order = (0, 3, 1)
         types = np.array([order[c % 3] for c in range(C)], dtype=np.uint8)
@@ -376,7 +390,8 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                                 f"RS41-SG x {C} channels/GPU x {n} samples per step (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)"
                                 + (f"; {len(blocks)} consecutive blocks of a continuous signal resident in HBM, cycled" if len(blocks) > 1 else "")),
                    "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{world}",
-                   "ingest": "rccl-scatter" if scatter_ms is not None else "rank-local"},
+                   "ingest": ("rank-local" if scatter_ms is None else
+                              "scatter from rank 0: torch.distributed" if args.scatter_torch else "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)")},
         "frames_per_s": round(nfr_total * args.steps / dt, 1),
         "frames_per_step_steady": round(nfr_total, 2),
         "frames_first_submit": nfr_first,
