@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Differential campaign (GPU box): the low-SNR mixed-batch parity test of tests/test_gpu_fuzz_parity.py over many seeds and
+SNRs, plus the RS corrector unit test with fresh random patterns.  usage: python tools/fuzz_campaign.py [n_seeds]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_fuzz_parity as fz  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(2024)
+t0 = time.time()
+for i in range(n):
+    ebn0 = float(rng.uniform(4.0, 16.0))
+    seed = int(rng.integers(10, 10_000))
+    total = fz.run_mixed(ebn0, seed, check_coverage=False)            # raises on the first differing bit, state or frame
+    print(f"[{i + 1}/{n}] Eb/N0 {ebn0:5.2f} dB seed {seed}: {total} frames, identical to the oracle", flush=True)
+for snr in (6.0, 10.0, 20.0):
+    fz.test_afsk_low_snr_bit_exact(snr)
+    print(f"afsk {snr} dB: identical", flush=True)
+print(f"campaign done in {time.time() - t0:.0f} s")
