@@ -184,7 +184,11 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	           is_ims = DEC == 2 && stype == SONDE_IMS100, is_m10 = DEC == 1 && stype == SONDE_M10,
 	           is_mrz = DEC == 2 && stype == SONDE_MRZN1;
 	const bool fuse = fo->fuse_fec != 0;
+#if defined(SD_NO_FRAMING) && !defined(SD_KEEP_K4)      // A/B builds (profiles/r2_notes.md): the demodulator alone / with K4 but no FEC epilogue
+	const bool framing = false;
+#else
 	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10 || is_mrz));   // workgroup-uniform
+#endif
 	if (framing && tid >= SD_WGT - SD_MIRROR_WORDS) {
 		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WGT - 1 - tid);      // the words up to and including wpos's
 		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
@@ -193,7 +197,11 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// K5/K6 in this kernel's epilogue: RS41 only (few, heavy frames per submit).  The short frames of the fixed-length
 	// framers (a DFM frame every 2.7 tiles) decode faster as one wave per frame across the whole GPU (framer2_kernel.hip)
 	// than eight at a time at the end of each workgroup: measured 0.358 vs 0.324 ms per step for 4096 DFM channels.
+#ifdef SD_NO_FRAMING
+	const bool fec_here = false;
+#else
 	const bool fec_here = is_rs41 && fuse;     // workgroup-uniform
+#endif
 	EpiTabs &et = *reinterpret_cast<EpiTabs *>(&s.B[1][SD_EPI_TAB_OFF]);
 	if (fec_here && is_rs41) {
 		// GF(2^8) tables for the epilogue: one 16-byte global load per thread now, hidden behind the first tile's loads
