@@ -154,7 +154,7 @@ def rs41_calibration_memory(channel: int) -> np.ndarray:
     putf(0x75, [RS41_CALH0, 0.0])
     putf(0x125, RS41_CO1); putf(0x131, RS41_CALT1)
     putf(0x25E, [RS41_CFP[k] for k in RS41_CFP_SLOT])                       # pressure polynomial (RS41-SGP)
-    kill = 0xFFFF if channel % 2 == 0 else 3600 + channel          # burst-kill countdown (s); 0xFFFF = not armed
+    kill = 0xFFFF if channel % 2 == 0 else 3600 + channel % 60000          # burst-kill countdown (s); 0xFFFF = not armed
     mem[0x316], mem[0x317] = kill & 0xFF, kill >> 8
     return mem
 
