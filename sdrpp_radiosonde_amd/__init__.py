@@ -1,0 +1,8 @@
+"""MI355X-native radiosonde demod + FEC path: ctypes binding of libsonde_mi355.so (include/sonde_abi.h).
+
+    _lib      the raw C ABI (argtypes / restypes), constants, structures
+    batch     SondeBatch (many 48 kS/s channels), SondeChannelizer (10 MS/s -> 512 bins), SondeVfo (VFO-rate front-end)
+    shard     channel sharding over the GPUs of a node; NativeShard = libsonde_rccl.so (include/sonde_shard.h)
+    synth     synthetic signal generator for all seven sonde types (tests and bench; independent of the decoders' code)
+
+Nothing here computes on the CPU: every entry point needs the HIP library and a GPU (no fallback)."""
