@@ -112,9 +112,12 @@ typedef struct {
 	uint32_t       flags;            /* SONDE_FLAG_*; 0 = defaults */
 } SondeBatchConfig;
 
-/* RS41 channels: decimate IQ 2:1 instead of 4:1 before the discriminator (24 kS/s internally): tolerates +-5 kHz of carrier
- * offset instead of +-1 kHz, at about 2 dB of sensitivity and twice the discriminator arithmetic.  IQ input only. */
-#define SONDE_FLAG_RS41_WIDE 1u
+/* One decimation step less before the discriminator for every GFSK sonde (RS41 / DFM / iMS-100 / MRZ-N1 2:1 instead of 4:1:
+ * 24 kS/s internally; M10 none instead of 2:1: 48 kS/s): tolerates about twice the carrier offset (+-5 kHz instead of +-2 kHz
+ * for RS41, +-10 kHz instead of +-4.5 kHz for M10) at about 2 dB of sensitivity and twice the discriminator arithmetic.
+ * IQ input only. */
+#define SONDE_FLAG_WIDE      1u
+#define SONDE_FLAG_RS41_WIDE SONDE_FLAG_WIDE     /* the flag's name in rounds 1-2, when it moved RS41 only */
 /* RS41 channels: run the Reed-Solomon stage as a kernel of its own behind the demodulator instead of in the demodulator
  * kernel's epilogue (one launch more per submit; same frames).  Kept for A/B measurements. */
 #define SONDE_FLAG_SPLIT_FEC 2u

@@ -24,24 +24,26 @@
 
 #define OR_PI_D     3.14159265358979323846
 
-/* Abramowitz & Stegun 4.4.47 (|err| <= 1e-5 rad on [0,1]) with the discriminator gain 2/pi folded in:
- * A_k * 2/pi rounded to binary32.  Angles are therefore in units of pi/2 ("quadrants"): pi/2 -> 1,
- * pi -> 2, and the discriminator output needs no further scaling. */
-#define AT_A1  0.636534452f    /* 0x3F22F3EC */
-#define AT_A3 -0.210275188f    /* 0xBE575261 */
-#define AT_A5  0.114681326f    /* 0x3DEADE0B */
-#define AT_A7 -0.0541973524f   /* 0xBD5DFE0B */
-#define AT_A9  0.0132640367f   /* 0x3C595167 */
+/* atan2 in quadrants (SPEC 3.1, round 3).  The consumer of the discriminator is a low-pass FIR and a hard slicer, so the
+ * arctangent needs about 1e-3 rad, not 1e-5: one division-free form for the whole first quadrant,
+ *     r = (|x| - |y|) / (|x| + |y|)  in [-1, 1],     angle = pi/4 - atan(r),
+ * (no |y| > |x| swap), a three-term odd minimax polynomial for (2/pi) atan(r) (max error 4.5e-4 quadrant = 7e-4 rad,
+ * constrained to 0.5 at r = 1 so that the octants join), and ONE Newton step on the reciprocal (relative error < 0.26 %,
+ * always from below, so |r| <= 1).  15 VALU operations per sample on the GPU instead of 24.
+ * Coefficients already carry the discriminator gain 2/pi (angles in quadrants: pi/2 -> 1, pi -> 2). */
+#define AT_C1  0.6332877278327942f     /* 0x3F221F25 */
+#define AT_C3 -0.18171308934688568f    /* 0xBE3A12FF */
+#define AT_C5  0.04842534288764f       /* 0x3D4659A7 */
+
+static inline uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
+static inline float u2f(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
 
 /* Reciprocal by Newton-Raphson from an integer-subtract seed: 1 integer op + 6 fmaf, the same
- * sequence on CPU and GPU (an IEEE divide costs the GPU ~13 issue slots and does not pack into
- * v_pk_fma_f32; this does).  Relative error ~1e-7 for normal x > 0.  SPEC 3.1. */
+ * sequence on CPU and GPU (an IEEE divide costs the GPU ~13 issue slots).  Relative error ~1e-7 for normal x > 0.
+ * Used by the loop filter (once per round). */
 float or_recip(float x)
 {
-	union { float f; uint32_t u; } v;
-	v.f = x;
-	v.u = 0x7EF311C7u - v.u;
-	float r = v.f;
+	float r = u2f(0x7EF311C7u - f2u(x));
 	float e = fmaf(-x, r, 1.0f);
 	r = fmaf(r, e, r);
 	e = fmaf(-x, r, 1.0f);
@@ -51,29 +53,24 @@ float or_recip(float x)
 	return r;
 }
 
-static inline uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
-static inline float u2f(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
-#define TINY_BITS 0x0DA24260u   /* 1e-30f: floor of the divisor, so that atan2q(0,0) = 0 without a select */
-
-/* atan2q(y, x) = atan2(y, x) * 2/pi, in [-2, 2]  (SPEC 3.1).  max/min of |x|,|y| are taken on the bit
- * patterns (exact for all non-NaN floats, defined for every input); the octant fix-ups are
- * 1 - p, 2 - p and a final copysign.  NaN inputs are outside the contract. */
+/* atan2q(y, x) = atan2(y, x) * 2/pi, in [-2, 2], |error| <= 2.5e-3 rad.  NaN / Inf inputs are outside the contract;
+ * atan2q(0, 0) = +-0.5 (the divisor is floored at 1e-30). */
 float or_atan2(float y, float x)
 {
-	const uint32_t ax = f2u(x) & 0x7FFFFFFFu, ay = f2u(y) & 0x7FFFFFFFu;
-	uint32_t mxb = ax > ay ? ax : ay;
-	if (mxb < TINY_BITS) mxb = TINY_BITS;
-	const uint32_t mnb = ax < ay ? ax : ay;
-	const float r = u2f(mnb) * or_recip(u2f(mxb));
-	const float s = r * r;
-	float p = fmaf(s, AT_A9, AT_A7);
-	p = fmaf(s, p, AT_A5);
-	p = fmaf(s, p, AT_A3);
-	p = fmaf(s, p, AT_A1);
-	p = p * r;
-	if (ay > ax) p = 1.0f - p;
-	if (f2u(x) >> 31) p = 2.0f - p;
-	return copysignf(p, y);
+	const float ax = u2f(f2u(x) & 0x7FFFFFFFu), ay = u2f(f2u(y) & 0x7FFFFFFFu);
+	const float s = fmaxf(ax + ay, 1.0e-30f);
+	const float d = ax - ay;
+	float rc = u2f(0x7EF311C7u - f2u(s));            /* seed: relative error < 5.1 % */
+	const float e = fmaf(-s, rc, 1.0f);
+	rc = fmaf(rc, e, rc);                            /* one Newton step: < 0.26 % */
+	const float r = d * rc;
+	const float t = r * r;
+	float p = fmaf(t, AT_C5, AT_C3);
+	p = fmaf(t, p, AT_C1);
+	const float q = fmaf(-p, r, 0.5f);               /* first-quadrant angle of (|x|, |y|), in [0, 1] */
+	const float s2 = (f2u(x) >> 31) ? 2.0f : 0.0f;
+	const float q2 = s2 - q;                         /* x < 0: 2 - q */
+	return u2f((f2u(q2) & 0x7FFFFFFFu) | (f2u(y) & 0x80000000u));
 }
 
 /* Quadrature FM discriminator: d[n] = arg(x[n] * conj(x[n-1])) * 2/pi.  In real arithmetic this is
@@ -98,13 +95,13 @@ void or_discriminate(const float *iq, size_t n, float *d, float *last)
 /* ---- modem table.  Baud rates: SURVEY.md Appendix B [RECALL]; VFO bandwidths in
  * /root/reference/src/main.hpp:44-52 bound them from above. ---- */
 static OrModem g_modems[OR_NTYPES] = {
-	{ OR_RS41,   4800.0, 0, 0.65f, 4, 1 },  /* RS41: 4800 Bd GFSK, NRZ; 12 kS/s internally (the reference's VFO is 10 kHz wide, main.hpp:45) */
-	{ OR_DFM09,  5000.0, 0, 0.65f, 2, 1 },  /* DFM: 2500 bit/s Manchester => 5000 chips/s */
-	{ OR_IMS100, 4800.0, 0, 0.65f, 2, 1 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s */
-	{ OR_M10,    9600.0, 0, 0.65f, 1, 1 },  /* M10/M20: 9600 chips/s Manchester: stays at 48 kS/s (5 samples/chip) */
-	{ OR_IMET4,  1200.0, 0, 0.65f, 1, 8 },  /* iMet-1/4: Bell-202 AFSK 1200 Bd; tone demodulator in front, 6 kS/s behind it */
-	{ OR_C50,    2400.0, 0, 0.65f, 1, 8 },  /* SRS-C50: AFSK 2400 Bd (2900 / 4700 Hz); tone demodulator in front, 6 kS/s behind it */
-	{ OR_MRZN1,  4800.0, 0, 0.65f, 2, 1 },  /* MRZ-N1: 2400 bit/s Manchester => 4800 chips/s */
+	{ OR_RS41,   4800.0, 0, 0.65f, 4, 1, 0 },  /* RS41: 4800 Bd GFSK, NRZ; 12 kS/s internally (the reference's VFO is 10 kHz wide, main.hpp:45) */
+	{ OR_DFM09,  5000.0, 0, 0.65f, 4, 1, 0 },  /* DFM: 2500 bit/s Manchester => 5000 chips/s; 12 kS/s (2.4 samples per chip) */
+	{ OR_IMS100, 4800.0, 0, 0.65f, 4, 1, 0 },  /* iMS-100/RS-11G: 2400 bit/s biphase => 4800 chips/s; 12 kS/s */
+	{ OR_M10,    9600.0, 0, 0.65f, 2, 1, 0 },  /* M10/M20: 9600 chips/s Manchester; 24 kS/s (2.5 samples per chip) */
+	{ OR_IMET4,  1200.0, 0, 0.65f, 1, 8, 0 },  /* iMet-1/4: Bell-202 AFSK 1200 Bd; tone demodulator in front, 6 kS/s behind it */
+	{ OR_C50,    2400.0, 0, 0.65f, 1, 8, 0 },  /* SRS-C50: AFSK 2400 Bd (2900 / 4700 Hz); tone demodulator in front, 6 kS/s behind it */
+	{ OR_MRZN1,  4800.0, 0, 0.65f, 4, 1, 0 },  /* MRZ-N1: 2400 bit/s Manchester => 4800 chips/s; 12 kS/s */
 };
 static OrModem g_modem_rt[OR_NTYPES];
 
@@ -122,6 +119,8 @@ const OrModem *or_modem(int type)
 	if (g_modem_rt[type].period0 == 0) {
 		g_modem_rt[type] = g_modems[type];
 		g_modem_rt[type].period0 = (int)llrint(65536.0 * ((double)OR_FS / (g_modems[type].decim * g_modems[type].pre)) / g_modems[type].baud);
+		/* 3.2 symbols of taps: 8 at ~2.5 samples per symbol, 16 at ~5; the AFSK streams keep 16-tap rows (SPEC 3.6) */
+		g_modem_rt[type].nt = (g_modems[type].pre == 1 && 2 * g_modem_rt[type].period0 < 7 * 65536) ? 8 : 16;
 	}
 	return &g_modem_rt[type];
 }
@@ -205,7 +204,7 @@ static void push_bit(OrDemod *d, int b)
 
 /* One tile's worth of symbols.  The number of symbols is fixed when the tile arrives
  * (K_total, from the timing state at that moment) and is split into rounds of at most 256 -- 512 for the
- * streams that are not decimated (M10 at 48 kS/s and the 6 kS/s AFSK streams: up to 410 / 822 symbols per tile), so
+ * streams whose tile holds more than 256 symbols (M10, 410 chips per tile, and the 6 kS/s AFSK streams: up to 822), so
  * that M10 and iMet update the loop once per tile like every other sonde (every 42.7 ms of signal);
  * the loop filter is updated after every round.  OR_LOOKAHEAD_MARGIN samples of slack keep the
  * FIR support inside the data when a mid-tile correction moves the instants later. */
@@ -213,7 +212,8 @@ static void run_rounds(OrDemod *d)
 {
 	const int64_t limit = (((d->n0 - 1 - OR_NT(d->m) / 2 - OR_LOOKAHEAD_MARGIN) << 16) | 0xFFFF);
 	float y[2 * OR_ROUND_MAX], m[2 * OR_ROUND_MAX];
-	const int rmax = d->m->decim == 1 ? 2 * OR_ROUND_MAX : OR_ROUND_MAX;
+	/* rounds of <= 256 symbols; 512 where a tile holds more than 256 (M10: 410 chips per tile; the 6 kS/s AFSK streams) */
+	const int rmax = ((OR_TILE / d->m->decim) / (OR_NT(d->m) == 8 ? 2 : 4) > OR_ROUND_MAX) ? 2 * OR_ROUND_MAX : OR_ROUND_MAX;
 	int64_t K_total = (d->t_next <= limit) ? (limit - d->t_next) / d->period + 1 : 0;
 
 	while (K_total > 0) {
@@ -345,13 +345,14 @@ static void afsk_front(OrDemod *d, const float *src, size_t n_in, int is_iq, flo
 	d->af_n += n_in;
 }
 
-/* One 2048-sample input tile at a time.  Stage K0 (SPEC 3.0): sondes whose symbol rate leaves room
- * are first decimated by a boxcar -- 4:1 for RS41 (z[m] = (x[4m] + x[4m+1]) + (x[4m+2] + x[4m+3]), 12 kS/s behind it),
- * 2:1 for DFM and iMS-100 (z[m] = x[2m] + x[2m+1], 24 kS/s); real discriminator input is averaged the same way --
- * so that the discriminator and everything behind it run at the lower rate.  This is the reference's own ordering (the VFO hands dsp::demod::FM a stream
- * at the channel bandwidth, 10 kS/s for RS41: /root/reference/src/main.cpp:55-57, src/main.hpp:45),
- * halves the arithmetic per input sample and lowers the FM threshold by narrowing the pre-detection
- * noise bandwidth.  M10 (9600 chips/s) stays at 48 kS/s. */
+/* One 2048-sample input tile at a time.  Stage K0 (SPEC 3.0): IQ is first decimated by a boxcar -- 4:1 for the sondes at
+ * about 5000 chips/s (RS41, DFM, iMS-100, MRZ-N1: z[m] = (x[4m] + x[4m+1]) + (x[4m+2] + x[4m+3]), 12 kS/s behind it),
+ * 2:1 for M10 (9600 chips/s: z[m] = x[2m] + x[2m+1], 24 kS/s); real discriminator input is averaged the same way --
+ * so that the discriminator and everything behind it run at about 2.5 samples per symbol.  This is the reference's own
+ * ordering (the VFO hands dsp::demod::FM a stream at the channel bandwidth, 10 kS/s for RS41:
+ * /root/reference/src/main.cpp:55-57, src/main.hpp:45), cuts the arithmetic per input sample and lowers the FM threshold by
+ * narrowing the pre-detection noise bandwidth (2-2.5 dB per halving, profiles/r3_sensitivity.md).  or_modem_set_decim()
+ * moves a type one step wider (the product's SONDE_FLAG_WIDE). */
 void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 {
 	{	/* one allocation per feed instead of doubling reallocs inside the symbol loop (many threads feed at once) */

@@ -41,7 +41,7 @@ extern "C" {
 #define OR_TILE        2048       /* samples per tile */
 #define OR_RING        4096       /* discriminator ring (floats) */
 #define OR_NTAPS       32         /* row length of the polyphase table */
-#define OR_NT(m)       ((m)->decim == 4 ? 8 : 16)   /* taps in use per branch: 3.2 symbols (2.5 or 5 samples per symbol) */
+#define OR_NT(m)       ((m)->nt)   /* taps in use per branch: 3.2 symbols = 8 at ~2.5 samples per symbol, 16 at ~5 (the 6 kS/s AFSK streams: 16) */
 #define OR_NPHASE      32         /* polyphase branches (1/32 sample resolution) */
 #define OR_ROUND_MAX   256        /* max symbols per timing-loop round */
 #define OR_LOOKAHEAD_MARGIN 4     /* samples of slack behind the newest sample */
@@ -55,8 +55,9 @@ typedef struct {
 	double baud;        /* on-air symbol (chip) rate */
 	int    period0;     /* Q16 (internal-rate) samples per symbol = rint(65536*(FS/decim)/baud) */
 	float  cutoff;      /* low-pass cutoff, in units of baud */
-	int    decim;       /* IQ is decimated decim:1 (boxcar) before the discriminator: 4 RS41 (12 kS/s), 2 DFM / iMS-100 (24 kS/s), 1 M10 */
+	int    decim;       /* IQ is decimated decim:1 (boxcar) before the discriminator: 4 RS41 / DFM / iMS-100 / MRZ-N1 (12 kS/s), 2 M10 (24 kS/s) */
 	int    pre;         /* 8: AFSK sonde, the tone demodulator in front delivers FS/8 samples (SPEC 3.6); else 1 */
+	int    nt;          /* taps in use per polyphase row (filled in by or_modem()): 8 below 3.5 samples per symbol, else 16; AFSK: 16 */
 } OrModem;
 
 typedef struct {
@@ -78,7 +79,7 @@ void  or_discriminate(const float *iq, size_t n, float *d, float *last);
 /* ---- stage 2: GFSK demod (sondedump gfsk.c equivalent; SPEC) ---- */
 void  or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS]);
 const OrModem *or_modem(int type);
-void  or_modem_set_decim(int type, int decim);   /* test hook: the product's SONDE_FLAG_RS41_WIDE */
+void  or_modem_set_decim(int type, int decim);   /* test hook: the product's SONDE_FLAG_WIDE (one decimation step less) */
 
 typedef struct OrDemod OrDemod;
 OrDemod *or_demod_new(int type);

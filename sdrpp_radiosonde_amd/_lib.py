@@ -44,7 +44,8 @@ class SondeBatchConfig(C.Structure):
                 ("input_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32)]
 
 
-FLAG_RS41_WIDE = 1
+FLAG_WIDE = 1            # one decimation step less for every GFSK sonde (SONDE_FLAG_WIDE)
+FLAG_RS41_WIDE = FLAG_WIDE
 FLAG_SPLIT_FEC = 2
 
 

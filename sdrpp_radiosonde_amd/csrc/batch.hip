@@ -45,22 +45,33 @@ extern "C" const char *sonde_version(void) { return "sonde_mi355 0.1 (gfx950)"; 
 struct ModemDef { double baud; float cutoff; int decim; int pre; };   // pre = 8: AFSK tone demodulator in front (SPEC 3.6)
 static const ModemDef k_modems[SONDE_NTYPES] = {
 	{ 4800.0, 0.65f, 4, 1 },   // RS41   4800 Bd GFSK NRZ; IQ decimated 4:1 before the discriminator: 12 kS/s (SPEC 3.0)
-	{ 5000.0, 0.65f, 2, 1 },   // DFM    2500 bit/s Manchester -> 5000 chips/s
-	{ 4800.0, 0.65f, 2, 1 },   // iMS100 2400 bit/s biphase    -> 4800 chips/s
-	{ 9600.0, 0.65f, 1, 1 },   // M10    9600 chips/s Manchester: stays at 48 kS/s (5 samples per chip)
+	{ 5000.0, 0.65f, 4, 1 },   // DFM    2500 bit/s Manchester -> 5000 chips/s; 12 kS/s
+	{ 4800.0, 0.65f, 4, 1 },   // iMS100 2400 bit/s biphase    -> 4800 chips/s; 12 kS/s
+	{ 9600.0, 0.65f, 2, 1 },   // M10    9600 chips/s Manchester; 2:1: 24 kS/s (2.5 samples per chip)
 	{ 1200.0, 0.65f, 1, 8 },   // iMet-1/4 Bell-202 AFSK 1200 Bd: tone demodulator, then 6 kS/s through the same loop
 	{ 2400.0, 0.65f, 1, 8 },   // SRS-C50 AFSK 2400 Bd (2900 / 4700 Hz): tone demodulator, then 6 kS/s (2.5 samples per symbol)
-	{ 4800.0, 0.65f, 2, 1 },   // MRZ-N1  2400 bit/s Manchester -> 4800 chips/s
+	{ 4800.0, 0.65f, 4, 1 },   // MRZ-N1  2400 bit/s Manchester -> 4800 chips/s; 12 kS/s
 };
+// (every GFSK sonde runs at about 2.5 samples per symbol behind the boxcar: each halving of the pre-detection bandwidth buys
+// 2-2.5 dB of sensitivity and halves the discriminator arithmetic, profiles/r3_sensitivity.md; SONDE_FLAG_WIDE: one step less)
 
 static int modem_div(const ModemDef *md, int type) { return md[type].decim * md[type].pre; }     // input samples per internal sample
 static int32_t modem_period0(const ModemDef *md, int type) { return (int32_t)llrint(65536.0 * ((double)SD_FS / modem_div(md, type)) / md[type].baud); }
+static int modem_nt(const ModemDef *md, int type) { return SD_NT_OF(modem_period0(md, type), md[type].pre); }
+// demod-kernel class of a (decimation, taps) pair: the instantiations of sd_demod_kernel
+static const int k_cls_decim[4] = { 1, 2, 4, 2 }, k_cls_nt[4] = { 16, 16, 8, 8 };
+static int modem_class(const ModemDef *md, int type)
+{
+	const int d = md[type].decim, nt = modem_nt(md, type);
+	for (int k = 0; k < 4; k++) if (k_cls_decim[k] == d && k_cls_nt[k] == nt) return k;
+	return -1;
+}
 
 static void make_taps(const ModemDef *md, int type, float *out /* [32][32] */)
 {
 	const double PI = 3.14159265358979323846;
 	const double fc = (double)md[type].cutoff * md[type].baud / ((double)SD_FS / modem_div(md, type));
-	const int nt = SD_NT(md[type].decim);              // taps in use
+	const int nt = modem_nt(md, type);                 // taps in use
 	memset(out, 0, sizeof(float) * SD_NPHASE * SD_NTAPS);
 	for (int p = 0; p < SD_NPHASE; p++) {
 		double h[SD_NTAPS], sum = 0.0;
@@ -137,17 +148,17 @@ struct SondeBatch {
 	// AFSK sondes (iMet): tone-demodulator state, mixer table, 6 kS/s scratch rows; the other channels' list for kernel A
 	SdAfskState *d_astates = nullptr;
 	float *d_wtab = nullptr, *d_wtab_c50 = nullptr, *d_afq = nullptr;
-	// kernel A runs once per decimation class (1, 2, 4) of the non-AFSK channels: one class in the batch = one plain
+	// kernel A runs once per (decimation, taps) class of the non-AFSK channels (k_cls_*): one class in the batch = one plain
 	// launch over all channels; several = one launch per class over its channel list
-	uint32_t *d_cls[3] = {};
-	uint32_t n_cls[3] = {};
+	uint32_t *d_cls[4] = {};
+	uint32_t n_cls[4] = {};
 	int n_classes = 0, only_class = 0;
-	// launch order of the classes of a mixed batch (index: 0 -> decim 1, 1 -> 2, 2 -> 4): the class with the longest-running
-	// workgroups (M10, undecimated) first, RS41 (whose workgroups end with the FEC epilogue) before the 2:1 class; measured over
-	// all six orders for RS41 / M10 / DFM: 0.3537 ms per step, the worst order 0.3667 (profiles/r2_notes.md)
-	int cls_order[3] = { 0, 2, 1 };
-	hipStream_t aux[3] = {};               // side streams so that the per-class launches of a mixed batch overlap
-	hipEvent_t ev_fork = nullptr, ev_join[3] = {};
+	// launch order of the classes of a mixed batch: the class with the longest-running workgroups (M10: twice the symbols
+	// per tile) first, then the 4:1 class (whose RS41 workgroups end with the FEC epilogue); round 2 measured all six orders of
+	// its three classes: 0.3537 ms per step for this rule, the worst order 0.3667 (profiles/r2_notes.md)
+	int cls_order[4] = { 3, 0, 2, 1 };
+	hipStream_t aux[4] = {};               // side streams so that the per-class launches of a mixed batch overlap
+	hipEvent_t ev_fork = nullptr, ev_join[4] = {};
 	uint32_t granule = SONDE_TILE;         // submit sizes must be a multiple of this
 
 	static const int kEvSlots = 128;       // submits timed between two sonde_batch_kernel_ms() calls
@@ -181,8 +192,8 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	for (int k = 0; k < 2; k++) { (void)hipFree(b->d_frames2[k]); (void)hipFree(b->d_counts2[k]); (void)hipFree(b->d_fo2[k]); if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]); }
 	if (b->ev_xs) (void)hipEventDestroy(b->ev_xs);
 	(void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
-	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_wtab_c50); (void)hipFree(b->d_afq); for (int k = 0; k < 3; k++) (void)hipFree(b->d_cls[k]);
-	for (int k = 0; k < 3; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
+	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_wtab_c50); (void)hipFree(b->d_afq); for (int k = 0; k < 4; k++) (void)hipFree(b->d_cls[k]);
+	for (int k = 0; k < 4; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
 	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_g64); (void)hipFree(b->d_m10tab); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
@@ -208,7 +219,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	b->input_kind = cfg->input_kind;
 	b->device = cfg->device;
 	for (int t = 0; t < SONDE_NTYPES; t++) b->md[t] = k_modems[t];
-	if ((cfg->flags & SONDE_FLAG_RS41_WIDE) && cfg->input_kind == SONDE_INPUT_IQ) b->md[SONDE_RS41].decim = 2;
+	if ((cfg->flags & SONDE_FLAG_WIDE) && cfg->input_kind == SONDE_INPUT_IQ)
+		for (int t = 0; t < SONDE_NTYPES; t++) if (b->md[t].pre == 1) b->md[t].decim /= 2;       // one decimation step less (SPEC 3.0)
 	const ModemDef *md = b->md;
 	b->types.assign(cfg->n_channels, SONDE_RS41);
 	if (cfg->types) b->types.assign(cfg->types, cfg->types + cfg->n_channels);
@@ -257,19 +269,20 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size() + b->chlist[SONDE_C50].size();      // tone-demodulated sondes
-	std::vector<uint32_t> cls[3];               // index: 0 -> decim 1, 1 -> decim 2, 2 -> decim 4
+	std::vector<uint32_t> cls[4];               // index: demod-kernel class (k_cls_decim, k_cls_nt)
 	for (uint32_t c = 0; c < b->n_channels; c++) {
 		if (b->types[c] == SONDE_IMET4 || b->types[c] == SONDE_C50) continue;
-		const int d = md[b->types[c]].decim;
-		cls[d == 4 ? 2 : d - 1].push_back(c);
+		const int k = modem_class(md, b->types[c]);
+		if (k < 0) { sonde_batch_destroy(b); return fail("sonde_batch_create: no demodulator class for this sonde type"); }
+		cls[k].push_back(c);
 	}
-	for (int k = 0; k < 3; k++) {
+	for (int k = 0; k < 4; k++) {
 		b->n_cls[k] = (uint32_t)cls[k].size();
-		if (b->n_cls[k]) { b->n_classes++; b->only_class = k == 2 ? 4 : k + 1; }
+		if (b->n_cls[k]) { b->n_classes++; b->only_class = k; }
 	}
 	const bool need_lists = n_afsk != 0 || b->n_classes > 1;
 	if (need_lists)
-		for (int k = 0; k < 3; k++) if (b->n_cls[k]) ALLOC(b->d_cls[k], cls[k].size() * sizeof(uint32_t));
+		for (int k = 0; k < 4; k++) if (b->n_cls[k]) ALLOC(b->d_cls[k], cls[k].size() * sizeof(uint32_t));
 	if (n_afsk) {
 		if (cfg->max_samples % (SONDE_TILE * SD_AF_DEC)) { sonde_batch_destroy(b); return fail("sonde_batch_create: with iMet channels max_samples must be a multiple of 16384"); }
 		b->granule = SONDE_TILE * SD_AF_DEC;
@@ -293,8 +306,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		modems[t].pmax = p0 + (p0 >> 8);
 		modems[t].decim = md[t].decim;
 		modems[t].itile = SD_TILE / md[t].decim;      // AFSK: kernel A sees the 6 kS/s stream as plain real input
-		modems[t].nt = SD_NT(md[t].decim);
-		const int rmax = SD_ROUND_MAX * SD_ROUND_SPL(modems[t].decim);
+		modems[t].nt = modem_nt(md, t);
+		const int rmax = SD_ROUND_MAX * SD_ROUND_SPL(modems[t].decim, modems[t].nt);
 		modems[t].rounds = (int32_t)(((((int64_t)modems[t].itile << 16) / modems[t].pmin) + 2 + rmax - 1) / rmax);   // 1; 2: C50
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -390,7 +403,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		CHK(hipMemcpy(b->d_wtab_c50, wc, sizeof(wc), hipMemcpyHostToDevice));
 		CHK(hipMemset(b->d_astates, 0, C * sizeof(SdAfskState)));
 	}
-	for (int k = 0; k < 3; k++)
+	for (int k = 0; k < 4; k++)
 		if (b->d_cls[k]) CHK(hipMemcpy(b->d_cls[k], cls[k].data(), cls[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty())
@@ -398,7 +411,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) CHK(hipEventCreateWithFlags(&b->ev[i], SD_EV_TIMING));
 	if (need_lists) {
 		CHK(hipEventCreateWithFlags(&b->ev_fork, SD_EV_ORDER));
-		for (int k = 0; k < 3; k++) {
+		for (int k = 0; k < 4; k++) {
 			CHK(hipStreamCreateWithFlags(&b->aux[k], hipStreamNonBlocking));
 			CHK(hipEventCreateWithFlags(&b->ev_join[k], SD_EV_ORDER));
 		}
@@ -460,7 +473,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	};
 	const bool one_launch = !n_afsk && b->n_classes == 1;
 	if (one_launch) {
-		sd_launch_demod(iq, b->only_class, b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
+		sd_launch_demod(iq, k_cls_decim[b->only_class], k_cls_nt[b->only_class], b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo);
 		HIPCHK(hipGetLastError());
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
@@ -471,17 +484,16 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		// waiting for the slowest one (a mixed RS41/M10/DFM batch: 0.368 -> see profiles/r2_notes.md)
 		HIPCHK(hipEventRecord(b->ev_fork, stream));
 		int used = 0;
-		for (int kk = 0; kk < 3; kk++) {
+		for (int kk = 0; kk < 4; kk++) {
 			const int k = b->cls_order[kk];
 			if (!b->n_cls[k]) continue;
 			hipStream_t sk = used == 0 ? stream : b->aux[k];
 			if (sk != stream) HIPCHK(hipStreamWaitEvent(sk, b->ev_fork, 0));
-			const int decim = k == 2 ? 4 : k + 1;
-			sd_launch_demod(iq, decim, b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
+			sd_launch_demod(iq, k_cls_decim[k], k_cls_nt[k], b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
 				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_cls[k], false, fo);
 			HIPCHK(hipGetLastError());
 			for (int t = 0; t < SONDE_NTYPES; t++)
-				if (t != SONDE_IMET4 && t != SONDE_C50 && b->md[t].decim == decim && launch_framers(t, sk)) return -1;
+				if (t != SONDE_IMET4 && t != SONDE_C50 && modem_class(b->md, t) == k && launch_framers(t, sk)) return -1;
 			if (sk != stream) { HIPCHK(hipEventRecord(b->ev_join[k], sk)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[k], 0)); }
 			used++;
 		}
@@ -496,7 +508,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 				float *rows = b->d_afq + row0 * (size_t)(b->max_samples / SD_AF_DEC);
 				sd_launch_afsk(t, iq, (uint32_t)nt, stream, (const float *)samples, channel_stride, n_tiles,
 					b->d_chlist[t], b->d_astates, t == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
-				sd_launch_demod(false, 1, (uint32_t)nt, stream, rows, nq, (int)(nq / SONDE_TILE),
+				sd_launch_demod(false, 1, 16, (uint32_t)nt, stream, rows, nq, (int)(nq / SONDE_TILE),
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[t], true, fo);
 				HIPCHK(hipGetLastError());
 				if (launch_framers(t, stream)) return -1;

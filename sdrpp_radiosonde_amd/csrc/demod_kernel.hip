@@ -48,9 +48,7 @@ __device__ __forceinline__ int wave_sum(int v)
 #define SD_LH      64     // samples of history kept in front of the tile in LDS
 #define SD_BUF     (SD_LH + SD_TILE + 4)
 #define SD_WGT     512    // workgroup: waves 0-3 run the timing-loop rounds, waves 4-7 the discriminator
-#ifndef SD_K4_WAVE
-#define SD_K4_WAVE 3      // which wave runs the RS41 sync search (K4): 3 = last round wave, 7 = last discriminator wave
-#endif
+// K4 (sync search) runs on round wave 3; on a discriminator wave it measured equal for RS41 and 40 % slower for DFM (profiles/r2_notes.md)
 
 // LDS: the discriminator samples of [tile_start - 64, tile_end) twice, so that every (d[x], d[x+1])
 // pair the FIR needs is one 8-byte-aligned ds_read_b64 with an immediate offset:
@@ -126,10 +124,11 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 // latency-bound chain (loop update -> FIR reads -> reduction).  Running them as different waves of the
 // same workgroup doubles the waves per SIMD and lets the hardware overlap them; the only hand-over is
 // the double-buffered LDS tile, one s_barrier per tile (two for sondes with > 256 symbols per tile).
-// LIST: work on the channels of `chlist` (mixed batches); the plain instantiation ignores it.  DEC: the decimation
-// factor of every channel of this launch (the host launches once per class), so that the three discriminator
-// variants do not share one register allocation.
-template <bool IS_IQ, bool LIST, int DEC>
+// LIST: work on the channels of `chlist` (mixed batches); the plain instantiation ignores it.  DEC, NT: the decimation
+// factor and the taps per filter row of every channel of this launch (the host launches once per class), so that the
+// discriminator and FIR variants do not share one register allocation.  Classes in use: (4, 8) RS41 / DFM / iMS-100 / MRZ-N1,
+// (2, 8) M10, (2, 16) and (1, 16) the same two groups under SONDE_FLAG_WIDE, (1, 16) also the 6 kS/s AFSK streams.
+template <bool IS_IQ, bool LIST, int DEC, int NT>
 __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
@@ -152,45 +151,76 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const uint32_t ch = LIST ? chlist[blockIdx.x] : blockIdx.x;        // channel (state, bit ring)
 	const uint32_t row = (LIST && compact_in) ? blockIdx.x : ch;       // row of `in`
 
+	// ---- discriminator waves: the first two tiles' loads go out before anything else (see the prologue note below)
+	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
+	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
+	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)row * ch_stride);
+	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
+	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
+	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
+	// of the same wave at r - 1 (no extra load); only each wave's very first sample needs the float4 before it.
+	const int kw = wave & 3;
+	auto f4_index = [&](int r) { return SD_WG / 4 * (NLD * kw + r) + lane; };      // float4 index inside the tile
+	auto load_vec = [&](int tile, float4 (&v)[NLD]) {
+#pragma unroll
+		for (int r = 0; r < NLD; r++) {                    // read-once data: streaming (nontemporal) loads
+			const sd_f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const sd_f32x4 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
+			v[r] = make_float4(q.x, q.y, q.z, q.w);
+		}
+	};
+	if (is_k) {
+		load_vec(0, va);
+		if (n_tiles > 1) load_vec(1, vb);
+	}
+
 	SdChanState st = states[ch];
 	const SdModem md = modems[st.type];
 	const int rounds = md.rounds;          // sub-phases (= barriers) per tile: 1, or 2 for the SRS-C50 6 kS/s stream
-	const int IT = md.itile;               // internal samples per input tile: 1024 after 2:1 decimation, else 2048
+	constexpr int IT = SD_TILE / DEC;      // internal samples per input tile (= md.itile)
 	constexpr bool dec2 = DEC == 2, dec4 = DEC == 4;
-	const float *taps_g = taps_all + (size_t)st.type * SD_NPHASE * SD_NTAPS;
-	for (int i = tid; i < SD_NPHASE * SD_NTAPS; i += SD_WGT)
-		s.taps[(i >> 5) * SD_TAPS_LD + ((i & 31) ^ 1)] = taps_g[i];     // pair-swapped rows, see interp()
-	// restore the carried history in front of the first tile (both copies)
-	if (tid < SD_LH) {
-		const float hv = hist[(size_t)ch * SD_HIST + tid];
-		s.A[0][tid] = hv;
-		if (tid) s.B[0][tid - 1] = hv;
-	}
+	// ---- prologue, round waves only (tid < 256): taps, carried history, bit-ring words, GF tables -> LDS.  The discriminator
+	// waves issue the first two tiles' loads right away instead (below): a wave's vector loads retire in order (vmcnt), so a
+	// wave that has to wait for its share of the taps cannot have tile loads in flight behind them; with the state -> taps
+	// chain (two dependent global loads) and the first tile's HBM round trip in parallel a workgroup reaches its first round
+	// in ~4 us instead of ~7 (tools/life_probe.py).
 	uint32_t *ring_g = bitring + (size_t)ch * ring_words;
 	const uint32_t ring_mask = ring_words - 1;
-	if (tid == 0) {
-		s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
-		s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
-		s.pub.flag = 0;
-		s.pub.wpos = st.wpos;
+	if (!is_k) {
+		const float4 *taps_g = reinterpret_cast<const float4 *>(taps_all + (size_t)st.type * SD_NPHASE * SD_NTAPS);
+		const float4 tv = taps_g[tid];                                   // 32 rows x 8 float4: one 16-byte load per lane
+		// pair-swapped rows (T[2i] = H[2i+1], T[2i+1] = H[2i]), see interp()
+		*reinterpret_cast<float4 *>(&s.taps[(tid >> 3) * SD_TAPS_LD + 4 * (tid & 7)]) = make_float4(tv.y, tv.x, tv.w, tv.z);
+		// restore the carried history in front of the first tile (both copies)
+		if (tid < SD_LH) {
+			const float hv = hist[(size_t)ch * SD_HIST + tid];
+			s.A[0][tid] = hv;
+			if (tid) s.B[0][tid - 1] = hv;
+		}
+		if (tid == 0) {
+			s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
+			s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
+			s.pub.flag = 0;
+			s.pub.wpos = st.wpos;
+		}
 	}
 	// K4: the sync search of the framed sondes runs in here, on round wave 3, over an LDS mirror of the newest ring words
 	// (RS41 always; DFM / iMS-100 / M10 unless the batch asked for the stand-alone framer kernels)
-	// Which sonde types an instantiation can meet follows from its decimation factor (batch.hip k_modems): 4 -> RS41;
-	// 2 -> DFM, iMS-100, MRZ-N1, RS41 in wide mode; 1 -> M10 (and the iMet 6 kS/s stream, which is framed elsewhere).  Testing DEC
-	// first lets the compiler drop the other types' code from each instantiation.
+	// Which sonde types an instantiation can meet follows from its class (batch.hip k_modems): (4, 8) and, wide, (2, 16) ->
+	// RS41, DFM, iMS-100, MRZ-N1; (2, 8) and, wide, (1, 16) -> M10 (and the AFSK 6 kS/s streams, which are framed elsewhere).
+	// Testing the class first lets the compiler drop the other types' code from each instantiation.
+	constexpr bool cls_slow = DEC == 4 || (DEC == 2 && NT == 16);     // the ~5000 chips/s sondes
 	const int stype = __builtin_amdgcn_readfirstlane(st.type);
-	const bool is_rs41 = DEC != 1 && stype == SONDE_RS41, is_dfm = DEC == 2 && stype == SONDE_DFM09,
-	           is_ims = DEC == 2 && stype == SONDE_IMS100, is_m10 = DEC == 1 && stype == SONDE_M10,
-	           is_mrz = DEC == 2 && stype == SONDE_MRZN1;
+	const bool is_rs41 = cls_slow && stype == SONDE_RS41, is_dfm = cls_slow && stype == SONDE_DFM09,
+	           is_ims = cls_slow && stype == SONDE_IMS100, is_m10 = !cls_slow && stype == SONDE_M10,
+	           is_mrz = cls_slow && stype == SONDE_MRZN1;
 	const bool fuse = fo->fuse_fec != 0;
 #if defined(SD_NO_FRAMING) && !defined(SD_KEEP_K4)      // A/B builds (profiles/r2_notes.md): the demodulator alone / with K4 but no FEC epilogue
 	const bool framing = false;
 #else
 	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10 || is_mrz));   // workgroup-uniform
 #endif
-	if (framing && tid >= SD_WGT - SD_MIRROR_WORDS) {
-		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WGT - 1 - tid);      // the words up to and including wpos's
+	if (framing && !is_k && tid >= SD_WG - SD_MIRROR_WORDS) {                               // round wave 3, the wave that runs K4
+		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WG - 1 - tid);       // the words up to and including wpos's
 		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
 	}
 
@@ -203,8 +233,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const bool fec_here = is_rs41 && fuse;     // workgroup-uniform
 #endif
 	EpiTabs &et = *reinterpret_cast<EpiTabs *>(&s.B[1][SD_EPI_TAB_OFF]);
-	if (fec_here && is_rs41) {
-		// GF(2^8) tables for the epilogue: one 16-byte global load per thread now, hidden behind the first tile's loads
+	if (fec_here && is_rs41 && !is_k) {
+		// GF(2^8) tables for the epilogue: one 16-byte global load per round-wave thread now, hidden behind the first tile's loads
+		static_assert(GF_EXP2 / 16 + 512 / 16 + RS_R * 8 * 4 / 16 <= SD_WG, "the round waves load the GF tables");
 		if (tid < GF_EXP2 / 16) reinterpret_cast<uint4 *>(et.tabs.exp2)[tid] = reinterpret_cast<const uint4 *>(fo->gf_exp)[tid];
 		else if (tid < GF_EXP2 / 16 + 512 / 16) reinterpret_cast<uint4 *>(et.tabs.log2)[tid - GF_EXP2 / 16] = reinterpret_cast<const uint4 *>(fo->gf_log)[tid - GF_EXP2 / 16];
 		else if (tid < GF_EXP2 / 16 + 512 / 16 + RS_R * 8 * 4 / 16)
@@ -212,25 +243,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	}
 
 	// ================================================================ discriminator role (waves 4-7)
-	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
-	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
-	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)row * ch_stride);
-	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
 	float4 pa, pb, qa, qb;                 // the float4s (two input samples each) just before the wave's first one: -1 (pa, pb), -2 (qa, qb)
 	qa = qb = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
 	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);
-	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
-	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
-	// of the same wave at r - 1 (no extra load); only each wave's very first sample needs the float4 before it.
-	const int kw = wave & 3;
-	auto f4_index = [&](int r) { return SD_WG / 4 * (NLD * kw + r) + lane; };      // float4 index inside the tile
-
-	auto load_tile = [&](int tile, float4 (&v)[NLD], float4 &pv, float4 &pw) {
-#pragma unroll
-		for (int r = 0; r < NLD; r++) {                    // read-once data: streaming (nontemporal) loads
-			const sd_f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const sd_f32x4 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
-			v[r] = make_float4(q.x, q.y, q.z, q.w);
-		}
+	auto load_prev = [&](int tile, float4 &pv, float4 &pw) {
 		if (IS_IQ) {
 			// the two float4s just before this wave's first one: wave-uniform addresses, so scalar loads (no VGPRs,
 			// not counted by vmcnt); at the very start of the stream they stand for the carried (decimated) sample.
@@ -246,6 +262,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			}
 		}
 	};
+	auto load_tile = [&](int tile, float4 (&v)[NLD], float4 &pv, float4 &pw) { load_vec(tile, v); load_prev(tile, pv, pw); };
 	// K0+K1: (2:1 boxcar decimation,) d[n] = atan2q(z[n] * conj(z[n-1])), straight into buffer b
 	auto k1_tile = [&](int b, const float4 (&v)[NLD], const float4 &pv, const float4 &pw) {
 		// lane 0's predecessor (decimated) sample; after each load: lane 63's last sample
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 
 	// FIR at this lane's symbol + Gardner term + slicer, integer statistics of the round -> LDS
 	// SPL symbols per lane: symbol k = 256 h + t of the round, h < SPL (the undecimated streams hold up to 410 / 822 symbols per tile)
-	constexpr int SPL = SD_ROUND_SPL(DEC);
+	constexpr int SPL = SD_ROUND_SPL(DEC, NT);
 	auto round_front = [&](int K, int b, int par) {
 		int Ei = 0, S1i = 0, S0i = 0, C1 = 0;
 #pragma unroll
@@ -333,13 +350,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			if (act) {
 				const int64_t base = (n0 - IT - SD_LH) << 16;
 				const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)k * (uint32_t)period;
-				if (dec4) {                                       // 2.5 samples per symbol: 8 taps = 3.2 symbols
-					y = interp<8>(s.A[b], s.B[b], s.taps, rel);
-					m = interp<8>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
-				} else {
-					y = interp<16>(s.A[b], s.B[b], s.taps, rel);
-					m = interp<16>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
-				}
+				y = interp<NT>(s.A[b], s.B[b], s.taps, rel);          // 3.2 symbols of taps (8 at 2.5 samples per symbol)
+				m = interp<NT>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
 			}
 			const float yprev = __shfl_up(y, 1, 64);
 			float e = (yprev - y) * (m - bias);
@@ -451,15 +463,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		}
 	};
 	if (is_k) {
-		const bool k4d = framing && SD_K4_WAVE == 7 && wave == 7;
-		if (k4d && lane == 0) k4_load();
-		// K4 on a discriminator wave: behind its loads, over the bits the lead wave has announced by then (LDS operations
-		// of a wave are performed in order, so whoever sees the new wpos also sees the mirror words written before it)
-		auto k4_step = [&]() {
-			if (k4d) k4_run(sd_uniform64(__hip_atomic_load(&s.pub.wpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
-		};
-		load_tile(0, va, pa, qa);
-		if (n_tiles > 1) load_tile(1, vb, pb, qb);
+		load_prev(0, pa, qa);              // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
+		if (n_tiles > 1) load_prev(1, pb, qb);
 		k1_tile(0, va, pa, qa);
 		if (n_tiles > 2) load_tile(2, va, pa, qa);
 		__syncthreads();
@@ -472,7 +477,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				k1_tile(1, vb, pb, qb);
 				if (tile + 3 < n_tiles) load_tile(tile + 3, vb, pb, qb);
 			}
-			k4_step();
 			for (int r = 0; r < rounds; r++) __syncthreads();
 			if (tile + 1 >= n_tiles) break;
 			if (tile + 2 < n_tiles) {
@@ -481,12 +485,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				k1_tile(0, va, pa, qa);
 				if (tile + 4 < n_tiles) load_tile(tile + 4, va, pa, qa);
 			}
-			k4_step();
 			for (int r = 0; r < rounds; r++) __syncthreads();
 		}
 		if (IS_IQ && t == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
 		__syncthreads();                                   // (E)
-		if (k4d) k4_finish();
 	} else {
 		// the round waves are the critical path of a tile (update -> FIR -> reduction, all dependent);
 		// the discriminator waves only have to be done by the next barrier: let the round waves win
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (lead) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
 		// K4 (wave 3 of an RS41 channel only): its state sits in LDS between steps, the output pointers in a
 		// descriptor in HBM -- scalar registers are the scarce resource of this kernel
-		const bool k4 = framing && SD_K4_WAVE == 3 && rwave == 3;
+		const bool k4 = framing && rwave == 3;
 		if (k4 && lane == 0) k4_load();
 		__syncthreads();
 #ifdef SD_EPI_TIMESTAMPS
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				if (lead) {
 					if (pendK >= 0) round_back(pendK, par ^ 1);       // the previous round's update
 					if (r == 0) {
-						const int64_t limit = (((n0 - 1 - md.nt / 2 - SD_MARGIN) << 16) | 0xFFFF);
+						const int64_t limit = (((n0 - 1 - NT / 2 - SD_MARGIN) << 16) | 0xFFFF);
 						K_total = (st.t_next <= limit) ? (int)((uint32_t)(limit - st.t_next) / (uint32_t)st.period) + 1 : 0;
 					}
 					K = K_total > SPL * SD_ROUND_MAX ? SPL * SD_ROUND_MAX : K_total;
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	}
 }
 
-void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
+void sd_launch_demod(bool is_iq, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */)
@@ -605,9 +607,10 @@ void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t str
 	const int ci = compact_in ? 1 : 0;
 #define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo
 #define SD_DEMOD_LAUNCH(IQ, LS) do { \
-		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 4>), g, blk, 0, stream, SD_DEMOD_ARGS); \
-		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 2>), g, blk, 0, stream, SD_DEMOD_ARGS); \
-		else hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 1>), g, blk, 0, stream, SD_DEMOD_ARGS); } while (0)
+		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
+		else if (decim == 2 && nt == 8) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
+		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 2, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); \
+		else hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 1, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); } while (0)
 	if (is_iq && !chlist) SD_DEMOD_LAUNCH(true, false);
 	else if (is_iq) SD_DEMOD_LAUNCH(true, true);
 	else if (!chlist) SD_DEMOD_LAUNCH(false, false);

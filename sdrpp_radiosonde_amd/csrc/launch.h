@@ -6,7 +6,7 @@
 
 // chlist: null = channels 0..n_channels-1 read their own row of `in`; else block i works on channel chlist[i] and reads
 // row chlist[i] (compact_in = false: the caller's buffer) or row i (compact_in = true: a per-list scratch buffer)
-// decim: the decimation factor (1, 2, 4) of EVERY channel this launch works on
+// decim, nt: the decimation factor (1, 2, 4) and the taps per filter row (8, 16) of EVERY channel this launch works on: (4, 8), (2, 8), (2, 16), (1, 16)
 // where the in-kernel sync search of the RS41 channels (sd_rs41.h) keeps its state and lists the complete frames
 // and, for the FEC epilogue of the same kernel (sd_rsdec.h), the GF(2^8) tables and the frame slots
 struct SdFramerOut {
@@ -16,7 +16,7 @@ struct SdFramerOut {
 	const uint8_t *gf64;                    // GF(2^6) tables of the iMS-100 BCH decoder
 	SondeFrame *frames;
 };
-void sd_launch_demod(bool is_iq, int decim, uint32_t n_channels, hipStream_t stream,
+void sd_launch_demod(bool is_iq, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */);

@@ -4,13 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Abramowitz & Stegun 4.4.47 with the discriminator gain 2/pi folded in (angles in quadrants:
-// pi/2 -> 1, pi -> 2); same binary32 constants as the oracle
-#define AT_A1  0.636534452f
-#define AT_A3 -0.210275188f
-#define AT_A5  0.114681326f
-#define AT_A7 -0.0541973524f
-#define AT_A9  0.0132640367f
+// Three-term odd minimax polynomial for (2/pi) atan(r) on [-1, 1] (max error 4.5e-4 quadrant, 0.5 at r = 1), discriminator
+// gain 2/pi folded in (angles in quadrants: pi/2 -> 1, pi -> 2); same binary32 constants as the oracle (SPEC 3.1)
+#define AT_C1  0.6332877278327942f     // 0x3F221F25
+#define AT_C3 -0.18171308934688568f    // 0xBE3A12FF
+#define AT_C5  0.04842534288764f       // 0x3D4659A7
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -44,32 +42,26 @@ __device__ __forceinline__ float sd_recip(float x)
 	return r;
 }
 
-// atan2q(y, x) in quadrants, [-2, 2]: SPEC 3.1.  Scalar on purpose: on gfx950 a v_pk_fma_f32 costs as
-// much VALU time as two v_fmac_f32 (measured, tools/ubench/valu_rate.hip) and packing needs operand
-// shuffles; the eight samples of a lane give the scheduler independent chains instead.
-// max/min of the magnitudes are single VOP3 instructions with |.| source modifiers (equal to the
-// oracle's integer max/min of the bit patterns for every non-NaN input); 1e-30 floors the divisor
-// so atan2q(0,0) = 0 with no select.
+// atan2q(y, x) in quadrants, [-2, 2]: SPEC 3.1 (round 3).  The consumer is a low-pass FIR and a hard slicer: 2e-3 rad is
+// plenty.  r = (|x| - |y|) / (|x| + |y|) covers the whole first quadrant with one polynomial (angle = 1/2 - f(r), no
+// |y| > |x| swap), the reciprocal takes ONE Newton step from the integer-subtract seed (relative error < 0.26 %, from below,
+// so |r| <= 1): 15 VALU operations, all 2-operand or inline-constant forms, against 24 for the round-2 version (A&S 4.4.47
+// with three Newton steps and two octant fix-ups); the M10 class was 85 % VALU-issue bound on that (profiles/r2_v4_class_counters.csv).
+// Scalar on purpose: on gfx950 a v_pk_fma_f32 costs as much VALU time as two v_fmac_f32 (tools/ubench/valu_rate.hip).
 __device__ __forceinline__ float sd_atan2q(float y, float x)
 {
-	const float tiny = 1.0e-30f;
-	float mx, mn;
-	asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mx) : "v"(y), "v"(x), "v"(tiny));
-	asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(y), "v"(x));
-	const float r = mn * sd_recip(mx);
-	const float sq = r * r;
-	float p = __builtin_fmaf(sq, AT_A9, AT_A7);
-	p = __builtin_fmaf(sq, p, AT_A5);
-	p = __builtin_fmaf(sq, p, AT_A3);
-	p = __builtin_fmaf(sq, p, AT_A1);
-	p = p * r;
-	// octant fix-ups, arithmetic form (cheap 2-operand ALU ops instead of compare+select pairs):
-	//   |y|>|x|: p = 1 - p      x<0: p = 2 - p      sign from y
-	const float dxy = __builtin_fabsf(x) - __builtin_fabsf(y);                                   // < 0 iff |y| > |x|
-	const float s1 = __uint_as_float((uint32_t)((int32_t)__float_as_uint(dxy) >> 31) & 0x3F800000u);   // 1.0 or 0.0
-	const float q1 = s1 - p;                                                                     // |q1| = 1-p or p
+	const float s = __builtin_fmaxf(__builtin_fabsf(x) + __builtin_fabsf(y), 1.0e-30f);
+	const float d = __builtin_fabsf(x) - __builtin_fabsf(y);
+	float rc = __uint_as_float(0x7EF311C7u - __float_as_uint(s));
+	const float e = __builtin_fmaf(-s, rc, 1.0f);
+	rc = __builtin_fmaf(rc, e, rc);
+	const float r = d * rc;
+	const float t = r * r;
+	float p = __builtin_fmaf(t, AT_C5, AT_C3);
+	p = __builtin_fmaf(t, p, AT_C1);
+	const float q = __builtin_fmaf(-p, r, 0.5f);                                                   // angle of (|x|, |y|), [0, 1]
 	const float s2 = __uint_as_float((uint32_t)((int32_t)__float_as_uint(x) >> 31) & 0x40000000u);     // 2.0 or 0.0
-	const float q2 = s2 - __builtin_fabsf(q1);                                                   // |q2| = 2-|q1| or |q1|
+	const float q2 = s2 - q;                                                                       // x < 0: 2 - q
 	return __builtin_copysignf(q2, y);
 }
 

@@ -10,11 +10,13 @@
 #define SD_TILE       2048        // samples per tile
 #define SD_RING       4096        // discriminator ring, floats (LDS)
 #define SD_NTAPS      32          // row length of the polyphase tap table
-#define SD_NT(decim)  ((decim) == 4 ? 8 : 16)   // taps in use per row: 3.2 symbols (SPEC 3.2)
+// taps in use per row: 3.2 symbols (SPEC 3.2) = 8 below 3.5 samples per symbol, else 16; the 6 kS/s AFSK streams (pre = 8) keep 16
+#define SD_NT_OF(period0, pre)  (((pre) == 1 && 2 * (int64_t)(period0) < 7 * 65536) ? 8 : 16)
 #define SD_NPHASE     32
 #define SD_TAPS_LD    36          // padded leading dimension of the tap table in LDS (16-B aligned rows)
-#define SD_ROUND_MAX  256         // symbols per timing-loop round = round lanes of the demod kernel; streams that are not decimated
-#define SD_ROUND_SPL(decim) ((decim) == 1 ? 2 : 1)   // (M10, the 6 kS/s AFSK streams) take two symbols per lane: rounds of <= 512
+#define SD_ROUND_MAX  256         // symbols per timing-loop round = round lanes of the demod kernel; streams whose tile holds more
+// (M10 at 24 kS/s / 2.5 samples per chip, anything at 48 or 6 kS/s with 5 samples per symbol) take two symbols per lane: rounds of <= 512
+#define SD_ROUND_SPL(decim, nt) (((SD_TILE / (decim)) / ((nt) == 8 ? 2 : 4)) > SD_ROUND_MAX ? 2 : 1)
 #define SD_HIST       64          // discriminator samples carried between submits
 #define SD_MARGIN     4           // look-ahead slack (samples) behind the newest sample, SPEC 3.2
 #define SD_WG         256
@@ -25,9 +27,9 @@ struct SdModem {            // per sonde type, built on the host
 	float   ki;             // integral gain
 	int32_t pmin, pmax;     // period clamp
 	int32_t rounds;         // timing-loop rounds per tile: 1; 2 for the SRS-C50 6 kS/s stream (822 symbols per tile, rounds of <= 512)
-	int32_t decim;          // IQ boxcar-decimated decim:1 before the discriminator: 4 RS41 (12 kS/s), 2 DFM / iMS-100, 1 M10 (SPEC 3.0)
+	int32_t decim;          // IQ boxcar-decimated decim:1 before the discriminator: 4 RS41 / DFM / iMS-100 / MRZ-N1 (12 kS/s), 2 M10 (SPEC 3.0)
 	int32_t itile;          // internal samples per 2048-sample input tile = 2048 / decim
-	int32_t nt;             // taps in use per polyphase row: 3.2 symbols = 8 (2.5 samples per symbol) or 16 (5)
+	int32_t nt;             // taps in use per polyphase row: 3.2 symbols = 8 (2.5 samples per symbol) or 16 (5): SD_NT_OF
 };
 
 #define SD_AF_DEC 8        // AFSK tone demodulator (SPEC 3.6): 48 kS/s -> 6 kS/s

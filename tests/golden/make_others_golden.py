@@ -16,7 +16,7 @@ from sdrpp_radiosonde_amd import synth  # noqa: E402
 import oracle_lib  # noqa: E402
 
 TILES = {1: 24, 2: 24, 3: 16, 4: 48, 5: 24, 6: 40}          # iMet / C50: multiples of 8 tiles (16384 samples)
-SNR = {1: 13.0, 2: 11.5, 3: 15.0, 4: 7.0, 5: 7.0, 6: 15.0}  # low enough that corrections / rejects occur
+SNR = {1: 10.5, 2: 10.0, 3: 12.5, 4: 7.0, 5: 7.0, 6: 12.5}  # low enough that corrections / rejects occur
 out = {}
 for t, tiles in TILES.items():
     n = 2048 * tiles

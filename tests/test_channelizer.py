@@ -51,7 +51,7 @@ def test_channelizer_isolates_a_tone(oracle):
     far = np.abs(bins[300, 200:, 0] + 1j * bins[300, 200:, 1])
     assert far.max() < 1e-3
     # discriminator gain 2/pi at 40 kS/s: d = 2*pi*df/40000 * 2/pi
-    assert np.allclose(out48[k, 500:], 4 * df / 40000, atol=2e-4)
+    assert np.allclose(out48[k, 500:], 4 * df / 40000, atol=2e-3)      # atan2q: |error| <= 2.5e-3 rad = 1.6e-3 quadrant (SPEC 3.1)
 
 
 def _oracle_decode_wideband(oracle, iq_np, bins_active):

@@ -15,7 +15,7 @@ NAMES = {0: "RS41", 1: "DFM09", 2: "iMS100", 3: "M10", 6: "MRZ-N1"}
 @pytest.mark.parametrize("stype", [1, 3, 2, 6])
 @pytest.mark.parametrize("noisy", [False, True])
 def test_single_type_bit_exact(oracle, stype, noisy):
-    ebn0 = {1: 12.0, 2: 12.5, 3: 15.0, 6: 12.0}[stype] if noisy else 30.0
+    ebn0 = {1: 10.0, 2: 10.5, 3: 12.5, 6: 11.0}[stype] if noisy else 30.0
     C, n = 12, TILE * (72 if stype == 6 else 40)          # MRZ-N1 sends one frame per second
     sb = synth.make_batch(stype, C, n, seed=40 + stype, ebn0_db=ebn0, invert=(stype == 1 and ebn0 < 20))
     b = SondeBatch(C, n, types=np.full(C, stype, dtype=np.uint8))

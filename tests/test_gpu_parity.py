@@ -236,9 +236,9 @@ def test_random_finite_garbage_matches_oracle(oracle):
 
 
 def test_rs41_wide_mode(oracle):
-    """SONDE_FLAG_RS41_WIDE: RS41 at 2:1 instead of 4:1 (24 kS/s internally) -- bit-exact against the oracle set the same
+    """SONDE_FLAG_WIDE: RS41 at 2:1 instead of 4:1 (24 kS/s internally) -- bit-exact against the oracle set the same
     way, and it decodes a carrier 4 kHz off centre, which the default (12 kS/s, like the reference's 10 kHz VFO) cannot."""
-    from sdrpp_radiosonde_amd._lib import FLAG_RS41_WIDE
+    from sdrpp_radiosonde_amd._lib import FLAG_WIDE as FLAG_RS41_WIDE
     C_, n = 6, TILE * 60
     nbits = int(n * 4800 / 48000) + 16
     bits, frames = synth.rs41_bitstreams(61, np.arange(C_), nbits)
@@ -264,6 +264,35 @@ def test_rs41_wide_mode(oracle):
     assert len(good) >= sent - 2 * C_
     for f in good:
         assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in frames[f["channel"]])
+
+
+@pytest.mark.parametrize("stype,wide_decim,cfo", [(1, 2, 4500.0), (3, 1, 8000.0)])
+def test_wide_mode_other_types(oracle, stype, wide_decim, cfo):
+    """SONDE_FLAG_WIDE for DFM (2:1 instead of 4:1) and M10 (48 kS/s instead of 2:1): the kernel classes (2, 16) and
+    (1, 16) -- bit-exact against the oracle set the same way; they decode a carrier offset the default classes cannot."""
+    from sdrpp_radiosonde_amd._lib import FLAG_WIDE
+    C_, n = 6, TILE * 40
+    sb = synth.make_batch(stype, C_, n, seed=63 + stype, ebn0_db=22.0, cfo_max_hz=0.0)
+    t = np.arange(n) / 48000.0
+    z = (sb.iq.numpy()[..., 0] + 1j * sb.iq.numpy()[..., 1]) * np.exp(2j * np.pi * cfo * t)[None, :]
+    x = np.ascontiguousarray(np.stack([z.real, z.imag], axis=-1).astype(np.float32))
+    types = np.full(C_, stype, dtype=np.uint8)
+    ok = lambda fr: int(((fr["nerr"][:, 1] == 0) if stype == 1 else (fr["nerr"][:, 0] == 0)).sum())
+    narrow = SondeBatch(C_, n, types=types)
+    narrow.submit(_dev(torch.from_numpy(x)))
+    assert ok(narrow.frames()) == 0
+    wide = SondeBatch(C_, n, types=types, flags=FLAG_WIDE)
+    wide.submit(_dev(torch.from_numpy(x)))
+    got = wide.frames()
+    L = oracle.lib()
+    L.or_modem_set_decim(stype, wide_decim)
+    try:
+        ref = oracle.batch_run(stype, x, nthreads=4)
+    finally:
+        L.or_modem_set_decim(stype, 2 * wide_decim)
+    assert got.tobytes() == ref.tobytes()
+    sent = sum(len(f) for f in sb.frames)
+    assert ok(got) >= sent - 2 * C_
 
 
 def test_split_fec_kernel_equals_fused_epilogue(oracle):

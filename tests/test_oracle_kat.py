@@ -15,13 +15,16 @@ def test_atan2_polynomial_accuracy_and_quadrants(oracle):
     # or_atan2 returns quadrants (atan2 * 2/pi, the discriminator gain folded in)
     got = np.array([L.or_atan2(float(y), float(x)) for x, y in xy], dtype=np.float64) * (np.pi / 2)
     ref = np.arctan2(xy[:, 1].astype(np.float64), xy[:, 0].astype(np.float64))
-    assert np.max(np.abs(got - ref)) < 2e-5          # Abramowitz-Stegun 4.4.47: 1e-5 + float rounding
-    assert L.or_atan2(0.0, 0.0) == 0.0
-    assert L.or_atan2(0.0, 1.0) == 0.0
-    assert abs(L.or_atan2(1.0, 0.0) - 1.0) < 1e-6
-    assert abs(L.or_atan2(0.0, -1.0) - 2.0) < 1e-6
-    assert abs(L.or_atan2(-1.0, 0.0) + 1.0) < 1e-6
-    assert abs(L.or_atan2(-1e-30, -1.0) + 2.0) < 1e-6
+    # SPEC 3.1 (round 3): three-term polynomial (7e-4 rad) + ONE Newton step on the reciprocal (0.26 %): <= 2.5e-3 rad
+    # the consumer is a low-pass FIR and a hard slicer; sensitivity unchanged (profiles/r3_sensitivity.md)
+    assert np.max(np.abs(got - ref)) < 2.5e-3
+    assert abs(L.or_atan2(0.0, 0.0)) == 0.5            # the divisor is floored, r = 0: the diagonal
+    assert abs(L.or_atan2(0.0, 1.0)) < 1.6e-3
+    assert abs(L.or_atan2(1.0, 0.0) - 1.0) < 1.6e-3
+    assert abs(L.or_atan2(0.0, -1.0) - 2.0) < 1.6e-3
+    assert abs(L.or_atan2(-1.0, 0.0) + 1.0) < 1.6e-3
+    assert abs(L.or_atan2(-1e-30, -1.0) + 2.0) < 1.6e-3
+    assert L.or_atan2(1.0, 1.0) == 0.5 and L.or_atan2(-1.0, -1.0) == -1.5 and L.or_atan2(1.0, -1.0) == 1.5
     # the Newton-Raphson reciprocal behind it
     xs = np.float32(10.0) ** rng.uniform(-6, 6, 4000).astype(np.float32)
     rr = np.array([L.or_recip(float(v)) for v in xs], dtype=np.float64)
@@ -37,7 +40,7 @@ def test_discriminator_tone_and_gain(oracle):
     d = np.zeros(n, dtype=np.float32)
     last = np.zeros(2, dtype=np.float32)
     L.or_discriminate(oracle.fptr(iq), n, oracle.fptr(d), oracle.fptr(last))
-    assert np.allclose(d[1:], 0.5, atol=3e-5)
+    assert np.allclose(d[1:], 0.5, atol=1.6e-3)
     # negative frequency near -fs/2 exercises the wrap
     ph = -2 * np.pi * 0.45 * np.arange(n)
     iq = np.stack([np.cos(ph), np.sin(ph)], axis=1).astype(np.float32).reshape(-1)
