@@ -88,11 +88,19 @@ def parse_args():
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
                     "4 for runs of fewer than 64 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
                     "(profiles/r2_notes.md), inside the timed region: every 8th costs 0.6 %% of the step")
-    ap.add_argument("--flags", type=int, default=0, help="SondeBatchConfig.flags (1: RS41 wide, 2: FEC as its own kernel)")
+    ap.add_argument("--flags", type=int, default=None, help="SondeBatchConfig.flags (1: wide, 2: FEC as its own kernel, 4: pipelined class streams; "
+                    "default 0, with --mix 4)")
+    ap.add_argument("--no-others", action="store_true", help="headline only: skip the other BASELINE configurations (other_configs), the low-SNR "
+                    "line and the rocprofv3 traffic passes that the default run appends")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # the sub-run rocprofv3 --pmc wraps (roofline.traffic)
     ap.add_argument("--stride-pad", type=int, default=0, help="experiment: extra samples between channels in HBM")
-    ap.add_argument("--scatter", action="store_true", help="ingest on rank 0 and scatter IQ shards over RCCL before timing")
-    ap.add_argument("--scatter-torch", action="store_true", help="--scatter through torch.distributed instead of libsonde_rccl.so")
-    return ap.parse_args()
+    ap.add_argument("--scatter", action="store_true", help="(the default with --gpus > 1) ingest on rank 0 and scatter IQ shards over RCCL before timing")
+    ap.add_argument("--scatter-torch", action="store_true", help="scatter through torch.distributed instead of libsonde_rccl.so")
+    ap.add_argument("--rank-local", action="store_true", help="--gpus > 1: every rank generates its own shard (no scatter): kernel scaling without xGMI time")
+    args = ap.parse_args()
+    if args.pmc_child:        # a short headline-shaped run for the counter passes: one block re-submitted, nothing printed
+        args.steps, args.warmup, args.ramp_ms, args.blocks, args.no_cpu, args.no_others, args.time_every = 10, 2, 60.0, 1, True, True, 0
+    return args
 
 
 def cpu_baseline(iq, C, n, args):
@@ -181,6 +189,8 @@ def main():
         objs = [None] * world
         dist.all_gather_object(objs, ident)
         nccl_ranks = {"backend": "rccl" if backend == "nccl" else backend, "world": world, "distinct_devices": len(set(objs))}
+        if backend == "nccl" and nccl_ranks["distinct_devices"] != world:
+            sys.exit(f"bench.py: {world} ranks sit on {nccl_ranks['distinct_devices']} distinct devices: one process per GPU is the contract")
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     def barrier():
@@ -202,6 +212,8 @@ def main():
         out = run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum)
     else:
         out = run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_sum)
+    if out is None:                                  # --pmc-child: the run rocprofv3 wraps; nothing to print
+        return
     if nccl_ranks is not None:
         out["nccl_ranks"] = nccl_ranks
     if rank == 0:
@@ -234,119 +246,189 @@ def ramp_and_time(submit, sync, args, barrier, reset=None):
     return dt
 
 
-def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_sum):
-    from sdrpp_radiosonde_amd import synth, _lib
+FLAG_PIPELINE = 4
+CLASS_NAMES = ("dec1_nt16", "dec2_nt16", "dec4_nt8 (RS41/DFM/iMS-100/MRZ-N1)", "dec2_nt8 (M10)")
+
+
+def cyclic_ok(n, NB):
+    """NB blocks of n samples hold a whole number of RS41 frame periods (320 + 64 bytes at 4800 Bd)?"""
+    nb = NB * n * 4800.0 / 48000.0
+    return abs(nb - round(nb)) < 1e-9 and int(round(nb)) % (8 * 384) == 0
+
+
+def make_blocks(kind, C, tiles, NB, ebn0, dev, seed, first_channel=0):
+    """NB consecutive blocks [C, n, 2] of ONE continuous signal per channel, each its own allocation in HBM, plus the
+    per-channel sonde types (None = all RS41).  RS41 channels: the bit stream repeats seamlessly after NB blocks when NB
+    blocks hold a whole number of frame periods (5 x 96 or 5 x 24 tiles do); the other sondes are continuous over the NB
+    blocks with one discontinuity at the wrap.
+    (One allocation per block: a [C, NB * n] view would put the channels 15 x 512 KiB apart, which costs 8 %: HBM channel
+    aliasing, profiles/r2_notes.md.)"""
+    from sdrpp_radiosonde_amd import synth
+    n = tiles * 2048
+    types = None
+
+    def rs41(c, fc, sd, eb):
+        if NB > 1 and cyclic_ok(n, NB):
+            return synth.make_rs41_cyclic(c, n, NB, seed=sd, ebn0_db=eb, device=dev, first_channel=fc, chunk=128).iq
+        return synth.make_rs41_batch(c, NB * n, seed=sd, ebn0_db=eb, device=dev, first_channel=fc).iq
+
+    if kind == "rs41":
+        full = rs41(C, first_channel, seed, ebn0)
+    elif kind == "mix":
+        order = (0, 3, 1)
+        types = np.array([order[c % 3] for c in range(C)], dtype=np.uint8)
+        full = torch.empty((C, NB * n, 2), dtype=torch.float32, device=dev)
+        for t in order:
+            idx = np.nonzero(types == t)[0]
+            part = rs41(len(idx), 0, seed, ebn0 + 2.0) if t == 0 else \
+                synth.make_batch(int(t), len(idx), NB * n, seed=seed + 10 * t, ebn0_db=ebn0 + 2.0, device=dev).iq
+            full[torch.from_numpy(idx).to(dev)] = part
+            del part
+    else:
+        types = np.full(C, int(kind), dtype=np.uint8)
+        full = synth.make_batch(int(kind), C, NB * n, seed=seed, ebn0_db=ebn0 + 2.0, device=dev).iq
+    blocks = [full[:, k * n: (k + 1) * n].contiguous() for k in range(NB)] if NB > 1 else [full]
+    del full
+    torch.cuda.synchronize()
+    return blocks, types
+
+
+def measure(blocks, types, flags, args, local_rank, barrier, stream):
+    """Time args.steps submits cycling through `blocks` (W warmup, clock ramp first); returns the raw figures of this rank."""
     from sdrpp_radiosonde_amd.batch import SondeBatch
-    from sdrpp_radiosonde_amd.shard import scatter_iq
+    C, n = blocks[0].shape[0], blocks[0].shape[1]
+    # frames of a FIRST submit from a fresh decoder: the quantity the CPU baseline's `frames_per_pass` counts
+    fresh = SondeBatch(C, n, device=local_rank, types=types, flags=flags)
+    fresh.submit(blocks[0], stream)
+    nfr_first = int(fresh.sync())
+    fresh.close()
+    batch = SondeBatch(C, n, device=local_rank, types=types, flags=flags)
+    turn = [0]
+
+    def submit():
+        batch.submit(blocks[turn[0] % len(blocks)], stream)
+        turn[0] += 1
+    # kernel times: HIP events recorded by the library around the launches of every --time-every-th timed step
+    # (an event record is a few microseconds of bubble in the command stream)
+    dt = ramp_and_time(submit, batch.sync, args, barrier, reset=lambda: batch.set_timing(args.time_every))
+    demod_ms, framer_ms, class_ms = 0.0, 0.0, {}
+    if args.time_every:
+        demod_ms, framer_ms = batch.kernel_ms()
+        class_ms = batch.class_ms()
+    nfr_step = 0                                   # frames of one more pass over the cycle, per step
+    for _ in range(len(blocks)):
+        submit()
+        nfr_step += batch.sync()
+    nfr_step /= len(blocks)
+    batch.close()
+    return {"dt": dt, "demod_ms": demod_ms, "framer_ms": framer_ms, "class_ms": class_ms, "nfr_first": nfr_first, "nfr_step": nfr_step}
+
+
+def alg_bytes_of(C, n):
+    """algorithmic bytes of one step: 8 B per complex64 sample read once + bits written"""
+    return C * n * 8 + C * (n * 4800 // 48000) // 8
+
+
+def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream, ebn0=None, steps=None, warmup=None):
+    """One of the non-headline configurations, measured in this process: a compact record for other_configs / low_snr."""
+    import copy
+    a = copy.copy(args)
+    a.steps = steps or max(20, min(args.steps, 100))
+    a.warmup = warmup or max(5, min(args.warmup, 20))
+    a.ramp_ms = min(args.ramp_ms, 100.0)
+    blocks, types = make_blocks(kind, C, tiles, NB, args.ebn0 if ebn0 is None else ebn0, dev, seed=1000)
+    m = measure(blocks, types, flags, a, local_rank, barrier, stream)
+    del blocks
+    torch.cuda.empty_cache()
+    n = tiles * 2048
+    ms = m["dt"] / a.steps * 1e3
+    rec = {"channels": C, "samples_per_channel": n, "blocks_cycled": NB, "flags": flags, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(ms, 4), "value": round(C * n / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s",
+           "step_frac": round(alg_bytes_of(C, n) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "frames_per_step_steady": round(m["nfr_step"], 2)}
+    if m["class_ms"]:
+        rec["kernel_ms"] = {CLASS_NAMES[k]: round(v, 4) for k, v in m["class_ms"].items()}
+    else:
+        rec["kernel_ms"] = {"demod": round(m["demod_ms"], 4), "framer_fec": round(m["framer_ms"], 4)}
+    return rec
+
+
+def measured_traffic(args):
+    """HBM bytes per launch of the demod kernel from rocprofv3 PMC counters, measured NOW: two separate --pmc passes
+    (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md) over a 10-step sub-run of this script with the
+    headline shape; FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B, same guide).
+    Returns (bytes, source text) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    C = args.channels or 1024
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sonde_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+               "--channels", str(C), "--tiles", str(args.tiles), "--ebn0", str(args.ebn0)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            db = sqlite3.connect(dbs[0])
+            # the counter is reported per dispatch (summed over its instances): average over the sub-run's launches
+            rows = db.execute("select dispatch_id, sum(value) from counters_collection where kernel_name like '%sd_demod_kernel%' "
+                              "and counter_name = ? group by dispatch_id", (ctr,)).fetchall()
+            if not rows:
+                return None, f"no {ctr} samples for sd_demod_kernel in the rocprofv3 output"
+            vals[ctr] = sum(v for _, v in rows) / len(rows)
+        except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as e:
+            return None, f"rocprofv3 --pmc {ctr}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch = vals["FETCH_SIZE"] * 1024 * 2          # KiB; x2: gfx950 correction for wide coalesced reads
+    write = vals["WRITE_SIZE"] * 1024
+    return int(fetch + write), ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over a 10-step "
+                                f"sub-run of this command's shape ({C} channels x {args.tiles} tiles); FETCH_SIZE x2 (gfx950 correction) = "
+                                f"{int(fetch)} B + WRITE_SIZE {int(write)} B per launch")
+
+
+def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_sum):
+    from sdrpp_radiosonde_amd import _lib
     import ctypes
 
     if args.channels is None:
         args.channels = 4096 if args.mix else 1024
     if args.time_every is None:
         args.time_every = 8 if args.steps >= 64 else 4
+    if args.flags is None:
+        args.flags = FLAG_PIPELINE if args.mix else 0
     C, n = args.channels, args.tiles * 2048
-    scatter_ms = None
-    types = None
-    blocks = None
-    if args.scatter and world > 1:
-        # rank 0 ingests the IQ of ALL channels (the same seamless NB-block signal the rank-local mode generates) and scatters
-        # it block by block: the native scatter (csrc/shard_rccl.cpp: grouped ncclSend / ncclRecv), or
-        # --scatter-torch: dist.scatter.  scatter_ms = the time of all NB scatters, outside the timed region.
-        NB = args.blocks
-        shards = None
-        if rank == 0:
-            shards = []
-            for r in range(world):
-                if NB > 1:
-                    f = synth.make_rs41_cyclic(C, n, NB, seed=1000 + r, ebn0_db=args.ebn0, device=dev, first_channel=r * C, chunk=128).iq
-                    shards.append([f[:, k * n: (k + 1) * n].contiguous() for k in range(NB)])
-                    del f
-                else:
-                    shards.append([synth.make_rs41_batch(C, n, seed=1000 + r, ebn0_db=args.ebn0, device=dev, first_channel=r * C).iq])
-        ns = None
-        if not args.scatter_torch:
-            from sdrpp_radiosonde_amd.shard import NativeShard
-            ns = NativeShard(local_rank)
-        blocks, scatter_ms = [], 0.0
-        for k in range(NB):
-            full = torch.cat([shards[r][k] for r in range(world)]) if rank == 0 else None
-            torch.cuda.synchronize()
-            barrier()
-            t0 = time.perf_counter()
-            blk = ns.scatter_iq(full, (C, n, 2), root=0) if ns is not None else scatter_iq(full, C, n, dev, src=0)
-            torch.cuda.synchronize()
-            scatter_ms += (time.perf_counter() - t0) * 1e3
-            blocks.append(blk)
-            del full
-        del shards
-        iq = blocks[0]
-        if NB == 1:
-            blocks = None
-    elif args.mix:
-        order = (0, 3, 1)
-        types = np.array([order[c % 3] for c in range(C)], dtype=np.uint8)
-        iq = torch.empty((C, n, 2), dtype=torch.float32, device=dev)
-        for t in order:
-            idx = np.nonzero(types == t)[0]
-            iq[torch.from_numpy(idx).to(dev)] = synth.make_batch(int(t), len(idx), n, seed=1000 + rank + 10 * t, ebn0_db=args.ebn0 + 2.0, device=dev).iq
-    elif args.sonde_type:
-        types = np.full(C, args.sonde_type, dtype=np.uint8)
-        iq = synth.make_batch(args.sonde_type, C, n, seed=1000 + rank, ebn0_db=args.ebn0 + 2.0, device=dev).iq
-    else:
-        # headline workload: NB consecutive blocks of one continuous signal per channel, cycled, so that every step decodes
-        # NEW samples of a seamless stream (re-submitting one block makes a junk frame per channel and step at the seam, which
-        # costs the RS corrector's full 24 iterations: an artefact of the bench, not of the signal)
-        NB = args.blocks
-        if NB > 1:
-            full = synth.make_rs41_cyclic(C, n, NB, seed=1000 + rank, ebn0_db=args.ebn0, device=dev, first_channel=rank * C, chunk=128).iq
-            # one allocation per block: a [C, NB * n] view would put the channels 15 x 512 KiB apart, which costs 8 % (HBM channel
-            # aliasing; 3 x 512 KiB, the contiguous block, does not)
-            blocks = [full[:, k * n: (k + 1) * n].contiguous() for k in range(NB)]
-            del full
-            iq = blocks[0]
-        else:
-            iq = synth.make_rs41_batch(C, n, seed=1000 + rank, ebn0_db=args.ebn0, device=dev, first_channel=rank * C).iq
-    if args.stride_pad:
-        padded = torch.empty((C, n + args.stride_pad, 2), dtype=torch.float32, device=dev)
-        padded[:, :n] = iq
-        iq = padded[:, :n]
-    torch.cuda.synchronize()
-
     stream = torch.cuda.current_stream().cuda_stream
-    # frames of a FIRST submit from a fresh decoder: the quantity the CPU baseline's `frames_per_pass` counts
-    fresh = SondeBatch(C, n, device=local_rank, types=types, flags=args.flags)
-    fresh.submit(iq, stream)
-    nfr_first = int(fresh.sync())
-    fresh.close()
-
-    batch = SondeBatch(C, n, device=local_rank, types=types, flags=args.flags)
-
-    # kernel times: HIP events recorded by the library on the submit stream around the launches of every
-    # --time-every-th timed step (an event record is a few microseconds of bubble in the command stream)
-    def reset():
-        if hasattr(batch.L, "sonde_batch_set_timing"):
-            batch.set_timing(args.time_every)
-        else:
-            batch.kernel_ms()
-    if blocks is None:
-        blocks = [iq]
-    turn = [0]
-
-    def submit():
-        batch.submit(blocks[turn[0] % len(blocks)], stream)
-        turn[0] += 1
-    dt = ramp_and_time(submit, batch.sync, args, barrier, reset=reset)
-    demod_ms, framer_ms = batch.kernel_ms()
-    nfr_step = 0                                   # frames of one more pass over the cycle, per step
-    for _ in range(len(blocks)):
-        submit()
-        nfr_step += batch.sync()
-    nfr_step /= len(blocks)
-    dt, nfr_total = reduce_max_sum(dt, nfr_step)
+    kind = "mix" if args.mix else (args.sonde_type if args.sonde_type else "rs41")
+    default_run = kind == "rs41" and world == 1 and not args.no_others and not args.pmc_child
+    scatter = None
+    if os.environ.get("SONDE_BENCH_BACKEND", "nccl") == "gloo":
+        args.scatter_torch = True                  # test hook (ranks share devices): RCCL needs one device per rank
+    if world > 1 and kind == "rs41" and not args.rank_local:
+        blocks, types, scatter = scattered_blocks(args, rank, local_rank, world, dev, dist, barrier)
+    else:
+        blocks, types = make_blocks(kind, C, args.tiles, args.blocks, args.ebn0, dev, seed=1000 + rank, first_channel=rank * C)
+    if args.stride_pad:
+        padded = [torch.empty((C, n + args.stride_pad, 2), dtype=torch.float32, device=dev) for _ in blocks]
+        for pb, bk in zip(padded, blocks):
+            pb[:, :n] = bk
+        blocks = [pb[:, :n] for pb in padded]
+    m = measure(blocks, types, args.flags, args, local_rank, barrier, stream)
+    if args.pmc_child:
+        return None
+    demod_ms, framer_ms = m["demod_ms"], m["framer_ms"]
+    dt, nfr_total = reduce_max_sum(m["dt"], m["nfr_step"])
 
     # read-only streaming kernel over the same IQ buffer: what this GPU's HBM delivers to a pure read
     gbs = ctypes.c_float(0.0)
-    if _lib.load().sonde_hbm_read_probe(ctypes.c_void_p(iq.data_ptr()), C * n * 8, 10, ctypes.byref(gbs)) != 0:
+    if _lib.load().sonde_hbm_read_probe(ctypes.c_void_p(blocks[0].data_ptr()), C * n * 8, 10, ctypes.byref(gbs)) != 0:
         raise RuntimeError(_lib.last_error())
     achievable = float(gbs.value)
 
@@ -355,22 +437,37 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
     ms_per_step = dt / args.steps * 1e3
     # roofline of the dominant kernel (the demodulator): algorithmic bytes = 8 B per complex64 sample read once
     # + bits written (n/sps/8 bytes per channel) -- DESIGN.md section 6
-    alg_bytes = C * n * 8 + C * (n * 4800 // 48000) // 8
+    alg_bytes = alg_bytes_of(C, n)
+    pipelined = bool(args.flags & FLAG_PIPELINE) and kind == "mix"
+    if pipelined:
+        demod_ms = ms_per_step        # the classes of consecutive submits overlap: there is no per-step kernel interval; see kernel_ms
     achieved = alg_bytes / (demod_ms * 1e-3) / 1e9
     step_achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is REPLAYED from the
-    # committed rocprofv3 --pmc passes of this same command (profiles/*_traffic.json) when the workload matches
+    # HBM traffic per launch: measured now by two rocprofv3 --pmc passes over a sub-run (default run); otherwise, and as the
+    # labelled fallback, REPLAYED from the committed passes of the same command (profiles/*_traffic.json)
     traffic, traffic_source = None, None
-    for name in ("r2_traffic.json", "r1_traffic.json"):
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if tj["channels_per_gpu"] == C and tj["samples_per_channel"] == n and not args.mix:
-                traffic = tj["fetch_bytes"] + tj["write_bytes"]
-                traffic_source = f"replayed from profiles/{name} (separate rocprofv3 --pmc passes of this command on the builder's box, FETCH_SIZE x2 gfx950 correction); not measured in this run"
-                break
-        except (OSError, KeyError, ValueError):
-            continue
+    if default_run and rank == 0:
+        traffic, traffic_source = measured_traffic(args)
+    if traffic is None:
+        why = traffic_source
+        for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if tj["channels_per_gpu"] == C and tj["samples_per_channel"] == n and kind == "rs41":
+                    traffic = tj["fetch_bytes"] + tj["write_bytes"]
+                    traffic_source = (f"replayed from profiles/{name} (separate rocprofv3 --pmc passes of this command on the builder's box, "
+                                      "FETCH_SIZE x2 gfx950 correction); not measured in this run" + (f" ({why})" if why else ""))
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
 
+    kernel_ms = {"demod": round(m["demod_ms"], 4), "framer_fec": round(framer_ms, 4),
+                 "note": f"HIP events on every {args.time_every}th timed step; for RS41 the demod kernel includes sync search and FEC"}
+    if m["class_ms"]:
+        kernel_ms["per_class"] = {CLASS_NAMES[k]: round(v, 4) for k, v in m["class_ms"].items()}
+        if pipelined:
+            kernel_ms["note"] += ("; pipelined class streams: `demod` spans a submit's fork to its completion and overlaps the neighbouring "
+                                  "submits, per_class = each class's demod kernel alone")
     out = {
         "metric": "IQ Msamples/s through demod+FEC @ 48 kS/s/ch",
         "value": round(msps, 3),
@@ -385,19 +482,17 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": (f"RS41/M10/DFM09 by channel % 3 x {C} channels/GPU x {n} samples (48 kS/s)" if args.mix else
+        "config": {"workload": (f"RS41/M10/DFM09 by channel % 3 x {C} channels/GPU x {n} samples (48 kS/s)" if kind == "mix" else
                                 f"SONDE type {args.sonde_type} x {C} channels/GPU x {n} samples (48 kS/s)" if args.sonde_type else
-                                f"RS41-SG x {C} channels/GPU x {n} samples per step (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)"
-                                + (f"; {len(blocks)} consecutive blocks of a continuous signal resident in HBM, cycled" if len(blocks) > 1 else "")),
-                   "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{world}",
-                   "ingest": ("rank-local" if scatter_ms is None else
-                              "scatter from rank 0: torch.distributed" if args.scatter_torch else "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)")},
+                                f"RS41-SG x {C} channels/GPU x {n} samples per step (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)")
+                               + (f"; {len(blocks)} consecutive blocks of a continuous signal resident in HBM, cycled" if len(blocks) > 1 else ""),
+                   "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{world}", "flags": args.flags,
+                   "ingest": "rank-local" if scatter is None else scatter["ingest"]},
         "frames_per_s": round(nfr_total * args.steps / dt, 1),
         "frames_per_step_steady": round(nfr_total, 2),
-        "frames_first_submit": nfr_first,
+        "frames_first_submit": m["nfr_first"],
         "realtime_channels": round(msps * 1e6 / 48000.0, 1),
-        "kernel_ms": {"demod": round(demod_ms, 4), "framer_fec": round(framer_ms, 4),
-                      "note": f"HIP events on every {args.time_every}th timed step; for RS41 the demod kernel includes sync search and FEC"},
+        "kernel_ms": kernel_ms,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "step_achieved": round(step_achieved, 2), "step_frac": round(step_achieved / HBM_PEAK_GBS, 4),
@@ -405,13 +500,78 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                      "achievable_read": round(achievable, 1), "frac_of_achievable": round(achieved / achievable, 4),
                      "algorithmic_bytes": alg_bytes, "kernel": "sd_demod_kernel (dominant kernel of the step; frac = its HIP-event time, step_frac = whole step by the wall clock)"},
     }
-    if scatter_ms is not None:
-        out["scatter_ms"] = round(scatter_ms, 3)
-    if rank == 0 and world == 1 and not args.no_cpu and not args.mix and not args.sonde_type:
-        out["cpu_baseline"] = cpu_baseline(iq, C, n, args)
-        out["cpu_baseline"]["frames_match_gpu_first_submit"] = bool(out["cpu_baseline"]["frames_per_pass"] == nfr_first) \
+    if scatter is not None:
+        out["scatter"] = scatter
+        out["scatter_ms"] = scatter["ms"]
+    if rank == 0 and world == 1 and not args.no_cpu and kind == "rs41":
+        out["cpu_baseline"] = cpu_baseline(blocks[0], C, n, args)
+        out["cpu_baseline"]["frames_match_gpu_first_submit"] = bool(out["cpu_baseline"]["frames_per_pass"] == m["nfr_first"]) \
             if (args.cpu_channels or C) == C else None
+    if default_run:
+        # ---- the other BASELINE configurations and the low-SNR point, measured in this same process
+        del blocks
+        torch.cuda.empty_cache()
+        others = {}
+        others["mix4096"] = small_run("mix", 4096, 24, 5, FLAG_PIPELINE, args, local_rank, dev, barrier, stream)
+        others["mix4096"]["workload"] = "BASELINE configs[2]: RS41 / M10 / DFM09 by channel % 3, 4096 channels x 49152 samples per step, pipelined class streams"
+        others["mix4096_joined"] = small_run("mix", 4096, 24, 5, 0, args, local_rank, dev, barrier, stream)
+        others["mix4096_joined"]["workload"] = "the same, every submit joined into the caller's stream (flags 0)"
+        others["shard8192"] = small_run("rs41", 8192, 24, 5, 0, args, local_rank, dev, barrier, stream)
+        others["shard8192"]["workload"] = "BASELINE configs[4], one GPU's shard: 8192 RS41 channels x 49152 samples (T = 1 s) per step"
+        for S in (1, 8):
+            import copy
+            a = copy.copy(args)
+            a.wb_streams, a.steps, a.warmup, a.ramp_ms = S, max(20, min(args.steps, 50)), max(5, min(args.warmup, 10)), min(args.ramp_ms, 100.0)
+            w = run_wideband(a, rank, local_rank, world, dev, barrier, reduce_max_sum)
+            others["wideband" if S == 1 else "wideband8"] = {
+                "workload": "BASELINE configs[3]: " + w["config"]["workload"], "ms_per_step": w["ms_per_step"], "value": w["value"],
+                "unit": w["unit"], "realtime_streams": w["realtime_streams"], "kernel_ms": w["kernel_ms"], "steps": a.steps, "warmup": a.warmup}
+        out["other_configs"] = others
+        ls = small_run("rs41", C, args.tiles, args.blocks, args.flags, args, local_rank, dev, barrier, stream, ebn0=9.0)
+        out["low_snr"] = {"ebn0": 9.0, "ms_per_step": ls["ms_per_step"], "step_frac": ls["step_frac"], "kernel_ms": ls["kernel_ms"],
+                          "frames_per_step_steady": ls["frames_per_step_steady"],
+                          "note": "the headline workload at Eb/N0 9 dB: most frames need the Reed-Solomon corrector's general path"}
     return out
+
+
+def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
+    """Multi-GPU ingest as north_star names it: rank 0 holds the IQ of ALL channels of one block at a time (generated block by
+    block: synth.make_rs41_cyclic_block), scatters it with the native grouped ncclSend / ncclRecv (csrc/shard_rccl.cpp,
+    SURVEY 8e) -- or --scatter-torch: dist.scatter -- and frees it.  The scatters are outside the timed region (inputs are
+    resident when timing starts); their time and rate are reported beside the 7-link xGMI egress bound."""
+    from sdrpp_radiosonde_amd import synth
+    from sdrpp_radiosonde_amd.shard import scatter_iq
+    C, n, NB = args.channels, args.tiles * 2048, args.blocks
+    cyc = NB > 1 and cyclic_ok(n, NB)
+    if not cyc:
+        NB = 1                                   # no seamless cycle of this shape: one block, re-submitted
+    ns = None
+    if not args.scatter_torch:
+        from sdrpp_radiosonde_amd.shard import NativeShard
+        ns = NativeShard(local_rank)
+    blocks, ms = [], 0.0
+    for k in range(NB):
+        full = None
+        if rank == 0:
+            full = synth.make_rs41_cyclic_block(world * C, n, NB, k, seed=1000, ebn0_db=args.ebn0, device=dev, chunk=128) if cyc else \
+                synth.make_rs41_batch(world * C, n, seed=1000, ebn0_db=args.ebn0, device=dev).iq
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        blk = ns.scatter_iq(full, (C, n, 2), root=0) if ns is not None else scatter_iq(full, C, n, dev, src=0)
+        torch.cuda.synchronize()
+        ms += (time.perf_counter() - t0) * 1e3
+        blocks.append(blk)
+        del full
+    torch.cuda.empty_cache()
+    sent = (world - 1) * C * n * 8 * NB                      # bytes that left the root
+    gbs = sent / (ms * 1e-3) / 1e9
+    bound = 7 * 153.0                                        # GB/s: all seven xGMI links of the root at once (SURVEY 8e)
+    return blocks, None, {
+        "ingest": "scatter from rank 0: torch.distributed" if args.scatter_torch else "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)",
+        "ms": round(ms, 3), "blocks": NB, "bytes_from_root": sent, "gbs": round(gbs, 2),
+        "root_egress_bound_gbs": bound, "frac_of_bound": round(gbs / (bound * min(1.0, (world - 1) / 7.0)), 4),
+        "note": "root holds one block of all ranks at a time; outside the timed region"}
 
 
 def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):

@@ -121,6 +121,14 @@ typedef struct {
 /* RS41 channels: run the Reed-Solomon stage as a kernel of its own behind the demodulator instead of in the demodulator
  * kernel's epilogue (one launch more per submit; same frames).  Kept for A/B measurements. */
 #define SONDE_FLAG_SPLIT_FEC 2u
+/* Mixed batches (several demodulator classes = several kernels on the library's own streams): do not join those streams
+ * into the caller's stream at the end of each submit.  Every class then runs submit after submit on its own stream, behind
+ * its own predecessor only, so the tail of one class (last workgroups draining, frame decoder) overlaps the next submit of
+ * the others.  The caller's stream orders the INPUT only (the kernels start once work queued on it before the submit has
+ * finished); completion is observed through sonde_batch_sync / sonde_batch_frames_of, NOT through the caller's stream:
+ * the sample buffer of submit t must stay untouched until sonde_batch_sync / frames_of(t) has returned.  No effect on
+ * batches of one class (one kernel on the caller's stream). */
+#define SONDE_FLAG_PIPELINE  4u
 
 typedef struct SondeBatch SondeBatch;
 
@@ -142,7 +150,8 @@ long sonde_batch_sync(SondeBatch *b);
 long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap);
 /* Pipelined hosts: frame slots exist twice, so the frames of submit t stay readable while submit t + 1 is queued or running.
  * sonde_batch_ticket: the number of the last submit (1-based; 0 = none yet).  sonde_batch_frames_of waits for THAT submit only
- * (not for the stream) and copies its frames; valid for the last two tickets, a negative error for older ones.  Per-submit
+ * (not for the stream) and copies its frames (out == NULL or cap == 0: returns their number without copying, so that the
+ * caller can size its buffer); valid for the last two tickets, a negative error for older ones.  Per-submit
  * completion events (a few microseconds of command-stream bubble each) are recorded from the first sonde_batch_ticket call on;
  * a submit queued before that call is waited for through its stream. */
 uint64_t sonde_batch_ticket(SondeBatch *b);
@@ -162,6 +171,11 @@ long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t c
  * timed; sonde_batch_set_timing changes that (1 = every submit, 0 = none) and restarts the count, so the next submit is timed. */
 int  sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *framer_ms);
 int  sonde_batch_set_timing(SondeBatch *b, int every_n);
+/* Mixed batches (several demodulator classes, one kernel each on the library's own streams): the average device time (ms) of
+ * each class's demod kernel alone over the timed submits since the last call; index 0: no decimation / 16 taps (M10 wide,
+ * the AFSK 6 kS/s streams), 1: 2:1 / 16 (RS41, DFM, iMS-100, MRZ-N1 wide), 2: 4:1 / 8 (the same four, default), 3: 2:1 / 8
+ * (M10); -1 = class not in the batch.  Returns the number of submits averaged (0 for a one-class batch). */
+int  sonde_batch_class_ms(SondeBatch *b, float out[4]);
 
 /* introspection for staged parity tests */
 int      sonde_batch_read_bits(SondeBatch *b, uint32_t channel, uint64_t from, size_t count, uint8_t *out /* one bit per byte */);

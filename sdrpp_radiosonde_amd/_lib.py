@@ -47,12 +47,13 @@ class SondeBatchConfig(C.Structure):
 FLAG_WIDE = 1            # one decimation step less for every GFSK sonde (SONDE_FLAG_WIDE)
 FLAG_RS41_WIDE = FLAG_WIDE
 FLAG_SPLIT_FEC = 2
+FLAG_PIPELINE = 4        # mixed batches: class streams are not joined into the caller's stream (SONDE_FLAG_PIPELINE)
 
 
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them
 ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
-    "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_read_bits",
+    "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_class_ms", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_test_rs255", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
     "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp", "sonde_rs41_pressure", "sonde_ozone_mpa",
     "sonde_m10_temp", "sonde_m10_rh", "sonde_m20_temp", "sonde_ims100_temp",

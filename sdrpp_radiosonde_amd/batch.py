@@ -102,9 +102,11 @@ class SondeBatch:
 
     def frames_of(self, ticket: int) -> np.ndarray:
         """Frames of submit `ticket` (one of the last two): waits for that submit only, not for later ones."""
-        out = np.zeros(self.n_channels * 64, dtype=FRAME_DTYPE)
-        got = self._chk(self.L.sonde_batch_frames_of(self.h, ticket, out.ctypes.data_as(C.c_void_p), len(out)))
-        return out[:got]
+        n = self._chk(self.L.sonde_batch_frames_of(self.h, ticket, None, 0))       # count first: the buffer is sized from it
+        out = np.zeros(n, dtype=FRAME_DTYPE)
+        if n:
+            out = out[:self._chk(self.L.sonde_batch_frames_of(self.h, ticket, out.ctypes.data_as(C.c_void_p), n))]
+        return out
 
     def overflow(self) -> int:
         return self._chk(self.L.sonde_batch_overflow(self.h))
@@ -127,6 +129,14 @@ class SondeBatch:
         a, b = C.c_float(), C.c_float()
         self._chk(self.L.sonde_batch_kernel_ms(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def class_ms(self) -> dict:
+        """Mixed batches: {class index: average ms of that demodulator class's kernel alone} over the timed submits
+        (sonde_batch_class_ms); {} for a batch of one class."""
+        v = (C.c_float * 4)()
+        self.L.sonde_batch_class_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        n = self._chk(self.L.sonde_batch_class_ms(self.h, v))
+        return {k: float(v[k]) for k in range(4) if n > 0 and v[k] >= 0.0}
 
     def set_timing(self, every_n: int):
         """Record kernel-timing events on every n-th submit only (0: never); the next submit is timed."""

@@ -148,22 +148,35 @@ struct SondeBatch {
 	// AFSK sondes (iMet): tone-demodulator state, mixer table, 6 kS/s scratch rows; the other channels' list for kernel A
 	SdAfskState *d_astates = nullptr;
 	float *d_wtab = nullptr, *d_wtab_c50 = nullptr, *d_afq = nullptr;
-	// kernel A runs once per (decimation, taps) class of the non-AFSK channels (k_cls_*): one class in the batch = one plain
-	// launch over all channels; several = one launch per class over its channel list
-	uint32_t *d_cls[4] = {};
+	// kernel A is instantiated per (decimation, taps) class (k_cls_*).  One class in the batch = one plain launch over all
+	// channels.  Several (or AFSK channels) = LAUNCH UNITS: every sonde type's channel list is cut into n_chunks pieces, a unit is
+	// (type, piece): its demod launch (the type's class) and its frame decoder behind it on the unit's OWN stream, so that the
+	// units overlap on the GPU and a unit's submits stay ordered from submit to submit.  Units are launched piece by piece,
+	// inside a piece the type with the longest-running workgroups first (M10: twice the symbols per tile; then RS41, whose
+	// workgroups end with the FEC epilogue): with n_chunks > 1 every compute unit holds a mix of heavy (M10: VALU / LDS bound)
+	// and light (HBM bound) workgroups at any time instead of a generation of M10 followed by generations of the others.
 	uint32_t n_cls[4] = {};
 	int n_classes = 0, only_class = 0;
-	// launch order of the classes of a mixed batch: the class with the longest-running workgroups (M10: twice the symbols
-	// per tile) first, then the 4:1 class (whose RS41 workgroups end with the FEC epilogue); round 2 measured all six orders of
-	// its three classes: 0.3537 ms per step for this rule, the worst order 0.3667 (profiles/r2_notes.md)
-	int cls_order[4] = { 3, 0, 2, 1 };
-	hipStream_t aux[4] = {};               // side streams so that the per-class launches of a mixed batch overlap
-	hipEvent_t ev_fork = nullptr, ev_join[4] = {};
+	// Joined batches (the default: every submit ends in the caller's stream) launch per CLASS instead (type = -1: the types
+	// of a class share one launch over the class's channel list, their frame decoders follow): measured 0.319 ms per step
+	// against 0.336 per type for 4096 RS41 / M10 / DFM channels x 24 tiles; pipelined (SONDE_FLAG_PIPELINE) it is the other way
+	// round, 0.321 per class against 0.289 per type, and more pieces than one only add launches (profiles/r3_notes.md).
+	struct Unit { int type, cls; uint32_t off, n; size_t row0; hipStream_t st; hipEvent_t ev_join; };
+	std::vector<Unit> units;
+	uint32_t *d_cls[4] = {};               // joined batches: the channel list of each class
+	int n_chunks = 1;
+	hipEvent_t ev_fork = nullptr;
+	// SONDE_FLAG_PIPELINE: the class streams are not joined into the caller's stream; this stream collects them for completion
+	bool pipeline = false;
+	hipStream_t done_stream = nullptr;
 	uint32_t granule = SONDE_TILE;         // submit sizes must be a multiple of this
 
 	static const int kEvSlots = 128;       // submits timed between two sonde_batch_kernel_ms() calls
 	hipEvent_t ev[3 * kEvSlots] = {};
 	int ev_used = 0;
+	// mixed batches: the same for each class's demod kernel alone, on its class stream (sonde_batch_class_ms)
+	hipEvent_t *evc = nullptr;             // [kEvSlots][units][2]
+	int evc_used = 0;
 	// an event record is a bubble of a few microseconds in the command stream (three of them cost a 0.29 ms step 3 %), so
 	// only every timing_every-th submit is timed (0: none)
 	int timing_every = 8;
@@ -192,12 +205,15 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	for (int k = 0; k < 2; k++) { (void)hipFree(b->d_frames2[k]); (void)hipFree(b->d_counts2[k]); (void)hipFree(b->d_fo2[k]); if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]); }
 	if (b->ev_xs) (void)hipEventDestroy(b->ev_xs);
 	(void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
-	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_wtab_c50); (void)hipFree(b->d_afq); for (int k = 0; k < 4; k++) (void)hipFree(b->d_cls[k]);
-	for (int k = 0; k < 4; k++) { if (b->aux[k]) (void)hipStreamDestroy(b->aux[k]); if (b->ev_join[k]) (void)hipEventDestroy(b->ev_join[k]); }
+	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_wtab_c50); (void)hipFree(b->d_afq);
+	for (auto &u : b->units) { if (u.st) (void)hipStreamDestroy(u.st); if (u.ev_join) (void)hipEventDestroy(u.ev_join); }
+	for (int k = 0; k < 4; k++) (void)hipFree(b->d_cls[k]);
+	if (b->done_stream) (void)hipStreamDestroy(b->done_stream);
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
 	(void)hipFree(b->d_gfexp); (void)hipFree(b->d_gflog); (void)hipFree(b->d_gfswar); (void)hipFree(b->d_g64); (void)hipFree(b->d_m10tab); (void)hipFree(b->d_descs); (void)hipFree(b->d_stage);
 	for (int t = 0; t < SONDE_NTYPES; t++) (void)hipFree(b->d_chlist[t]);
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+	if (b->evc) { for (size_t i = 0; i < 2 * b->units.size() * SondeBatch::kEvSlots; i++) if (b->evc[i]) (void)hipEventDestroy(b->evc[i]); delete[] b->evc; }
 	delete b;
 }
 
@@ -281,8 +297,6 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		if (b->n_cls[k]) { b->n_classes++; b->only_class = k; }
 	}
 	const bool need_lists = n_afsk != 0 || b->n_classes > 1;
-	if (need_lists)
-		for (int k = 0; k < 4; k++) if (b->n_cls[k]) ALLOC(b->d_cls[k], cls[k].size() * sizeof(uint32_t));
 	if (n_afsk) {
 		if (cfg->max_samples % (SONDE_TILE * SD_AF_DEC)) { sonde_batch_destroy(b); return fail("sonde_batch_create: with iMet channels max_samples must be a multiple of 16384"); }
 		b->granule = SONDE_TILE * SD_AF_DEC;
@@ -403,17 +417,52 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		CHK(hipMemcpy(b->d_wtab_c50, wc, sizeof(wc), hipMemcpyHostToDevice));
 		CHK(hipMemset(b->d_astates, 0, C * sizeof(SdAfskState)));
 	}
-	for (int k = 0; k < 4; k++)
-		if (b->d_cls[k]) CHK(hipMemcpy(b->d_cls[k], cls[k].data(), cls[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty())
 			CHK(hipMemcpy(b->d_chlist[t], b->chlist[t].data(), b->chlist[t].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) CHK(hipEventCreateWithFlags(&b->ev[i], SD_EV_TIMING));
 	if (need_lists) {
 		CHK(hipEventCreateWithFlags(&b->ev_fork, SD_EV_ORDER));
-		for (int k = 0; k < 4; k++) {
-			CHK(hipStreamCreateWithFlags(&b->aux[k], hipStreamNonBlocking));
-			CHK(hipEventCreateWithFlags(&b->ev_join[k], SD_EV_ORDER));
+		const bool pipelined = (cfg->flags & SONDE_FLAG_PIPELINE) != 0;
+		// pieces per type (pipelined batches): one; SONDE_MIX_CHUNKS overrides for experiments (2-8 pieces measured 6-70 % slower)
+		int R = 1;
+		if (const char *e = getenv("SONDE_MIX_CHUNKS")) R = std::max(1, std::min(16, atoi(e)));
+		b->n_chunks = pipelined ? R : 1;
+		static const int order[] = { SONDE_M10, SONDE_RS41, SONDE_DFM09, SONDE_IMS100, SONDE_MRZN1 };
+		if (pipelined) {
+			for (int j = 0; j < R; j++)
+				for (int t : order) {
+					const size_t nt = b->chlist[t].size();
+					const size_t lo = nt * (size_t)j / (size_t)R, hi = nt * (size_t)(j + 1) / (size_t)R;
+					if (hi > lo) b->units.push_back({ t, modem_class(md, t), (uint32_t)lo, (uint32_t)(hi - lo), 0, nullptr, nullptr });
+				}
+		} else {
+			// class order: the class with the longest-running workgroups (M10: twice the symbols per tile) first, then the 4:1
+			// class (whose RS41 workgroups end with the FEC epilogue): best of all orders in round 2 (profiles/r2_notes.md)
+			for (int k : { 3, 0, 2, 1 }) {
+				if (!b->n_cls[k]) continue;
+				hipError_t e_ = hipMalloc((void **)&b->d_cls[k], cls[k].size() * sizeof(uint32_t));
+				if (e_ == hipSuccess) e_ = hipMemcpy(b->d_cls[k], cls[k].data(), cls[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+				if (e_ != hipSuccess) { sonde_batch_destroy(b); return fail("hipMalloc d_cls", e_); }
+				b->units.push_back({ -1, k, 0, b->n_cls[k], 0, nullptr, nullptr });
+			}
+		}
+		size_t row0 = 0;
+		for (int t : { SONDE_IMET4, SONDE_C50 }) {       // AFSK chains: tone demodulator -> 6 kS/s rows -> demod -> framer, one unit per type
+			if (b->chlist[t].empty()) continue;
+			b->units.push_back({ t, 0, 0, (uint32_t)b->chlist[t].size(), row0, nullptr, nullptr });
+			row0 += b->chlist[t].size();
+		}
+		for (auto &u : b->units) {
+			CHK(hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking));
+			CHK(hipEventCreateWithFlags(&u.ev_join, SD_EV_ORDER));
+		}
+		const size_t nev = 2 * b->units.size() * SondeBatch::kEvSlots;
+		b->evc = new hipEvent_t[nev]();
+		for (size_t i = 0; i < nev; i++) CHK(hipEventCreateWithFlags(&b->evc[i], SD_EV_TIMING));
+		if (cfg->flags & SONDE_FLAG_PIPELINE) {
+			b->pipeline = true;
+			CHK(hipStreamCreateWithFlags(&b->done_stream, hipStreamNonBlocking));
 		}
 	}
 #undef CHK
@@ -444,27 +493,31 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	uint32_t *const d_counts = b->d_counts2[slot];
 	const SdFramerOut *fo = b->d_fo2[slot];    // the demod kernel runs the sync search itself and lists complete frames there
 	// consecutive submits share the per-channel state: a submit on another stream waits for the previous one
-	if (b->tickets && stream != b->last_stream) {
+	// (pipelined mixed batches: every class keeps its own stream from submit to submit, which orders them)
+	const bool pipe = b->pipeline;
+	if (!pipe && b->tickets && stream != b->last_stream) {
 		HIPCHK(hipEventRecord(b->ev_xs, b->last_stream));
 		HIPCHK(hipStreamWaitEvent(stream, b->ev_xs, 0));
 	}
 	// the framers of one sonde type, behind the demod launch that produced its bits, on that launch's stream
 	// (d_counts: zeroed at creation; every sync kernel rewrites the entry of each channel it owns on every submit)
 	bool framer_launched = false;
-	auto launch_framers = [&](int t, hipStream_t sk) -> int {
+	// (off, nch: the piece of the type's channel list to work on; nch = 0: all of it)
+	auto launch_framers = [&](int t, hipStream_t sk, uint32_t off = 0, uint32_t nch = 0) -> int {
 		if (b->chlist[t].empty()) return 0;
-		const uint32_t nch = (uint32_t)b->chlist[t].size();
+		if (!nch) nch = (uint32_t)b->chlist[t].size();
+		const uint32_t *list = b->d_chlist[t] + off;
 		if (t == SONDE_RS41) {
 			if (b->fuse_fec) return 0;             // sync search and FEC ran inside the demod kernel
 			sd_launch_framer_rs41(nch, sk, b->d_bitring, b->ring_words, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_descs,
-				d_frames, d_counts, b->max_frames, b->type_frames[SONDE_RS41], b->d_chlist[SONDE_RS41]);
+				d_frames, d_counts, b->max_frames, b->type_frames[SONDE_RS41], list);
 		} else if (t == SONDE_C50) {
-			sd_launch_framer_c50(nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words, d_frames, d_counts, b->max_frames, b->d_chlist[t]);
+			sd_launch_framer_c50(nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words, d_frames, d_counts, b->max_frames, list);
 		} else if (t == SONDE_IMET4) {
-			sd_launch_framer_imet(nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words, d_frames, d_counts, b->max_frames, b->d_chlist[t]);
+			sd_launch_framer_imet(nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words, d_frames, d_counts, b->max_frames, list);
 		} else {
 			sd_launch_framer_other(t, nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
-				t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, d_frames, d_counts, b->max_frames, b->type_frames[t], b->d_chlist[t],
+				t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, d_frames, d_counts, b->max_frames, b->type_frames[t], list,
 				/* with_sync = */ !b->fuse_fec);        // default: the demod kernel has run the sync search (K4) itself
 		}
 		HIPCHK(hipGetLastError());
@@ -479,42 +532,45 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
 		for (int t = 0; t < SONDE_NTYPES; t++) if (launch_framers(t, stream)) return -1;
 	} else {
-		// fork: the class launches are independent (disjoint channels), let them share the GPU; each class's frame decoders
-		// follow its demod kernel on the same stream, so that they overlap the other classes' demodulators instead of
-		// waiting for the slowest one (a mixed RS41/M10/DFM batch: 0.368 -> see profiles/r2_notes.md)
+		// fork: the launch units are independent (disjoint channels), let them share the GPU; a unit's frame decoder follows
+		// its demod kernel on the unit's stream, so that it overlaps the other units' demodulators
 		HIPCHK(hipEventRecord(b->ev_fork, stream));
-		int used = 0;
-		for (int kk = 0; kk < 4; kk++) {
-			const int k = b->cls_order[kk];
-			if (!b->n_cls[k]) continue;
-			hipStream_t sk = used == 0 ? stream : b->aux[k];
-			if (sk != stream) HIPCHK(hipStreamWaitEvent(sk, b->ev_fork, 0));
-			sd_launch_demod(iq, k_cls_decim[k], k_cls_nt[k], b->n_cls[k], sk, (const float *)samples, channel_stride, n_tiles,
-				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_cls[k], false, fo);
-			HIPCHK(hipGetLastError());
-			for (int t = 0; t < SONDE_NTYPES; t++)
-				if (t != SONDE_IMET4 && t != SONDE_C50 && modem_class(b->md, t) == k && launch_framers(t, sk)) return -1;
-			if (sk != stream) { HIPCHK(hipEventRecord(b->ev_join[k], sk)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[k], 0)); }
-			used++;
-		}
-		if (n_afsk) {
-			// AFSK channels: tone demodulator into 6 kS/s scratch rows (iMet's first, then C50's), then kernel A's real-input
-			// path over those rows (one kernel-A tile = 2048 scratch samples = 16384 input samples)
-			const size_t nq = n_samples / SD_AF_DEC;
-			size_t row0 = 0;
-			for (int t : { SONDE_IMET4, SONDE_C50 }) {
-				const size_t nt = b->chlist[t].size();
-				if (!nt) continue;
-				float *rows = b->d_afq + row0 * (size_t)(b->max_samples / SD_AF_DEC);
-				sd_launch_afsk(t, iq, (uint32_t)nt, stream, (const float *)samples, channel_stride, n_tiles,
-					b->d_chlist[t], b->d_astates, t == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
-				sd_launch_demod(false, 1, 16, (uint32_t)nt, stream, rows, nq, (int)(nq / SONDE_TILE),
-					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[t], true, fo);
-				HIPCHK(hipGetLastError());
-				if (launch_framers(t, stream)) return -1;
-				row0 += nt;
+		const size_t nq = n_samples / SD_AF_DEC;
+		hipStream_t join_to = pipe ? b->done_stream : stream;
+		for (size_t ui = 0; ui < b->units.size(); ui++) {
+			const SondeBatch::Unit &u = b->units[ui];
+			HIPCHK(hipStreamWaitEvent(u.st, b->ev_fork, 0));
+			hipEvent_t *ec = b->evc + 2 * (b->units.size() * (size_t)(b->evc_used % SondeBatch::kEvSlots) + ui);
+			if (timed) HIPCHK(hipEventRecord(ec[0], u.st));
+			if (u.type == SONDE_IMET4 || u.type == SONDE_C50) {
+				// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows
+				// (one kernel-A tile = 2048 scratch samples = 16384 input samples)
+				float *rows = b->d_afq + u.row0 * (size_t)(b->max_samples / SD_AF_DEC);
+				sd_launch_afsk(u.type, iq, u.n, u.st, (const float *)samples, channel_stride, n_tiles,
+					b->d_chlist[u.type], b->d_astates, u.type == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
+				sd_launch_demod(false, 1, 16, u.n, u.st, rows, nq, (int)(nq / SONDE_TILE),
+					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo);
+			} else {
+				sd_launch_demod(iq, k_cls_decim[u.cls], k_cls_nt[u.cls], u.n, u.st, (const float *)samples, channel_stride, n_tiles,
+					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems,
+					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo);
 			}
+			HIPCHK(hipGetLastError());
+			if (timed) HIPCHK(hipEventRecord(ec[1], u.st));
+			if (u.type >= 0) {
+				if (launch_framers(u.type, u.st, u.off, u.n)) return -1;
+			} else {
+				for (int t = 0; t < SONDE_NTYPES; t++)
+					if (t != SONDE_IMET4 && t != SONDE_C50 && modem_class(b->md, t) == u.cls && launch_framers(t, u.st)) return -1;
+			}
+			// join: into the caller's stream (work queued there afterwards sees the submit finished), or -- pipelined -- into the
+			// library's completion stream only, so that the next submit's units start behind their OWN predecessors and the
+			// tail of one unit (its last workgroups draining, its frame decoder) overlaps the other units' next submit
+			HIPCHK(hipEventRecord(u.ev_join, u.st));
+			HIPCHK(hipStreamWaitEvent(join_to, u.ev_join, 0));
 		}
+		if (timed) b->evc_used++;
+		if (pipe) stream = b->done_stream;      // where the submit completes: timing end, completion event, sonde_batch_sync
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
 		framer_launched = false;               // inside the fork/join region: timed with the demodulators
 	}
@@ -605,7 +661,8 @@ extern "C" long sonde_batch_frames_of(SondeBatch *b, uint64_t ticket, SondeFrame
 	if (!b) return fail("sonde_batch_frames_of: null argument");
 	const long n = sync_ticket(b, ticket);
 	if (n < 0) return n;
-	if (n == 0 || !out || cap == 0) return 0;
+	if (!out || cap == 0) return n;          // count only: size the buffer from it
+	if (n == 0) return 0;
 	const int slot = (int)((ticket - 1) & 1);
 	const std::vector<uint32_t> &h_counts = b->h_counts2[slot];
 	const SondeFrame *d_frames = b->d_frames2[slot];
@@ -701,7 +758,38 @@ extern "C" int sonde_batch_set_timing(SondeBatch *b, int every_n)
 	b->timing_every = every_n;
 	b->n_submits = 0;
 	b->ev_used = 0;
+	b->evc_used = 0;
 	return 0;
+}
+
+// Mixed batches: average device time (ms) of each demodulator class's kernel alone over the timed submits since the last
+// call / sonde_batch_set_timing; class index: 0 (decimation 1, 16 taps), 1 (2, 16), 2 (4, 8), 3 (2, 8); -1: class not in the
+// batch.  Returns the number of timed submits averaged (0: the batch is one class -- use sonde_batch_kernel_ms).
+extern "C" int sonde_batch_class_ms(SondeBatch *b, float out[4])
+{
+	if (!b || !out) return fail("sonde_batch_class_ms: null argument");
+	for (int k = 0; k < 4; k++) out[k] = -1.0f;
+	if (!b->evc) return 0;
+	if (sonde_batch_sync(b) < 0) return -1;
+	const int n = std::min(b->evc_used, (int)SondeBatch::kEvSlots);
+	const size_t nu = b->units.size();
+	for (int k = 0; k < 4 && n > 0; k++) {
+		float acc = 0.0f;
+		int cnt = 0;
+		for (size_t ui = 0; ui < nu; ui++) {
+			const SondeBatch::Unit &u = b->units[ui];
+			if (u.type == SONDE_IMET4 || u.type == SONDE_C50 || u.cls != k) continue;
+			for (int i = 0; i < n; i++) {
+				float x = 0.0f;
+				HIPCHK(hipEventElapsedTime(&x, b->evc[2 * (nu * (size_t)i + ui)], b->evc[2 * (nu * (size_t)i + ui) + 1]));
+				acc += x;
+				cnt++;
+			}
+		}
+		if (cnt) out[k] = acc / (float)cnt;
+	}
+	b->evc_used = 0;
+	return n;
 }
 
 // ---------------------------------------------------------------- introspection (staged parity tests)

@@ -413,6 +413,77 @@ def gfsk_modulate(bits: np.ndarray, n_samples: int, baud: float, *, seed: int = 
     return out, cfo, tau, amp
 
 
+def make_rs41_cyclic_block(n_channels: int, n_block: int, n_blocks: int, k: int, *, seed: int = 1, ebn0_db: float = 30.0,
+                           device: str | torch.device = "cpu", h: float = 1.0, bt: float = 0.5, cfo_max_hz: float = 500.0,
+                           amp_range=(0.25, 1.0), chunk: int = 128, fs: float = FS) -> torch.Tensor:
+    """Block k (of n_blocks) of the seamless RS41 signal make_rs41_cyclic describes, generated ALONE: [C, n_block, 2] float32.
+    For ingest nodes that hold one block of many channels at a time (bench.py --gpus N: generate -> scatter -> free).
+    The phase at the block's first sample comes from the closed-form integral of the Gaussian frequency pulses (a prefix sum
+    of the NRZ symbols plus the erf-integral of the few pulses that straddle the boundary), the phase inside the block from
+    the same per-sample frequency the whole-signal modulator integrates; the noise generator is keyed by (seed, k, chunk).
+    Not sample-identical to make_rs41_cyclic (the discrete and the continuous integral differ by a fraction of one sample's
+    phase step at each block boundary), the same signal to a decoder."""
+    baud = 4800.0
+    total = n_blocks * n_block
+    nb = total * baud / fs
+    assert abs(nb - round(nb)) < 1e-9 and int(round(nb)) % (8 * 384) == 0, "the cycle must hold a whole number of frame periods"
+    nb = int(round(nb))
+    C = n_channels
+    sps = fs / baud
+    start = k * n_block
+    rng = np.random.Generator(np.random.Philox(key=(seed * 104729 + 5) & 0xFFFFFFFFFFFFFFFF))
+    cfo = rng.uniform(-cfo_max_hz, cfo_max_hz, size=C)
+    tau = rng.uniform(0.0, 1.0, size=C)
+    amp = rng.uniform(amp_range[0], amp_range[1], size=C)
+    dev_hz = h * baud / 2.0
+    sigma_t = math.sqrt(math.log(2.0)) / (2.0 * math.pi * bt)
+    k_erf = 1.0 / (sigma_t * math.sqrt(2.0))
+    out = torch.empty((C, n_block, 2), dtype=torch.float32, device=device)
+    n = torch.arange(start, start + n_block, device=device, dtype=torch.float64)
+
+    def H(z):                                                    # integral of erf(k_erf z)
+        return z * torch.erf(k_erf * z) + torch.exp(-(k_erf * z) ** 2) / (k_erf * math.sqrt(math.pi))
+
+    for c0 in range(0, C, chunk):
+        c1 = min(C, c0 + chunk)
+        bits, _ = rs41_cyclic_bitstreams(seed + 7 * (c0 // chunk), np.arange(c0, c1), n_frames=nb // (8 * 384))
+        nrz_np = bits.astype(np.float64) * 2.0 - 1.0
+        nrz = torch.from_numpy(nrz_np).to(device)                                     # [c, nb]
+        prefix = torch.from_numpy(np.concatenate([np.zeros((c1 - c0, 1)), np.cumsum(nrz_np, axis=1)], axis=1)).to(device)
+        tau_t = torch.from_numpy(tau[c0:c1]).to(device)[:, None]
+        # ---- phase at the block's first sample: sum over the symbols of this cycle that started before it
+        us = start / sps - tau_t                                                      # [c, 1] symbol units
+        kb = torch.floor(us).to(torch.int64) - 4                                      # symbols <= kb lie wholly before the block
+        acc = torch.gather(prefix, 1, (kb + 1).clamp(0, nb))                          # their NRZ sum (0 if none)
+        for j in range(1, 10):
+            kk = kb + j
+            valid = (kk >= 0) & (kk < nb)
+            a = torch.gather(nrz, 1, kk.clamp(0, nb - 1)) * valid
+            x = us - kk.to(torch.float64) - 0.5
+            acc = acc + a * (0.5 * (H(x + 0.5) - H(x - 0.5)) + 0.5)
+        ph0 = (torch.from_numpy(cfo[c0:c1]).to(device)[:, None] * start + dev_hz * sps * acc) * (2.0 * math.pi / fs)
+        # ---- inside the block: the modulator's per-sample frequency (symbols looked up cyclically)
+        u = n[None, :] / sps - tau_t
+        k0 = torch.floor(u).to(torch.int64)
+        f = torch.zeros_like(u)
+        for j in range(-2, 3):
+            kk = k0 + j
+            valid = kk >= 0                                                            # the cycle's first pass has no past
+            a = torch.gather(nrz, 1, torch.remainder(kk, nb)) * valid
+            x = u - kk.to(torch.float64) - 0.5
+            f += a * 0.5 * (torch.erf(k_erf * (x + 0.5)) - torch.erf(k_erf * (x - 0.5)))
+        f = f * dev_hz + torch.from_numpy(cfo[c0:c1]).to(device)[:, None]
+        ph = ph0 + (torch.cumsum(f, dim=1) - f) * (2.0 * math.pi / fs)                  # phase AT sample i: everything before it
+        a_t = torch.from_numpy(amp[c0:c1]).to(device)[:, None]
+        sig = (a_t * math.sqrt(sps / (2.0 * 10.0 ** (ebn0_db / 10.0)))).to(torch.float32)
+        gen = torch.Generator(device=device)
+        gen.manual_seed((seed * 2654435761 + 1000003 * k + c0) % (2 ** 63))
+        noise = torch.randn((c1 - c0, n_block, 2), generator=gen, device=device, dtype=torch.float32)
+        out[c0:c1, :, 0] = (a_t * torch.cos(ph)).to(torch.float32) + sig * noise[:, :, 0]
+        out[c0:c1, :, 1] = (a_t * torch.sin(ph)).to(torch.float32) + sig * noise[:, :, 1]
+    return out
+
+
 def make_rs41_batch(n_channels: int, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
                     device: str | torch.device = "cpu", first_channel: int = 0, extended: bool = False,
                     invert: bool = False, sgp: bool = False, **mod_kw) -> SynthBatch:

@@ -18,14 +18,14 @@ def test_bench_two_ranks_share_one_gpu_under_gloo():
     env = dict(os.environ, SONDE_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu", "--channels", "64",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rank-local", "--no-cpu", "--channels", "64",
                           "--tiles", "12", "--steps", "4", "--warmup", "2", "--ramp-ms", "10"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                    # ONE line, from rank 0
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["sharding"] == "channels/2"
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["sharding"] == "channels/2" and j["config"]["ingest"] == "rank-local"
     assert j["nccl_ranks"]["world"] == 2 and j["nccl_ranks"]["backend"] == "gloo"
     assert j["frames_per_step_steady"] > 0 and j["value"] > 0
     # whole-job aggregate: both ranks' samples over the slowest rank's time
@@ -34,18 +34,40 @@ def test_bench_two_ranks_share_one_gpu_under_gloo():
 
 @pytest.mark.gpu
 def test_bench_scatter_ingest_two_ranks_under_gloo():
-    """--scatter: rank 0 generates every rank's blocks of the seamless signal and scatters them block by block (here through
-    torch.distributed, the two ranks sharing the one GPU; the native RCCL scatter needs one device per rank)."""
+    """`bench.py --gpus 2` as typed ingests the way north_star names it: rank 0 generates ONE block of every rank's channels at a
+    time and scatters it (here through torch.distributed, the two ranks sharing the one GPU under the gloo test hook; the
+    native RCCL scatter needs one device per rank: test_bench_native_scatter_two_gpus)."""
     env = dict(os.environ, SONDE_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scatter", "--scatter-torch", "--no-cpu",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu",
                           "--channels", "64", "--tiles", "12", "--steps", "4", "--warmup", "2", "--ramp-ms", "10"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 2 and j["config"]["ingest"].startswith("scatter from rank 0") and j["scatter_ms"] > 0
+    assert j["scatter"]["blocks"] == 5 and j["scatter"]["bytes_from_root"] == 5 * 64 * 12 * 2048 * 8
     assert j["frames_per_step_steady"] == pytest.approx(2 * 64 * 12 * 2048 / 10 / 3072, rel=0.02)      # one frame per 3072 symbols and channel
+
+
+@pytest.mark.gpu
+def test_bench_native_scatter_two_gpus():
+    """world = 2 over RCCL with the native grouped ncclSend / ncclRecv scatter (csrc/shard_rccl.cpp) when the box has two GPUs:
+    `python bench.py --gpus 2` exactly as the driver types it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the one-GPU boxes run the gloo variant above)")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SONDE_BENCH_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu", "--channels", "256",
+                          "--tiles", "24", "--steps", "10", "--warmup", "3", "--ramp-ms", "50"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["config"]["ingest"] == "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)"
+    assert j["nccl_ranks"] == {"backend": "rccl", "world": 2, "distinct_devices": 2}
+    assert j["frames_per_step_steady"] == pytest.approx(2 * 256 * 24 * 2048 / 10 / 3072, rel=0.02)
 
 
 def test_bench_refuses_more_ranks_than_gpus_without_the_hook():

@@ -105,3 +105,47 @@ def test_split_framers_equal_in_kernel_sync(oracle):
         g = np.concatenate(parts)
         outs.append(g[np.lexsort((g["bitpos"], g["channel"]))])
     assert len(outs[0]) >= 2 * C and outs[0].tobytes() == outs[1].tobytes()
+
+
+def test_pipelined_mixed_batch_equals_joined(oracle):
+    """SONDE_FLAG_PIPELINE: every sonde type's kernels keep their own stream from submit to submit and are never joined into
+    the caller's stream; three submits queued back to back, frames fetched per ticket afterwards (the last two) and per
+    submit (a second run): the same records as the default (joined) batch, which equal the oracle's."""
+    from sdrpp_radiosonde_amd._lib import FLAG_PIPELINE
+    C, n, parts = 16, TILE * 24 * 3, 3          # RS41, M10, DFM, iMS-100 + one iMet and one C50 channel (AFSK units: 16384-sample granule)
+    types = np.array([(0, 3, 1, 2)[c % 4] for c in range(C)], dtype=np.uint8)
+    types[4], types[9] = 4, 5
+    iq = torch.empty((C, n, 2), dtype=torch.float32)
+    for t in sorted(set(types.tolist())):
+        idx = np.nonzero(types == t)[0]
+        iq[idx] = synth.make_batch(int(t), len(idx), n, seed=90 + int(t), ebn0_db=15.0).iq
+    dev = iq.to("cuda:0")
+    chunks = [dev[:, p * (n // parts): (p + 1) * (n // parts)].contiguous() for p in range(parts)]
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    outs = {}
+    for flags in (0, FLAG_PIPELINE):
+        b = SondeBatch(C, n // parts, types=types, flags=flags)
+        fr = []
+        for ch in chunks:
+            b.submit(ch)
+            fr.append(b.frames())
+        outs[flags] = key(np.concatenate(fr))
+        b.close()
+    assert len(outs[0]) >= C and outs[0].tobytes() == outs[FLAG_PIPELINE].tobytes()
+    # queued back to back: tickets
+    b = SondeBatch(C, n // parts, types=types, flags=FLAG_PIPELINE)
+    b.ticket()
+    b.submit(chunks[0]); t1 = b.ticket()
+    b.submit(chunks[1]); t2 = b.ticket()
+    f1 = b.frames_of(t1)
+    b.submit(chunks[2]); t3 = b.ticket()
+    f2, f3 = b.frames_of(t2), b.frames_of(t3)
+    assert key(np.concatenate([f1, f2, f3])).tobytes() == outs[0].tobytes()
+    # and the joined result is the oracle's
+    refs = []
+    for t in sorted(set(types.tolist())):
+        idx = np.nonzero(types == t)[0]
+        r = oracle.batch_run(int(t), iq[idx].numpy(), nthreads=4, cap_per_channel=4096 if t in (4, 5) else 0)     # C50: 9-byte packets
+        r["channel"] = idx[r["channel"]]
+        refs.append(r)
+    assert key(np.concatenate(refs)).tobytes() == outs[0].tobytes()

@@ -266,7 +266,7 @@ def test_rs41_wide_mode(oracle):
         assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in frames[f["channel"]])
 
 
-@pytest.mark.parametrize("stype,wide_decim,cfo", [(1, 2, 4500.0), (3, 1, 8000.0)])
+@pytest.mark.parametrize("stype,wide_decim,cfo", [(1, 2, 3700.0), (3, 1, 8000.0)])
 def test_wide_mode_other_types(oracle, stype, wide_decim, cfo):
     """SONDE_FLAG_WIDE for DFM (2:1 instead of 4:1) and M10 (48 kS/s instead of 2:1): the kernel classes (2, 16) and
     (1, 16) -- bit-exact against the oracle set the same way; they decode a carrier offset the default classes cannot."""
