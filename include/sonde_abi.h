@@ -162,7 +162,9 @@ long sonde_batch_overflow(SondeBatch *b);
 /* The decoded telemetry of the last submit as SondeData fragments (what the reference's per-channel X_decode loops
  * would have returned, decoder.hpp:61), in (channel, time) order, with the channel each belongs to.  The engine keeps
  * one stateful parser per channel.  Call repeatedly until it returns 0; fragments not fetched before the next
- * submit's poll are kept and delivered first.  Returns the number written (<= cap) or a negative error. */
+ * submit's poll are kept and delivered first.  Every submit since the previous poll that is still resident is parsed, in
+ * order (frame slots exist twice: poll at least every second submit; an overwritten, unpolled submit is a negative error,
+ * once).  Returns the number written (<= cap) or a negative error. */
 long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t cap);
 /* Average device time (ms) of the demod kernel (for RS41 channels it includes the sync search and the FEC epilogue) and of
  * the framer/FEC kernels behind it (0 if there are none) over the TIMED submits since the previous call of this function
@@ -225,6 +227,11 @@ float sonde_ims100_temp(uint32_t f, float c0, float c1, float c2);
 typedef struct SondeChannelizer SondeChannelizer;
 int         sonde_chan_create(const uint8_t *types /* 512 entries or NULL = RS41 */, uint32_t blocks_per_submit /* 1..2 */,
                               int device, SondeChannelizer **out);
+/* The same for n_streams wideband streams per submit (one launch of each stage over all streams: grid.y = stream): types has
+ * n_streams * 512 entries (stream-major) or is NULL; sonde_chan_submit then takes n_streams blocks laid out back to back,
+ * [n_streams][n_samples] complex64; channel s * 512 + k of sonde_chan_batch() is bin k of stream s. */
+int         sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out);
+uint32_t    sonde_chan_streams(const SondeChannelizer *c);
 void        sonde_chan_destroy(SondeChannelizer *c);
 uint32_t    sonde_chan_samples_per_submit(const SondeChannelizer *c);
 int         sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t n_samples, void *stream);

@@ -220,6 +220,8 @@ public:
 		if (sonde_batch_create(&cfg, &m_batch) != 0) { deinit(); return false; }
 		m_cb = cb;
 		m_ctx = ctx;
+		// one object serves every sonde type here (the reference keeps one Decoder<> per type, whose m_data is never reset,
+		// decoder.hpp:127, and clears the module's lastData on a type switch, main.cpp:376): a re-init starts an empty aggregate
 		m_data = FullData();
 		m_n = 0;
 		return true;

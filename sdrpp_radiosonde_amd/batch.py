@@ -158,30 +158,33 @@ class SondeBatch:
 
 
 class SondeChannelizer:
-    """Wideband front-end (BASELINE config 4): 10 MS/s complex IQ -> 512 bins -> per-bin decode."""
+    """Wideband front-end (BASELINE config 4): n_streams x 10 MS/s complex IQ -> 512 bins each -> per-bin decode; every stage
+    is one launch over all streams.  submit() takes [samples_per_submit, 2] (one stream) or [n_streams, samples_per_submit, 2]."""
 
-    def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0):
+    def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0, n_streams: int = 1):
         self.L = _lib.load()
         self._types = None
+        self.n_streams = int(n_streams)
         tp = None
         if types is not None:
             self._types = np.ascontiguousarray(types, dtype=np.uint8)
-            assert self._types.shape == (512,)
+            assert self._types.shape == (512 * self.n_streams,)
             tp = self._types.ctypes.data_as(C.c_void_p)
         h = C.c_void_p()
-        if self.L.sonde_chan_create(tp, blocks_per_submit, device, C.byref(h)) != 0:
-            raise SondeError(_lib.last_error() or "sonde_chan_create failed")
+        if self.L.sonde_chan_create_multi(tp, blocks_per_submit, self.n_streams, device, C.byref(h)) != 0:
+            raise SondeError(_lib.last_error() or "sonde_chan_create_multi failed")
         self.h = h
         self.samples_per_submit = int(self.L.sonde_chan_samples_per_submit(self.h))
         self.n_steps = self.samples_per_submit // 250
         self.batch = SondeBatch.__new__(SondeBatch)          # borrowed view of the embedded 512-channel batch
         self.batch.L = self.L
         self.batch.h = C.c_void_p(self.L.sonde_chan_batch(self.h))
-        self.batch.n_channels = 512
+        self.batch.n_channels = 512 * self.n_streams
         self.batch.close = lambda: None
 
     def submit(self, iq, stream: int | None = None):
-        assert tuple(iq.shape) == (self.samples_per_submit, 2)
+        assert tuple(iq.shape) in ((self.samples_per_submit, 2), (self.n_streams, self.samples_per_submit, 2)) and iq.is_contiguous()
+        assert self.n_streams == 1 or iq.dim() == 3
         self._keep = iq
         if self.L.sonde_chan_submit(self.h, C.c_void_p(iq.data_ptr()), self.samples_per_submit, C.c_void_p(stream or 0)) != 0:
             raise SondeError(_lib.last_error() or "sonde_chan_submit failed")
@@ -197,8 +200,8 @@ class SondeChannelizer:
         return tuple(x.value for x in v)
 
     def read(self):
-        bins = np.zeros((512, self.n_steps, 2), dtype=np.float32)
-        out48 = np.zeros((512, self.n_steps * 6 // 5), dtype=np.float32)
+        bins = np.zeros((512 * self.n_streams, self.n_steps, 2), dtype=np.float32)
+        out48 = np.zeros((512 * self.n_streams, self.n_steps * 6 // 5), dtype=np.float32)
         if self.L.sonde_chan_read(self.h, bins.ctypes.data_as(C.c_void_p), out48.ctypes.data_as(C.c_void_p)) != 0:
             raise SondeError("sonde_chan_read failed")
         return bins, out48

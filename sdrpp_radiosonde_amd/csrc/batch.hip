@@ -191,7 +191,7 @@ struct SondeBatch {
 	// sonde_batch_poll: per-channel parsers (created on first use), fragments waiting to be fetched
 	std::vector<std::unique_ptr<SondeParser>> parsers;
 	std::deque<std::pair<uint32_t, SondeData>> frags;
-	bool polled = true;                    // the last submit's frames have been parsed
+	uint64_t polled_ticket = 0;            // submits up to this one have been parsed by sonde_batch_poll
 };
 
 static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
@@ -585,7 +585,6 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	b->last_stream = stream;
 	b->pending = true;
 	b->have_counts2[slot] = false;
-	b->polled = false;
 	return 0;
 }
 
@@ -703,11 +702,19 @@ extern "C" long sonde_batch_frames(SondeBatch *b, SondeFrame *out, size_t cap)
 extern "C" long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t cap)
 {
 	if (!b || !out || !channel) return fail("sonde_batch_poll: null argument");
-	if (!b->polled) {
-		const long n = sonde_batch_sync(b);
+	// every submit since the last poll that is still resident (frame slots exist twice): a pipelined host may have queued
+	// submit t + 1 before it polls; the per-channel parsers are stateful (RS41 calibration, DFM date, C50 position), so a
+	// skipped submit would not only lose its own fragments
+	while (b->polled_ticket < b->tickets) {
+		const uint64_t t = b->polled_ticket + 1;
+		if (b->tickets - t >= 2) {
+			b->polled_ticket = b->tickets - 2;     // resume with what is left, but say so
+			return fail("sonde_batch_poll: the frames of an unpolled submit have been overwritten (poll at least every second submit)");
+		}
+		const long n = sync_ticket(b, t);
 		if (n < 0) return n;
 		std::vector<SondeFrame> fr((size_t)n);
-		const long got = n ? sonde_batch_frames(b, fr.data(), (size_t)n) : 0;
+		const long got = n ? sonde_batch_frames_of(b, t, fr.data(), (size_t)n) : 0;
 		if (got < 0) return got;
 		if (b->parsers.empty()) b->parsers.resize(b->n_channels);
 		std::vector<SondeData> v;
@@ -719,7 +726,7 @@ extern "C" long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channe
 			b->parsers[c]->feed(fr[(size_t)i], v);
 			for (const SondeData &d : v) b->frags.emplace_back(c, d);
 		}
-		b->polled = true;
+		b->polled_ticket = t;
 	}
 	size_t k = 0;
 	while (k < cap && !b->frags.empty()) {

@@ -3,10 +3,11 @@
 //   -> per-bin FM discriminator at 40 kS/s -> real rational resampler 6/5 -> 48 kS/s -> kernel A (real input)
 // i.e. the reference's ordering  VFO channeliser -> dsp::demod::FM -> RationalResampler -> decoder
 // (/root/reference/src/main.cpp:55-60) for all 512 bins at once.  SPEC: DESIGN.md section 3.5; the CPU oracle is
-// oracle/or_chan.c.  A 10 MS/s stream is 80 MB/s: this stage is nowhere near a roofline, the kernels are
-// written for clarity and exact reproducibility (fixed summation orders), not tuned.
+// oracle/or_chan.c.  One object takes S wideband streams per submit (grid.y = stream): the filter bank, the per-bin
+// discriminator + resampler and the decoders of all S x 512 bins are one launch each.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -195,6 +196,122 @@ __global__ __launch_bounds__(PFB_NT) void sd_pfb_kernel(const float2 *__restrict
 	}
 }
 
+// ---- PFB, second form (round 3): 8 steps per 512-thread workgroup, the window (8192 + 7*250 samples = 79.5 KB) leaves room for
+// TWO workgroups per CU, blockIdx.y = wideband stream.  The 20-step form above runs one workgroup per CU and all 256 of a
+// block in lockstep, so its phases add up: staging (HBM / L2 bound, 5 us), fold (LDS bound: every step reads its 8192
+// samples, 4.3 us), FFT (VALU, 3.6 us), stores (5 us) -- 24.7 us measured for a 1.28 M-sample block.  Here the phases of the
+// two resident workgroups (and, with several streams or blocks in one launch, of successive generations) overlap; the
+// window overlap between neighbouring workgroups (5x instead of 2.6x) is served by the L2.  Arithmetic, operand order and
+// tables are those of the 20-step form (bit-identical bins: tests/test_channelizer.py).
+#define P8_S    8
+#define P8_NT   (64 * P8_S)
+#define P8_WIN  (CH_L + (P8_S - 1) * CH_D)            // 9942 samples
+#define P8_OT   (P8_S + 1)
+static_assert(P8_NT == CH_M, "fold: one thread per bin residue; FFT: one wave per step; stores: one thread per bin");
+static_assert(P8_S * PFB_FB + CH_M / 2 <= P8_WIN && CH_M * P8_OT <= P8_S * PFB_FB, "FFT buffers + twiddles / output tile alias the window");
+static_assert(2 * P8_WIN * sizeof(float2) <= 160 * 1024, "two workgroups per CU");
+static_assert(P8_WIN % 2 == 0 && (P8_S * CH_D) % 2 == 0, "16-byte staging loads");
+
+__global__ __launch_bounds__(P8_NT, 4) void sd_pfb8_kernel(const float2 *__restrict__ iq_all, size_t stream_stride,
+                                                            const float2 *__restrict__ hist_in_all, float2 *__restrict__ hist_out_all,
+                                                            const float *__restrict__ h, const float2 *__restrict__ tw,
+                                                            float2 *__restrict__ bins_all, uint32_t n_steps)
+{
+	__shared__ __attribute__((aligned(16))) float2 s_x[P8_WIN];
+	float2 *const s_tw = s_x + P8_S * PFB_FB;                 // written once the window is dead
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t m0 = blockIdx.x * P8_S, sidx = blockIdx.y;
+	const float2 *iq = iq_all + (size_t)sidx * stream_stride;
+	const float2 *hist_in = hist_in_all + (size_t)sidx * CH_H;
+	float2 *bins = bins_all + (size_t)sidx * CH_M * n_steps;
+	{	// 1. stage the window: all loads first, then all LDS stores
+		const long p0 = (long)m0 * CH_D - CH_H;                       // stream position of window sample 0 (even)
+		const float4 *src_iq = reinterpret_cast<const float4 *>(iq) + p0 / 2;
+		const float4 *src_h = reinterpret_cast<const float4 *>(hist_in) + (CH_H + p0) / 2;
+		float4 *dst = reinterpret_cast<float4 *>(s_x);
+		constexpr int NQ = (P8_WIN / 2 + P8_NT - 1) / P8_NT;
+		float4 tmp[NQ];
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			const int i = tid + P8_NT * q;
+#ifdef PFB_AB_NOSTAGE       // A/B builds (profiles/r3_notes.md): what each phase of the kernel costs
+			tmp[q] = make_float4((float)i, 0.f, 1.f, 0.f);
+#else
+			tmp[q] = i < P8_WIN / 2 ? (p0 + 2 * (long)i < 0 ? src_h[i] : src_iq[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+		}
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			const int i = tid + P8_NT * q;
+			if (i < P8_WIN / 2) dst[i] = tmp[q];
+		}
+	}
+	const float2 twv = tid < CH_M / 2 ? tw[tid] : make_float2(0.f, 0.f);
+	const int r = tid;
+	float hr[CH_T];
+#pragma unroll
+	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
+	__syncthreads();
+	if (blockIdx.x == gridDim.x - 1) {     // the last CH_H samples of [history | block] are the next submit's history
+		const float4 *tail = reinterpret_cast<const float4 *>(s_x + (P8_WIN - CH_H));
+		float4 *ho = reinterpret_cast<float4 *>(hist_out_all + (size_t)sidx * CH_H);
+		for (int i = tid; i < CH_H / 2; i += P8_NT) ho[i] = tail[i];
+	}
+	// 2. fold (SPEC 3.5: v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc), t ascending)
+	float2 v[P8_S];
+#pragma unroll
+	for (int q = 0; q < P8_S; q++) {
+		const float2 *xs = s_x + q * CH_D + r;
+		float ar = 0.0f, ai = 0.0f;
+#ifdef PFB_AB_NOFOLD
+		constexpr int NTAP = 1;
+#else
+		constexpr int NTAP = CH_T;
+#endif
+#pragma unroll
+		for (int t = 0; t < NTAP; t++) {
+			const float2 xv = xs[t * CH_M];
+			ar = __builtin_fmaf(hr[t], xv.x, ar);
+			ai = __builtin_fmaf(hr[t], xv.y, ai);
+		}
+		v[q] = make_float2(ar, ai);
+	}
+	__syncthreads();                       // the window is dead from here on
+	// 3. rotate + bit-reverse into the buffer of the step; twiddles next to the buffers
+#pragma unroll
+	for (int q = 0; q < P8_S; q++) {
+		const uint32_t shift = ((m0 + (uint32_t)q) * CH_D) & (CH_M - 1);
+		const uint32_t pos = ((uint32_t)r + shift) & (CH_M - 1);
+		s_x[q * PFB_FB + pfb_pad((int)(__brev(pos) >> 23))] = v[q];
+	}
+	if (tid < CH_M / 2) s_tw[tid] = twv;
+	__syncthreads();
+	// 4. FFT of step m0 + wave by this wave alone
+	float2 e0[8];
+#ifdef PFB_AB_NOFFT
+#pragma unroll
+	for (int j = 0; j < 8; j++) e0[j] = s_x[wave * PFB_FB + pfb_pad(lane + 64 * j)];
+#else
+	pfb_fft512(s_x + wave * PFB_FB, s_tw, lane, e0);
+#endif
+	__syncthreads();                       // every wave has left its FFT buffer: the output tile aliases them
+	// 5. tile[bin][step] (row stride 9), then one 64-byte run per thread (bin = tid)
+#pragma unroll
+	for (int j = 0; j < 8; j++) s_x[(lane + 64 * j) * P8_OT + wave] = e0[j];
+	__syncthreads();
+	{
+		float2 o[P8_S];
+#pragma unroll
+		for (int j = 0; j < P8_S; j++) o[j] = s_x[tid * P8_OT + j];
+		float4 *dst = reinterpret_cast<float4 *>(bins + (size_t)tid * n_steps + m0);
+#ifdef PFB_AB_NOSTORE
+		if (o[0].x == 1.2345e-30f)
+#endif
+#pragma unroll
+		for (int j = 0; j < P8_S / 2; j++) dst[j] = make_float4(o[2 * j].x, o[2 * j].y, o[2 * j + 1].x, o[2 * j + 1].y);
+	}
+}
+
 // ---- per bin: discriminator at 40 kS/s + 6/5 polyphase resampler to 48 kS/s.  One workgroup per bin.
 __global__ __launch_bounds__(256) void sd_disc_resamp_kernel(const float2 *__restrict__ bins, uint32_t n_steps,
                                                               const float *__restrict__ g, float2 *__restrict__ iq_last,
@@ -246,7 +363,10 @@ extern "C" const char *sonde_last_error(void);
 
 struct SondeChannelizer {
 	int device = 0;
-	uint32_t n_steps = 0;
+	uint32_t n_steps = 0, n_streams = 1;
+	int pfb_form = 8;                      // steps per filter-bank workgroup: 8 (two workgroups per CU) or 20 (SONDE_PFB_FORM=20: the round-2 kernel, one stream)
+	hipStream_t last_stream = nullptr;     // a submit on another stream waits for the previous one (the state is carried)
+	hipEvent_t ev_xs = nullptr;
 	SondeBatch *batch = nullptr;
 	float2 *d_hist[2] = {}, *d_bins = nullptr, *d_tw = nullptr, *d_iqlast = nullptr;
 	float *d_h = nullptr, *d_g = nullptr, *d_dhist = nullptr, *d_out48 = nullptr;
@@ -305,22 +425,26 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 	(void)hipSetDevice(c->device);
 	sonde_batch_destroy(c->batch);
 	for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if (c->ev_xs) (void)hipEventDestroy(c->ev_xs);
 	(void)hipFree(c->d_hist[0]); (void)hipFree(c->d_hist[1]); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_iqlast);
 	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48);
 	delete c;
 }
 
-extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submit, int device, SondeChannelizer **out)
+extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out)
 {
-	if (!out || blocks_per_submit == 0 || blocks_per_submit > 2) return -1;   // LDS: (16 + 5120 q) floats per bin
+	if (!out || blocks_per_submit == 0 || blocks_per_submit > 2 || n_streams == 0 || n_streams > 64) return -1;   // LDS: (16 + 5120 q) floats per bin
 	*out = nullptr;
 	SondeChannelizer *c = new SondeChannelizer;
 	c->device = device;
+	c->n_streams = n_streams;
 	c->n_steps = 5120u * blocks_per_submit;                  // 5120 steps = 1.28 M wideband samples = 6144 samples at 48 kS/s
+	if (const char *e = getenv("SONDE_PFB_FORM")) c->pfb_form = (atoi(e) == 20 && n_streams == 1) ? 20 : 8;
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
+	const size_t nb = (size_t)n_streams * CH_M;              // bins of all streams: the decoder batch's channels, stream-major
 	SondeBatchConfig cfg;
 	memset(&cfg, 0, sizeof(cfg));
-	cfg.n_channels = CH_M;
+	cfg.n_channels = (uint32_t)nb;
 	cfg.types = types;
 	cfg.max_samples = n_out;
 	cfg.input_kind = SONDE_INPUT_REAL;
@@ -328,24 +452,32 @@ extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submi
 	if (sonde_batch_create(&cfg, &c->batch) != 0) { delete c; return -1; }
 	std::vector<float> h, tw, g;
 	make_tables(h, tw, g);
-	bool ok = hipMalloc((void **)&c->d_hist[0], (size_t)CH_H * sizeof(float2)) == hipSuccess && hipMalloc((void **)&c->d_hist[1], (size_t)CH_H * sizeof(float2)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_bins, (size_t)CH_M * c->n_steps * sizeof(float2)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_out48, (size_t)CH_M * n_out * sizeof(float)) == hipSuccess &&
+	const size_t hist_bytes = (size_t)n_streams * CH_H * sizeof(float2);
+	bool ok = hipMalloc((void **)&c->d_hist[0], hist_bytes) == hipSuccess && hipMalloc((void **)&c->d_hist[1], hist_bytes) == hipSuccess &&
+	          hipMalloc((void **)&c->d_bins, nb * c->n_steps * sizeof(float2)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_out48, nb * n_out * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_h, CH_L * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_tw, CH_M * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_g, RS_UP * RS_TAPS * sizeof(float)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_iqlast, CH_M * sizeof(float2)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_dhist, CH_M * RS_TAPS * sizeof(float)) == hipSuccess;
-	ok = ok && hipMemset(c->d_hist[0], 0, (size_t)CH_H * sizeof(float2)) == hipSuccess && hipMemset(c->d_hist[1], 0, (size_t)CH_H * sizeof(float2)) == hipSuccess && hipMemset(c->d_iqlast, 0, CH_M * sizeof(float2)) == hipSuccess &&
-	     hipMemset(c->d_dhist, 0, CH_M * RS_TAPS * sizeof(float)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_iqlast, nb * sizeof(float2)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dhist, nb * RS_TAPS * sizeof(float)) == hipSuccess;
+	ok = ok && hipMemset(c->d_hist[0], 0, hist_bytes) == hipSuccess && hipMemset(c->d_hist[1], 0, hist_bytes) == hipSuccess && hipMemset(c->d_iqlast, 0, nb * sizeof(float2)) == hipSuccess &&
+	     hipMemset(c->d_dhist, 0, nb * RS_TAPS * sizeof(float)) == hipSuccess &&
 	     hipMemcpy(c->d_h, h.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_tw, tw.data(), CH_M * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_g, g.data(), RS_UP * RS_TAPS * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
 	for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence) == hipSuccess;     // timing only, same device
+	ok = ok && hipEventCreateWithFlags(&c->ev_xs, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
 	if (!ok) { sonde_chan_destroy(c); return -1; }
 	*out = c;
 	return 0;
 }
+
+extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submit, int device, SondeChannelizer **out)
+{
+	return sonde_chan_create_multi(types, blocks_per_submit, 1, device, out);
+}
+extern "C" uint32_t sonde_chan_streams(const SondeChannelizer *c) { return c ? c->n_streams : 0; }
 
 extern "C" uint32_t sonde_chan_samples_per_submit(const SondeChannelizer *c) { return c ? c->n_steps * CH_D : 0; }
 extern "C" SondeBatch *sonde_chan_batch(SondeChannelizer *c) { return c ? c->batch : nullptr; }
@@ -365,13 +497,23 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		c->ev_pending = false;
 	}
 	const bool timed = !c->ev_pending && (c->n_submits++ % 8) == 0;
-	if ((uintptr_t)iq_dev & 15u) return -1;       // 16-byte loads straight from the caller's block
+	if ((uintptr_t)iq_dev & 15u) return -1;       // 16-byte loads straight from the caller's block(s)
+	// the front-end kernels carry state too (window history, discriminator history): a submit on another stream waits for
+	// the previous one BEFORE the filter bank starts (sonde_batch_submit orders only the decoder behind them)
+	if (c->n_blocks && stream != c->last_stream) {
+		if (hipEventRecord(c->ev_xs, c->last_stream) != hipSuccess || hipStreamWaitEvent(stream, c->ev_xs, 0) != hipSuccess) return -1;
+	}
+	c->last_stream = stream;
 	if (timed) (void)hipEventRecord(c->ev[0], stream);
-	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(PFB_NT), 0, stream, (const float2 *)iq_dev, c->d_hist[c->n_blocks & 1],
-	                   c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
+	if (c->pfb_form == 20)
+		hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(PFB_NT), 0, stream, (const float2 *)iq_dev, c->d_hist[c->n_blocks & 1],
+		                   c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
+	else
+		hipLaunchKernelGGL(sd_pfb8_kernel, dim3(c->n_steps / P8_S, c->n_streams), dim3(P8_NT), 0, stream, (const float2 *)iq_dev, n_samples,
+		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
 	c->n_blocks++;
 	if (timed) (void)hipEventRecord(c->ev[1], stream);
-	hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
+	hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M * c->n_streams), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
 	                   c->d_bins, c->n_steps, c->d_g, c->d_iqlast, c->d_dhist, c->d_out48);
 	if (timed) { (void)hipEventRecord(c->ev[2], stream); c->ev_pending = true; }
 	if (hipGetLastError() != hipSuccess) return -1;
@@ -406,8 +548,9 @@ extern "C" int sonde_chan_read(SondeChannelizer *c, float *bins /* [512][n_steps
 	if (!c) return -1;
 	if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
-	if (bins && hipMemcpy(bins, c->d_bins, (size_t)CH_M * c->n_steps * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-	if (out48 && hipMemcpy(out48, c->d_out48, (size_t)CH_M * n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	const size_t nb = (size_t)c->n_streams * CH_M;
+	if (bins && hipMemcpy(bins, c->d_bins, nb * c->n_steps * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if (out48 && hipMemcpy(out48, c->d_out48, nb * n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return 0;
 }
 

@@ -603,10 +603,12 @@ void SondeParser::feed_mrzn1(const SondeFrame &f, std::vector<SondeData> &out)
 }
 
 // SRS-C50 (README.md:17: GPS + temperature).  One value per 9-byte packet 00 FF <type> <value, 4 bytes big-endian> <c1> <c2>
-// ([RECALL]: the packet shape and the Fletcher sum are the public C34/C50 decoders'; the type numbers and scalings below
-// are this repo's -- the reference's are in the absent sondedump):
-//   0x03 air temperature (float32) | 0x10 sonde number | 0x14 latitude, 0x15 longitude (i32, 1e-6 deg) |
-//   0x16 altitude (i32, cm) | 0x17 UTC time as the decimal number hhmmss | 0x18 date as the decimal number ddmmyy
+// EXPERIMENTAL: [RECALL] the packet shape, the Fletcher sum and the type numbers (0x14 date, 0x15 time, 0x16 latitude,
+// 0x17 longitude, 0x18 altitude; 0x03 temperature, 0x10 sonde number) are the public C34/C50 decoders' as recalled; the value
+// SCALINGS are this repo's and unverified against a recorded sonde (the reference's are in the absent sondedump) -- the
+// generator shares them, so the round-trip tests cannot see a wrong scaling:
+//   0x03 air temperature (float32) | 0x10 sonde number | 0x14 date as the decimal number ddmmyy | 0x15 UTC time as the decimal
+//   number hhmmss | 0x16 latitude, 0x17 longitude (i32, 1e-6 deg) | 0x18 altitude (i32, cm; emits DATA_POS)
 void SondeParser::feed_c50(const SondeFrame &f, std::vector<SondeData> &out)
 {
 	if (f.len != 9 || f.nerr[0] != 0) return;
@@ -625,21 +627,21 @@ void SondeParser::feed_c50(const SondeFrame &f, std::vector<SondeData> &out)
 		sd.fields = DATA_SERIAL;
 		snprintf(sd.serial, sizeof(sd.serial), "C50-%u", (unsigned)v);
 		break;
-	case 0x14: m_c50_lat = (int32_t)v * 1e-6; m_c50_have |= 1; break;
-	case 0x15: m_c50_lon = (int32_t)v * 1e-6; m_c50_have |= 2; break;
-	case 0x16:
+	case 0x16: m_c50_lat = (int32_t)v * 1e-6; m_c50_have |= 1; break;
+	case 0x17: m_c50_lon = (int32_t)v * 1e-6; m_c50_have |= 2; break;
+	case 0x18:
 		if ((m_c50_have & 3) == 3) {
 			sd.fields = DATA_POS;
 			sd.lat = (float)m_c50_lat; sd.lon = (float)m_c50_lon; sd.alt = (float)((int32_t)v * 1e-2);
 		}
 		break;
-	case 0x17:
+	case 0x15:
 		if ((m_c50_have & 4) && v < 240000u && (v / 100) % 100 < 60 && v % 100 < 61) {
 			sd.fields = DATA_TIME;
 			sd.time = (time_t)(m_c50_date + (long long)(v / 10000) * 3600 + (long long)((v / 100) % 100) * 60 + (long long)(v % 100));
 		}
 		break;
-	case 0x18: {
+	case 0x14: {
 		const int day = (int)(v / 10000), mon = (int)((v / 100) % 100), yr = (int)(v % 100);
 		if (day >= 1 && day <= 31 && mon >= 1 && mon <= 12) { m_c50_date = days_from_civil(2000 + yr, mon, day) * 86400LL; m_c50_have |= 4; }
 		break;

@@ -58,8 +58,12 @@ class NativeShard:
             import ctypes as C
             import os
             from . import _lib as main
-            main.load()                                  # builds both libraries on a fresh checkout
-            L = C.CDLL(os.path.join(main.PKG_DIR, "libsonde_rccl.so"))
+            main.load()
+            path = os.path.join(main.PKG_DIR, "libsonde_rccl.so")
+            if not os.path.exists(path):                 # built on demand: only multi-GPU hosts need RCCL (csrc/Makefile `rccl`)
+                import subprocess
+                subprocess.check_call(["make", "-s", "-C", os.path.join(main.PKG_DIR, "csrc"), "rccl"])
+            L = C.CDLL(path)
             vp = C.c_void_p
             L.sonde_shard_unique_id.argtypes = [vp]
             L.sonde_shard_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]

@@ -1116,10 +1116,10 @@ def c50_build_packets(channel: int, k: int):
     """The seven packets of second k: id, date, time, latitude, longitude, altitude, temperature."""
     tod = (k + 45296) % 86400
     t32 = int(np.frombuffer(np.float32(c50_true_temp(channel, k)).tobytes(), dtype="<u4")[0])
-    return [c50_packet(0x10, 3000000 + channel), c50_packet(0x18, 150624),
-            c50_packet(0x17, (tod // 3600) * 10000 + ((tod // 60) % 60) * 100 + tod % 60),
-            c50_packet(0x14, int(round((47.0 + 1e-3 * channel) * 1e6))), c50_packet(0x15, int(round((8.0 + 1e-4 * k) * 1e6))),
-            c50_packet(0x16, int(round((1200.0 + 5.0 * k) * 100))), c50_packet(0x03, t32)]
+    return [c50_packet(0x10, 3000000 + channel), c50_packet(0x14, 150624),
+            c50_packet(0x15, (tod // 3600) * 10000 + ((tod // 60) % 60) * 100 + tod % 60),
+            c50_packet(0x16, int(round((47.0 + 1e-3 * channel) * 1e6))), c50_packet(0x17, int(round((8.0 + 1e-4 * k) * 1e6))),
+            c50_packet(0x18, int(round((1200.0 + 5.0 * k) * 100))), c50_packet(0x03, t32)]
 
 
 def c50_bitstreams(seed: int, channels: np.ndarray, nbits: int):

@@ -5,8 +5,13 @@
 //   ref_boundary_test link                 -- construct the seven blocks (no GPU needed): proves compile + link
 //   ref_boundary_test pump <f32 file> <n>  -- GPU: pump an RS41 discriminator stream through the REFERENCE's run()
 //                                             and through sonde::Decoder<> (include/sonde_decoder.hpp); print both
+//   ref_boundary_test physics              -- no GPU: the header's OWN static dewpt() / altitude_to_pressure()
+//                                             (decoder.hpp:132-174) over the ISA layer edges +- 1 ulp, 400 pseudo-random
+//                                             altitudes and a T / RH grid, printed as hex floats: the generator of
+//                                             tests/golden/physics_golden.json (tests/golden/make_physics_golden.py)
 #include <dsp/block.h>
 #include "decode/decoder.hpp"
+#include <cmath>
 #include <cstdio>
 #include <vector>
 #include "sonde_decoder.hpp"
@@ -43,6 +48,24 @@ int main(int argc, char **argv)
 		dsp::block *all[7] = { &rs41decoder, &dfm09decoder, &ims100decoder, &m10decoder, &imet4decoder, &c50decoder, &mrzn1decoder };
 		for (dsp::block *b : all) if (b->_block_init) return 1;
 		printf("LINK OK %zu\n", sizeof(all) / sizeof(*all));
+		return 0;
+	}
+	if (argc >= 2 && std::string(argv[1]) == "physics") {
+		// dewpt / altitude_to_pressure are statics of the reference's header: this calls the reference's own compiled bodies
+		const float edges[] = { 0.0f, 11000.0f, 20000.0f, 32000.0f, 47000.0f, 51000.0f, 77000.0f };
+		for (float e : edges)
+			for (float a : { std::nextafterf(e, -1e9f), e, std::nextafterf(e, 1e9f) }) printf("ALT %a %a\n", a, altitude_to_pressure(a));
+		uint32_t lcg = 0x5EED0003u;
+		for (int i = 0; i < 400; i++) {
+			lcg = lcg * 1664525u + 1013904223u;
+			const float a = -500.0f + 90500.0f * (float)(lcg >> 8) * (1.0f / 16777216.0f);
+			printf("ALT %a %a\n", a, altitude_to_pressure(a));
+		}
+		for (int ti = 0; ti <= 26; ti++)
+			for (int ri = 0; ri <= 20; ri++) {
+				const float t = -90.0f + 5.0f * (float)ti, rh = ri == 0 ? 0.5f : 5.0f * (float)ri;
+				printf("DEW %a %a %a\n", t, rh, dewpt(t, rh));
+			}
 		return 0;
 	}
 	if (argc < 4) return 2;

@@ -131,3 +131,59 @@ def test_hip_channelizer_two_blocks_per_submit_equals_oracle(oracle):
     act = got[np.lexsort((got["bitpos"], got["channel"]))]
     assert len(ref) >= len(bins_active) and act.tobytes() == ref.tobytes()
 
+
+
+@pytest.mark.gpu
+def test_hip_channelizer_three_streams_in_one_object(oracle, monkeypatch):
+    """sonde_chan_create_multi: S wideband streams per submit, one launch of every stage over all of them (grid.y = stream).
+    Stream s carries its own scene: bins, 48 kS/s rows and frames of stream s equal a single-stream object's for that scene
+    (which test_hip_channelizer_bit_exact_and_decodes ties to the oracle), channel = 512 s + bin; alternating the submit
+    stream exercises the front-end's own cross-stream ordering."""
+    import torch
+    from sdrpp_radiosonde_amd.batch import SondeChannelizer
+    S, NBLK = 3, 6
+    scenes = [synth.make_wideband_rs41([40 + 100 * s, 300 + s], NBLK * BLOCK, seed=30 + s, ebn0_db=33.0, device="cuda:0")[0] for s in range(S)]
+    multi = SondeChannelizer(n_streams=S)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    got, first = [], None
+    for b in range(NBLK):
+        blk = torch.stack([sc[b * BLOCK: (b + 1) * BLOCK] for sc in scenes]).contiguous()
+        torch.cuda.synchronize()
+        multi.submit(blk, streams[b & 1].cuda_stream)
+        if b == 0:
+            first = multi.read()
+        got.append(multi.frames())
+    got = np.concatenate(got)
+    for s in range(S):
+        one = SondeChannelizer()
+        ref = []
+        for b in range(NBLK):
+            one.submit(scenes[s][b * BLOCK: (b + 1) * BLOCK].contiguous())
+            if b == 0:
+                rb, ro = one.read()
+                assert first[0][512 * s: 512 * (s + 1)].tobytes() == rb.tobytes(), s
+                assert first[1][512 * s: 512 * (s + 1)].tobytes() == ro.tobytes(), s
+            ref.append(one.frames())
+        ref = np.concatenate(ref)
+        ref["channel"] += 512 * s
+        mine = got[(got["channel"] >= 512 * s) & (got["channel"] < 512 * (s + 1))]
+        key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+        assert len(ref) >= 1 and key(mine).tobytes() == key(ref).tobytes(), s
+
+
+@pytest.mark.gpu
+def test_pfb_forms_give_identical_bins(oracle, monkeypatch):
+    """The 8-step filter-bank kernel (two workgroups per CU, the default) and the round-2 20-step kernel (SONDE_PFB_FORM=20)
+    produce the same bins and rows, bit for bit."""
+    from sdrpp_radiosonde_amd.batch import SondeChannelizer
+    iq, _ = synth.make_wideband_rs41([77, 400], 2 * BLOCK, seed=41, ebn0_db=30.0, device="cuda:0")
+    outs = []
+    for form in ("8", "20"):
+        monkeypatch.setenv("SONDE_PFB_FORM", form)
+        chz = SondeChannelizer()
+        for b in range(2):
+            chz.submit(iq[b * BLOCK: (b + 1) * BLOCK].contiguous())
+        outs.append(chz.read())
+        chz.close()
+    assert outs[0][0].tobytes() == outs[1][0].tobytes() and outs[0][1].tobytes() == outs[1][1].tobytes()

@@ -271,3 +271,47 @@ def test_b3_iq_stream_decoder_vfo_rate_cpp(tmp_path, oracle, stype, rate, chunk)
     L.sonde_parser_destroy(h)
     assert len(cbs) == nfrag >= 3, (len(cbs), nfrag)
 
+
+
+def test_b3_type_switch_on_one_decoder_cpp(tmp_path, oracle):
+    """The reference's onTypeSelected (/root/reference/src/main.cpp:366-405): stop the active decoder, new VFO bandwidth,
+    resampler.setInSamplerate(bw), start another decoder.  Here: ONE sonde::IqStreamDecoder, RS41 at 10 kS/s, then re-initialised
+    for M10 at 50 kS/s: the callbacks of each stream are the oracle chain's fragments for that type; the aggregate starts
+    empty after the switch (lastData.init(), main.cpp:376)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "iq_stream_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "iq_stream_test.cpp"), "-o", exe,
+                           "-L", libdir, "-l:libsonde_mi355.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    paths, want = [], []
+    L = _lib.load()
+    for stype, rate in ((0, 10000), (3, 50000)):
+        up, down = {10000: (24, 5), 50000: (24, 25)}[rate]
+        n_in = 6144 * 40 * down // up
+        sb = synth.make_batch(stype, 1, n_in, seed=191 + stype, ebn0_db=24.0, fs=float(rate), cfo_max_hz=300.0)
+        x = sb.iq.numpy()[0]
+        path = str(tmp_path / f"iq{stype}.bin")
+        x.tofile(path)
+        paths.append((path, stype, rate))
+        gran = 6144 * down // up
+        vo, ch = oracle.Vfo(rate), oracle.Channel(stype, 0)
+        ch.feed(vo.process(x[:(n_in // gran) * gran]), is_iq=False)
+        h = L.sonde_parser_create(stype)
+        o = (_lib.SondeData * 8)()
+        nfrag = 0
+        for f in ch.frames():
+            fr = _lib.SondeFrame.from_buffer_copy(f.tobytes())
+            nfrag += L.sonde_parser_feed(h, C.byref(fr), o, 8)
+        L.sonde_parser_destroy(h)
+        want.append(nfrag)
+    (pa, ta, ra), (pb, tb, rb) = paths
+    out = subprocess.check_output([exe, pa, str(ta), "1000", str(ra), pb, str(tb), str(rb)], text=True)
+    assert "ERROR" not in out, out[-1500:]
+    first, second = out.split("SWITCH")
+    cbs = [[l for l in part.splitlines() if l.startswith("CB ")] for part in (first, second)]
+    assert [len(c) for c in cbs] == want and min(want) >= 3, ([len(c) for c in cbs], want)
+    assert "serial=S" in cbs[0][-1]                      # RS41 serial numbers of the generator
+    assert "serial=S" not in cbs[1][0]                   # nothing of the RS41 aggregate survives the switch

@@ -202,6 +202,35 @@ def test_poll_returns_the_fragments_of_every_channel(oracle):
     assert kinds.get(_lib.DATA_TIME, 0) == kinds[_lib.DATA_SEQ | _lib.DATA_SERIAL] == kinds[_lib.DATA_POS | _lib.DATA_SPEED]
 
 
+def test_poll_covers_every_submit_queued_since_the_last_poll(oracle):
+    """A pipelined host queues submit t + 1 before it polls: sonde_batch_poll parses every unpolled submit that is still
+    resident, in order (the per-channel parsers are stateful: a skipped submit would also break later fragments); a third
+    unpolled submit overwrites the first one's frame slots, which is an error, not a silent gap."""
+    from sdrpp_radiosonde_amd.batch import SondeError
+    C_, n, parts = 4, TILE * 96, 4
+    sb = synth.make_rs41_batch(C_, n, seed=78, ebn0_db=30.0)
+    chunks = [_dev(sb.iq[:, p * (n // parts): (p + 1) * (n // parts)].contiguous()) for p in range(parts)]
+    key = lambda fr: [(c, d.fields, d.seq, d.time, d.lat, d.temp) for c, d in fr]
+    seq = SondeBatch(C_, n // parts)
+    want = []
+    for ch in chunks:
+        seq.submit(ch)
+        want += seq.poll()
+    b = SondeBatch(C_, n // parts)
+    got = []
+    for i in (0, 2):
+        b.submit(chunks[i])
+        b.submit(chunks[i + 1])            # queued before the poll
+        got += b.poll()
+    assert len(want) >= 8 * C_ and key(got) == key(want)
+    c3 = SondeBatch(C_, n // parts)
+    for ch in chunks[:3]:
+        c3.submit(ch)
+    with pytest.raises(SondeError, match="overwritten"):
+        c3.poll()
+    assert len(c3.poll()) > 0              # the two resident submits are still delivered
+
+
 def test_random_finite_garbage_matches_oracle(oracle):
     """The arithmetic contract holds for any finite input whose products stay finite (|I|, |Q| < 1e18; NaN/Inf and
     overflowing magnitudes are outside it): samples with log-uniform magnitudes over 36 decades, random

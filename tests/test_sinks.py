@@ -22,6 +22,13 @@ def test_sinks_equal_committed_reference_output():
     assert gold["gpx"][-1].count("<trkpt") == 5 and gold["gpx"][-1].endswith("</trkseg>\n</trk>\n</gpx>\n")
 
 
+@pytest.mark.gpu
+def test_sinks_equal_committed_reference_output_on_the_gpu_box():
+    """The same check inside the driver's `-m gpu` run: the one row pinned to the reference's own compiled code (the fixture
+    is the output of /root/reference/src/gpx.cpp + ptu.cpp, tests/make_sinks_golden.py) is then part of GPUTEST_rNN."""
+    test_sinks_equal_committed_reference_output()
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/src/gpx.cpp"), reason="needs the mounted reference")
 def test_sinks_equal_live_reference():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
