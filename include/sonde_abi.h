@@ -232,6 +232,11 @@ int         sonde_chan_create(const uint8_t *types /* 512 entries or NULL = RS41
  * [n_streams][n_samples] complex64; channel s * 512 + k of sonde_chan_batch() is bin k of stream s. */
 int         sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out);
 uint32_t    sonde_chan_streams(const SondeChannelizer *c);
+/* By default (where every bin's sonde type allows it: no AFSK sonde) the per-bin discriminator and the 6/5 resampler run in
+ * the decoder kernel's load path: a submit is two launches and the 48 kS/s rows never exist in HBM.  on = 0 keeps them as a
+ * kernel of their own (then sonde_chan_read can return the rows: parity tests).  Call before the first submit; returns the mode
+ * in force (1 fused, 0 not). */
+int         sonde_chan_set_fused(SondeChannelizer *c, int on);
 void        sonde_chan_destroy(SondeChannelizer *c);
 uint32_t    sonde_chan_samples_per_submit(const SondeChannelizer *c);
 int         sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t n_samples, void *stream);

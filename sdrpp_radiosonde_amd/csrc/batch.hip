@@ -471,6 +471,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	return 0;
 }
 
+static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_, const SdBinsIn *bins_in);
+
 extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_)
 {
 	if (!b || !samples) return fail("sonde_batch_submit: null argument");
@@ -479,6 +481,34 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	// the kernels read 16 bytes per lane: every channel row must start on a 16-byte boundary
 	if (((uintptr_t)samples & 15u) || channel_stride % (b->input_kind == SONDE_INPUT_IQ ? 2 : 4))
 		return fail("sonde_batch_submit: samples must be 16-byte aligned and channel_stride a multiple of 2 (IQ) / 4 (real) samples");
+	return submit_impl(b, samples, n_samples, channel_stride, stream_, nullptr);
+}
+
+// The channelizer's decoder batch (created with SONDE_INPUT_REAL) takes its rows as 40 kS/s complex bins instead: n_steps bin
+// samples per channel (a multiple of 5120 = 3 tiles of 48 kS/s output), the per-bin discriminator and the 6/5 resampler run
+// in the demod kernel's load path (SPEC 3.5).  Internal to the library (channelizer.hip).
+int sd_batch_bins_capable(const SondeBatch *b)
+{
+	if (!b || b->input_kind != SONDE_INPUT_REAL) return 0;
+	for (int t = 0; t < SONDE_NTYPES; t++) {
+		if (b->chlist[t].empty()) continue;
+		if (t == SONDE_IMET4 || t == SONDE_C50) return 0;                     // the tone demodulator wants 48 kS/s rows
+		const int k = modem_class(b->md, t);
+		if (!(k_cls_nt[k] == 8 && (k_cls_decim[k] == 4 || k_cls_decim[k] == 2))) return 0;
+	}
+	return 1;
+}
+int sd_batch_submit_bins(SondeBatch *b, const void *bins, size_t n_steps, size_t channel_stride, const SdBinsIn *d_bins_in, void *stream_)
+{
+	if (!b || !bins || !d_bins_in || !sd_batch_bins_capable(b)) return fail("sd_batch_submit_bins: bad argument");
+	const size_t n_out = n_steps / 5 * 6;
+	if (n_steps == 0 || n_steps % 5120 || n_out > b->max_samples || channel_stride < n_steps || ((uintptr_t)bins & 7u))
+		return fail("sd_batch_submit_bins: n_steps must be a multiple of 5120 within max_samples");
+	return submit_impl(b, bins, n_out, channel_stride, stream_, d_bins_in);
+}
+
+static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_, const SdBinsIn *bins_in)
+{
 	HIPCHK(hipSetDevice(b->device));
 	hipStream_t stream = (hipStream_t)stream_;
 	const int n_tiles = (int)(n_samples / SONDE_TILE);
@@ -487,7 +517,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	if (timed) HIPCHK(hipEventRecord(ev[0], stream));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size() + b->chlist[SONDE_C50].size();
-	const bool iq = b->input_kind == SONDE_INPUT_IQ;
+	const int iq = bins_in ? SD_IN_BINS : (b->input_kind == SONDE_INPUT_IQ ? SD_IN_IQ : SD_IN_REAL);      // what the rows hold
 	const int slot = (int)(b->tickets & 1);
 	SondeFrame *const d_frames = b->d_frames2[slot];
 	uint32_t *const d_counts = b->d_counts2[slot];
@@ -527,7 +557,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	const bool one_launch = !n_afsk && b->n_classes == 1;
 	if (one_launch) {
 		sd_launch_demod(iq, k_cls_decim[b->only_class], k_cls_nt[b->only_class], b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
-			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo);
+			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, bins_in);
 		HIPCHK(hipGetLastError());
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
 		for (int t = 0; t < SONDE_NTYPES; t++) if (launch_framers(t, stream)) return -1;
@@ -546,14 +576,14 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 				// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows
 				// (one kernel-A tile = 2048 scratch samples = 16384 input samples)
 				float *rows = b->d_afq + u.row0 * (size_t)(b->max_samples / SD_AF_DEC);
-				sd_launch_afsk(u.type, iq, u.n, u.st, (const float *)samples, channel_stride, n_tiles,
+				sd_launch_afsk(u.type, iq == SD_IN_IQ, u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_chlist[u.type], b->d_astates, u.type == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
-				sd_launch_demod(false, 1, 16, u.n, u.st, rows, nq, (int)(nq / SONDE_TILE),
+				sd_launch_demod(SD_IN_REAL, 1, 16, u.n, u.st, rows, nq, (int)(nq / SONDE_TILE),
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo);
 			} else {
 				sd_launch_demod(iq, k_cls_decim[u.cls], k_cls_nt[u.cls], u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems,
-					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo);
+					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo, bins_in);
 			}
 			HIPCHK(hipGetLastError());
 			if (timed) HIPCHK(hipEventRecord(ec[1], u.st));

@@ -14,6 +14,7 @@
 #include "sd_math.h"
 #include "sonde_dev.h"
 #include "../../include/sonde_abi.h"
+#include "launch.h"
 
 #define CH_M 512
 #define CH_D 250
@@ -364,6 +365,8 @@ extern "C" const char *sonde_last_error(void);
 struct SondeChannelizer {
 	int device = 0;
 	uint32_t n_steps = 0, n_streams = 1;
+	bool fused = false;                    // the decoder kernel takes the bins themselves (discriminator + resampler in its load path): two launches per submit
+	SdBinsIn *d_bins_in = nullptr;
 	int pfb_form = 8;                      // steps per filter-bank workgroup: 8 (two workgroups per CU) or 20 (SONDE_PFB_FORM=20: the round-2 kernel, one stream)
 	hipStream_t last_stream = nullptr;     // a submit on another stream waits for the previous one (the state is carried)
 	hipEvent_t ev_xs = nullptr;
@@ -427,7 +430,7 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 	for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->ev_xs) (void)hipEventDestroy(c->ev_xs);
 	(void)hipFree(c->d_hist[0]); (void)hipFree(c->d_hist[1]); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_iqlast);
-	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48);
+	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48); (void)hipFree(c->d_bins_in);
 	delete c;
 }
 
@@ -468,6 +471,12 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 	     hipMemcpy(c->d_g, g.data(), RS_UP * RS_TAPS * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
 	for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence) == hipSuccess;     // timing only, same device
 	ok = ok && hipEventCreateWithFlags(&c->ev_xs, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+	if (ok) {
+		const SdBinsIn bi = { c->d_g, reinterpret_cast<float *>(c->d_iqlast), c->d_dhist };
+		ok = hipMalloc((void **)&c->d_bins_in, sizeof(bi)) == hipSuccess && hipMemcpy(c->d_bins_in, &bi, sizeof(bi), hipMemcpyHostToDevice) == hipSuccess;
+		// fused unless a bin's sonde type needs 48 kS/s rows (AFSK) or the host asks for the rows (sonde_chan_set_fused, SONDE_CHAN_UNFUSED)
+		c->fused = sd_batch_bins_capable(c->batch) && !getenv("SONDE_CHAN_UNFUSED");
+	}
 	if (!ok) { sonde_chan_destroy(c); return -1; }
 	*out = c;
 	return 0;
@@ -478,6 +487,15 @@ extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submi
 	return sonde_chan_create_multi(types, blocks_per_submit, 1, device, out);
 }
 extern "C" uint32_t sonde_chan_streams(const SondeChannelizer *c) { return c ? c->n_streams : 0; }
+// on = 0: keep the per-bin discriminator + resampler as a kernel of its own, so that the 48 kS/s rows exist (sonde_chan_read;
+// parity tests); on = 1 (the default where every bin's sonde type allows it): they run inside the decoder kernel.  Before the
+// first submit only.  Returns the mode in force.
+extern "C" int sonde_chan_set_fused(SondeChannelizer *c, int on)
+{
+	if (!c) return -1;
+	if (c->n_blocks == 0) c->fused = on && sd_batch_bins_capable(c->batch);
+	return c->fused ? 1 : 0;
+}
 
 extern "C" uint32_t sonde_chan_samples_per_submit(const SondeChannelizer *c) { return c ? c->n_steps * CH_D : 0; }
 extern "C" SondeBatch *sonde_chan_batch(SondeChannelizer *c) { return c ? c->batch : nullptr; }
@@ -513,10 +531,12 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
 	c->n_blocks++;
 	if (timed) (void)hipEventRecord(c->ev[1], stream);
-	hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M * c->n_streams), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
-	                   c->d_bins, c->n_steps, c->d_g, c->d_iqlast, c->d_dhist, c->d_out48);
+	if (!c->fused)
+		hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M * c->n_streams), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
+		                   c->d_bins, c->n_steps, c->d_g, c->d_iqlast, c->d_dhist, c->d_out48);
 	if (timed) { (void)hipEventRecord(c->ev[2], stream); c->ev_pending = true; }
 	if (hipGetLastError() != hipSuccess) return -1;
+	if (c->fused) return sd_batch_submit_bins(c->batch, c->d_bins, c->n_steps, c->n_steps, c->d_bins_in, stream_);
 	return sonde_batch_submit(c->batch, c->d_out48, n_out, n_out, stream_);
 }
 
@@ -550,6 +570,7 @@ extern "C" int sonde_chan_read(SondeChannelizer *c, float *bins /* [512][n_steps
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
 	const size_t nb = (size_t)c->n_streams * CH_M;
 	if (bins && hipMemcpy(bins, c->d_bins, nb * c->n_steps * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if (out48 && c->fused) return -1;      // the rows are never materialised in fused mode: sonde_chan_set_fused(c, 0) before the first submit
 	if (out48 && hipMemcpy(out48, c->d_out48, nb * n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return 0;
 }

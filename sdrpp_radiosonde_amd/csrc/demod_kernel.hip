@@ -66,6 +66,8 @@ struct DemodLds {
 	// what the lead round wave (wave 0) computes once per round and the other round waves pick up:
 	// the PI loop filter runs on one wave instead of four (it is ~35 % of a round wave's VALU work)
 	struct { long long t_next; int period; float bias; int K; unsigned flag; unsigned long long wpos; } pub;
+	alignas(16) float rs_g[96];                         // SD_IN_BINS: the 6 x 16 taps of the 6/5 resampler; rs_dh: the 16 carried discriminator samples
+	float rs_dh[16];
 	uint32_t mirror[SD_MIRROR_WORDS];       // the newest 2048 bits of the bit ring, for the in-kernel sync search (K4)
 	SdSyncRun k4;                           // K4's state between steps (wave 3 only)
 };
@@ -128,14 +130,22 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 // factor and the taps per filter row of every channel of this launch (the host launches once per class), so that the
 // discriminator and FIR variants do not share one register allocation.  Classes in use: (4, 8) RS41 / DFM / iMS-100 / MRZ-N1,
 // (2, 8) M10, (2, 16) and (1, 16) the same two groups under SONDE_FLAG_WIDE, (1, 16) also the 6 kS/s AFSK streams.
-template <bool IS_IQ, bool LIST, int DEC, int NT>
-__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
+// IN: what `in` holds per channel: SD_IN_REAL 48 kS/s discriminator samples, SD_IN_IQ 48 kS/s complex samples, SD_IN_BINS
+// 40 kS/s complex samples of a channelizer bin (the per-bin FM discriminator and the 6/5 resampler of SPEC 3.5 then run in
+// this kernel's load path: the 48 kS/s rows are never written to HBM).
+template <int IN, bool LIST, int DEC, int NT>
+#ifndef SD_BINS_WAVES
+#define SD_BINS_WAVES 6      // waves per SIMD of the SD_IN_BINS instantiations (<= 80 VGPRs, three workgroups per CU): at 8 (64 VGPRs) the tile
+                             // prefetch spills to scratch; 4096 bins x 3 tiles: 113 us at 4, 93 at 6 (profiles/r3_notes.md)
+#endif
+__global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
-	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo)
+	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, const SdBinsIn *__restrict__ bins_in)
 {
+	constexpr bool IS_IQ = IN == SD_IN_IQ, BINS = IN == SD_IN_BINS;
 	__shared__ __attribute__((aligned(16))) DemodLds s;
 #ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: a workgroup's life: entry, first round, end of the tile loop
 	__shared__ unsigned long long s_life[3];
@@ -168,9 +178,31 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			v[r] = make_float4(q.x, q.y, q.z, q.w);
 		}
 	};
+	// SD_IN_BINS: wave kw produces the outputs j in [J0, J0 + 512), J0 = 2048 tile + 512 kw (block-relative, SPEC 3.5:
+	// o[j] = sum_t g[5j mod 6][t] d[floor(5j/6) - t]); it needs d[ilo .. ilo + 442], ilo = floor(5 J0 / 6) - 15, i.e. the bin samples
+	// x[ilo - 1 ..]: 7 eight-byte loads per lane, element e = lane + 64 q <-> x[ilo - 1 + e]
+	constexpr int NB2 = 7;
+	float2 wa[NB2], wb[NB2];
+	const int bins_n = BINS ? (n_tiles / 3) * 5120 : 0;                       // samples per bin in this submit (3 tiles = 6144 outputs = 5120 inputs)
+	auto bins_ilo = [&](int tile) { return (int)((5u * (2048u * (uint32_t)tile + 512u * (uint32_t)kw)) / 6u) - 15; };
+	auto load_bins = [&](int tile, float2 (&w)[NB2]) {
+		const float2 *x = reinterpret_cast<const float2 *>(in) + (size_t)row * ch_stride;
+		const int base = bins_ilo(tile) - 1 + lane;
+#pragma unroll
+		for (int q = 0; q < NB2; q++) {
+			int i = base + 64 * q;
+			i = i < 0 ? 0 : (i >= bins_n ? bins_n - 1 : i);                       // elements outside the block are never used (or patched, tile 0)
+			w[q] = x[i];
+		}
+	};
 	if (is_k) {
-		load_vec(0, va);
-		if (n_tiles > 1) load_vec(1, vb);
+		if (BINS) {
+			load_bins(0, wa);
+			if (n_tiles > 1) load_bins(1, wb);
+		} else {
+			load_vec(0, va);
+			if (n_tiles > 1) load_vec(1, vb);
+		}
 	}
 
 	SdChanState st = states[ch];
@@ -328,6 +360,108 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (IS_IQ) last_iq = make_float2(cx, cy);      // wave 7: the last (decimated) sample of the tile
 	};
 
+	// SD_IN_BINS: discriminator at 40 kS/s into a wave-private LDS scratch, then the 6/5 polyphase resampler evaluated where
+	// the decimated samples of this wave need it, the boxcar average of the real-input path (SPEC 3.0), straight into buffer b.
+	// Scratch: the part of a tile buffer a decimated tile never uses (DEC 4: 580 of 2116 floats, DEC 2: 1092), one buffer per wave.
+	// plus a 512-float staging row for the resampler's outputs.  Wave 3 of a 4:1 instantiation shares B[1] with the FEC tables
+	// (at 1100): its scratch sits at B[1][600..1048), its staging row in A[0][584..1096).
+	float *const bscr = !BINS ? nullptr : (kw == 0 ? &s.A[0][1100] : kw == 1 ? &s.A[1][1100] : kw == 2 ? &s.B[0][1100] : &s.B[1][DEC == 4 ? 600 : 1100]);
+	float *const bstg = !BINS ? nullptr : (kw == 0 ? &s.A[0][1548] : kw == 1 ? &s.A[1][1548] : kw == 2 ? &s.B[0][1548] : (DEC == 4 ? &s.A[0][584] : &s.B[1][1548]));
+	static_assert(!BINS || DEC == 4 || DEC == 2, "the bins path needs the free part of a decimated tile buffer");
+	static_assert(SD_LH + SD_TILE / 2 + 4 <= 1100 && 1100 + 64 * NB2 <= 1548 && 1548 + 512 <= SD_BUF && 600 + 64 * NB2 <= SD_EPI_TAB_OFF &&
+	              SD_LH + SD_TILE / 4 + 4 <= 584 && 584 + 512 <= 1100 && (1548 % 4) == 0 && (584 % 4) == 0, "scratch and staging regions");
+	float2 bins_last = make_float2(0.0f, 0.0f);
+	if (BINS && is_k) {
+		// the resampler's taps: every discriminator wave writes the same 96 values (identical stores may race), then reads them
+		// behind its own stores; the first wave of the block also needs the carried history
+		const float gv0 = bins_in->g[lane], gv1 = lane < 32 ? bins_in->g[64 + lane] : 0.0f;
+		s.rs_g[lane] = gv0;
+		if (lane < 32) s.rs_g[64 + lane] = gv1;
+		if (kw == 0) {
+			if (lane < 16) s.rs_dh[lane] = bins_in->dhist[(size_t)ch * 16 + lane];
+			bins_last = reinterpret_cast<const float2 *>(bins_in->iq_last)[ch];
+		}
+	}
+	auto k1_bins = [&](int b, int tile, const float2 (&w)[NB2]) {
+		const int ilo = bins_ilo(tile);
+		const bool first = tile == 0 && kw == 0;                 // wave-uniform: the block's first wave (ilo = -15)
+		float cx = 0.0f, cy = 0.0f;
+#pragma unroll
+		for (int q = 0; q < NB2; q++) {
+			float px = __shfl_up(w[q].x, 1, 64), py = __shfl_up(w[q].y, 1, 64);
+			if (lane == 0) { px = cx; py = cy; }
+			if (q == 0 && first && lane == 16) { px = bins_last.x; py = bins_last.y; }      // element 16 is x[0]: its predecessor is carried
+			float d = sd_disc(w[q].x, w[q].y, px, py);
+			if (q == 0 && first && lane < 16) d = s.rs_dh[lane];                             // elements 1..15 are d[-15..-1]: carried
+			bscr[lane + 64 * q] = d;
+			cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[q].x), 63));
+			cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[q].y), 63));
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// The resampler: lane <-> m computes the six outputs j = 6 m + c, c = 0..5: tap row p_c = 5c mod 6 (the same for every
+		// lane: broadcast LDS reads) against d[5 m + floor(5c/6) - t], i.e. 20 consecutive d's per lane, read from LDS once (lanes 5 floats
+		// apart: conflict-free) and indexed statically.  (One lane per output with 32 lane-dependent LDS reads each -- and a
+		// phase-major variant with 16 -- were LDS-bound: 110-118 us for 4096 bins x 3 tiles against 56 + 58 us for the two kernels
+		// this replaces; profiles/r3_notes.md.)  The outputs pass through a wave-private staging row so that the
+		// boxcar average of the real-input path (SPEC 3.0) finds its DEC consecutive outputs in one aligned read.
+		constexpr int PER_WAVE = SD_TILE / DEC / 4;              // decimated samples a wave produces per tile: 128 (4:1) or 256 (2:1)
+		const uint32_t J0 = 2048u * (uint32_t)tile + 512u * (uint32_t)kw;
+		const uint32_t m_lo = J0 / 6u;
+#pragma unroll 1
+		for (int a = 0; a < 2; a++) {
+			uint32_t m = m_lo + (uint32_t)lane + 64u * a;
+			if (6u * m >= J0 + 512u) m = m_lo;                                   // no output of this wave: stay inside the scratch
+			// the six outputs of this m read d[5m - 15 .. 5m + 4]: 20 LDS reads per lane instead of 96
+			const float *dp = &bscr[(int)(5u * m) - 15 - (ilo - 1)];
+			float dv[20];
+#pragma unroll
+			for (int k = 0; k < 20; k++) dv[k] = dp[k];
+#pragma unroll
+			for (int c = 0; c < 6; c++) {
+				const int pc = (5 * c) % 6, fc = (5 * c) / 6;
+				// the tap row from LDS, one address for the whole wave, read OUTSIDE the divergent part (as global loads the
+				// compiler put them behind vmcnt(0) inside it: a memory round trip per phase that also drained the tile prefetch)
+				float gt[16];
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const float4 g4 = *reinterpret_cast<const float4 *>(&s.rs_g[16 * pc + 4 * q]);
+					gt[4 * q] = g4.x; gt[4 * q + 1] = g4.y; gt[4 * q + 2] = g4.z; gt[4 * q + 3] = g4.w;
+				}
+				float acc = 0.0f;
+#pragma unroll
+				for (int t = 0; t < 16; t++) acc = __builtin_fmaf(gt[t], dv[15 + fc - t], acc);
+				const uint32_t jr = 6u * m + (uint32_t)c - J0;                   // output index inside the wave's span (wraps below J0)
+				if (jr < 512u) bstg[jr] = acc;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int h = 0; h < PER_WAVE / 64; h++) {
+			const uint32_t n = (uint32_t)lane + 64u * h;
+			float z;
+			if (DEC == 4) {
+				const float4 o = *reinterpret_cast<const float4 *>(&bstg[4u * n]);
+				z = ((o.x + o.y) + (o.z + o.w)) * 0.25f;
+			} else {
+				const float2 o = *reinterpret_cast<const float2 *>(&bstg[2u * n]);
+				z = (o.x + o.y) * 0.5f;
+			}
+			store_one(s, b, (uint32_t)PER_WAVE * (uint32_t)kw + n, z);
+		}
+		if (tile == n_tiles - 1 && kw == 3) {
+			// the block's last wave: carry the last 16 discriminator samples and the last bin sample to the next submit
+			// (read by the first wave at the top of the next launch; every barrier of this launch lies in between)
+			// for this wave J0 = n_out - 512, so ilo = bins_n - 442: x[bins_n - 1] is element 442 (lane 58 of load 6), d[bins_n - 16] element 427
+			constexpr int E_LAST = 442;
+			if (lane < 16) bins_in->dhist[(size_t)ch * 16 + lane] = bscr[E_LAST - 15 + lane];
+			if (lane == (E_LAST & 63)) reinterpret_cast<float2 *>(bins_in->iq_last)[ch] = w[E_LAST >> 6];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();                         // the next k1 of this wave rewrites the scratch
+	};
+
 	// ================================================================ round role (waves 0-3)
 	const bool lead = rwave == 0;          // wave 0 owns the loop filter, the bit ring and the state
 	unsigned seq = 0;                      // round counter; its parity selects the red/chunk/partial slots
@@ -463,10 +597,17 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		}
 	};
 	if (is_k) {
-		load_prev(0, pa, qa);              // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
-		if (n_tiles > 1) load_prev(1, pb, qb);
-		k1_tile(0, va, pa, qa);
-		if (n_tiles > 2) load_tile(2, va, pa, qa);
+		// register set A holds the even tiles, set B the odd ones (the arguments are literals at every call: static register sets)
+		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, va, pa, qa); };
+		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wb); else k1_tile(b, vb, pb, qb); };
+		auto ldA = [&](int tile) { if constexpr (BINS) load_bins(tile, wa); else load_tile(tile, va, pa, qa); };
+		auto ldB = [&](int tile) { if constexpr (BINS) load_bins(tile, wb); else load_tile(tile, vb, pb, qb); };
+		if (!BINS) {
+			load_prev(0, pa, qa);          // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
+			if (n_tiles > 1) load_prev(1, pb, qb);
+		}
+		k1A(0, 0);
+		if (n_tiles > 2) ldA(2);
 		__syncthreads();
 		// phase `tile`: tile+1 goes from registers into the other LDS buffer, tile+3 is requested from HBM
 		// (two phases of latency budget); the loop is unrolled by two so the register sets are static
@@ -474,16 +615,16 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			if (tile + 1 < n_tiles) {
 				if (t < SD_LH) s.A[1][t] = s.A[0][IT + t];            // history roll into the other buffer
 				else if (t < 2 * SD_LH - 1) s.B[1][t - SD_LH] = s.B[0][IT + t - SD_LH];
-				k1_tile(1, vb, pb, qb);
-				if (tile + 3 < n_tiles) load_tile(tile + 3, vb, pb, qb);
+				k1B(1, tile + 1);
+				if (tile + 3 < n_tiles) ldB(tile + 3);
 			}
 			for (int r = 0; r < rounds; r++) __syncthreads();
 			if (tile + 1 >= n_tiles) break;
 			if (tile + 2 < n_tiles) {
 				if (t < SD_LH) s.A[0][t] = s.A[1][IT + t];
 				else if (t < 2 * SD_LH - 1) s.B[0][t - SD_LH] = s.B[1][IT + t - SD_LH];
-				k1_tile(0, va, pa, qa);
-				if (tile + 4 < n_tiles) load_tile(tile + 4, va, pa, qa);
+				k1A(0, tile + 2);
+				if (tile + 4 < n_tiles) ldA(tile + 4);
 			}
 			for (int r = 0; r < rounds; r++) __syncthreads();
 		}
@@ -598,23 +739,30 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	}
 }
 
-void sd_launch_demod(bool is_iq, int decim, int nt, uint32_t n_channels, hipStream_t stream,
+void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */)
+	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */, const SdBinsIn *bins_in /* device memory; SD_IN_BINS only */)
 {
 	const dim3 g(n_channels), blk(SD_WGT);
 	const int ci = compact_in ? 1 : 0;
-#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo
-#define SD_DEMOD_LAUNCH(IQ, LS) do { \
-		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
-		else if (decim == 2 && nt == 8) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
-		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 2, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); \
-		else hipLaunchKernelGGL((sd_demod_kernel<IQ, LS, 1, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); } while (0)
-	if (is_iq && !chlist) SD_DEMOD_LAUNCH(true, false);
-	else if (is_iq) SD_DEMOD_LAUNCH(true, true);
-	else if (!chlist) SD_DEMOD_LAUNCH(false, false);
-	else SD_DEMOD_LAUNCH(false, true);
+#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo, bins_in
+#define SD_DEMOD_LAUNCH(KIND, LS) do { \
+		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
+		else if (decim == 2 && nt == 8) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
+		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 2, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); \
+		else hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 1, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); } while (0)
+	if (in_kind == SD_IN_BINS) {
+		// channelizer bins: real-input classes only (the wide flag does not apply behind the discriminator): (4, 8) and (2, 8)
+		if (decim == 4 && !chlist) hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, false, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
+		else if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, true, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
+		else if (!chlist) hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, false, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
+		else hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, true, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
+	}
+	else if (in_kind == SD_IN_IQ && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ, false);
+	else if (in_kind == SD_IN_IQ) SD_DEMOD_LAUNCH(SD_IN_IQ, true);
+	else if (!chlist) SD_DEMOD_LAUNCH(SD_IN_REAL, false);
+	else SD_DEMOD_LAUNCH(SD_IN_REAL, true);
 #undef SD_DEMOD_LAUNCH
 #undef SD_DEMOD_ARGS
 }

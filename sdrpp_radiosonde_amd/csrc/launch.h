@@ -16,10 +16,16 @@ struct SdFramerOut {
 	const uint8_t *gf64;                    // GF(2^6) tables of the iMS-100 BCH decoder
 	SondeFrame *frames;
 };
-void sd_launch_demod(bool is_iq, int decim, int nt, uint32_t n_channels, hipStream_t stream,
+// in_kind: SD_IN_REAL / SD_IN_IQ (48 kS/s rows) or SD_IN_BINS (40 kS/s complex channelizer bins: the kernel runs the per-bin
+// discriminator and the 6/5 resampler in its load path; bins_in: taps and carried state, device memory)
+void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */);
+	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */,
+	const SdBinsIn *bins_in = nullptr);
+// the batch object behind a channelizer takes its input as bins (channelizer.hip): 3 tiles per 5120 bin samples
+int sd_batch_submit_bins(SondeBatch *b, const void *bins, size_t n_steps, size_t channel_stride, const SdBinsIn *d_bins_in, void *stream);
+int sd_batch_bins_capable(const SondeBatch *b);      // 1: every channel's class has a bins instantiation (no AFSK sonde, no class without one)
 
 void sd_launch_afsk(int type /* SONDE_IMET4 or SONDE_C50 */, bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
 	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride);

@@ -21,6 +21,16 @@
 #define SD_MARGIN     4           // look-ahead slack (samples) behind the newest sample, SPEC 3.2
 #define SD_WG         256
 
+// what the demod kernel's input rows hold
+#define SD_IN_REAL 0        // 48 kS/s FM-discriminator samples (float)
+#define SD_IN_IQ   1        // 48 kS/s complex samples
+#define SD_IN_BINS 2        // 40 kS/s complex samples of a channelizer bin: discriminator + 6/5 resampler in the kernel (SPEC 3.5)
+struct SdBinsIn {           // SD_IN_BINS: resampler taps and the state carried from block to block (device pointers)
+	const float *g;         // [6][16]
+	float       *iq_last;   // per channel [2]: the last bin sample (re, im) of the previous block
+	float       *dhist;     // per channel: the last 16 discriminator samples of the previous block, oldest first
+};
+
 struct SdModem {            // per sonde type, built on the host
 	int32_t period0;        // Q16 internal-rate samples per symbol
 	float   kp;             // proportional gain, Q16 samples per unit error

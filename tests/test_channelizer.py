@@ -54,11 +54,11 @@ def test_channelizer_isolates_a_tone(oracle):
     assert np.allclose(out48[k, 500:], 4 * df / 40000, atol=2e-3)      # atan2q: |error| <= 2.5e-3 rad = 1.6e-3 quadrant (SPEC 3.1)
 
 
-def _oracle_decode_wideband(oracle, iq_np, bins_active):
+def _oracle_decode_wideband(oracle, iq_np, bins_active, types=None):
     L = oracle.lib()
     nblk = iq_np.shape[0] // BLOCK
     ch = L.or_chan_new()
-    dec = {k: oracle.Channel(0, k) for k in bins_active}
+    dec = {k: oracle.Channel(int(types[k]) if types is not None else 0, k) for k in bins_active}
     out48 = np.zeros((512, STEPS * 6 // 5), dtype=np.float32)
     first = None
     for b in range(nblk):
@@ -90,8 +90,8 @@ def test_hip_channelizer_bit_exact_and_decodes(oracle):
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
     bins_active = [5, 100, 333, 511]
     iq, truth = synth.make_wideband_rs41(bins_active, 10 * BLOCK, seed=8, ebn0_db=33.0, device="cuda:0")
-    chz = SondeChannelizer()
-    assert chz.samples_per_submit == BLOCK
+    chz = SondeChannelizer(fused=False)            # keep the 48 kS/s rows: the intermediate products are compared below
+    assert chz.samples_per_submit == BLOCK and not chz.fused
     got_frames, first = [], None
     for b in range(10):
         chz.submit(iq[b * BLOCK: (b + 1) * BLOCK].contiguous())
@@ -141,9 +141,9 @@ def test_hip_channelizer_three_streams_in_one_object(oracle, monkeypatch):
     stream exercises the front-end's own cross-stream ordering."""
     import torch
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
-    S, NBLK = 3, 6
+    S, NBLK = 3, 10
     scenes = [synth.make_wideband_rs41([40 + 100 * s, 300 + s], NBLK * BLOCK, seed=30 + s, ebn0_db=33.0, device="cuda:0")[0] for s in range(S)]
-    multi = SondeChannelizer(n_streams=S)
+    multi = SondeChannelizer(n_streams=S, fused=False)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     torch.cuda.synchronize()
     got, first = [], None
@@ -156,7 +156,7 @@ def test_hip_channelizer_three_streams_in_one_object(oracle, monkeypatch):
         got.append(multi.frames())
     got = np.concatenate(got)
     for s in range(S):
-        one = SondeChannelizer()
+        one = SondeChannelizer(fused=False)
         ref = []
         for b in range(NBLK):
             one.submit(scenes[s][b * BLOCK: (b + 1) * BLOCK].contiguous())
@@ -181,9 +181,49 @@ def test_pfb_forms_give_identical_bins(oracle, monkeypatch):
     outs = []
     for form in ("8", "20"):
         monkeypatch.setenv("SONDE_PFB_FORM", form)
-        chz = SondeChannelizer()
+        chz = SondeChannelizer(fused=False)
         for b in range(2):
             chz.submit(iq[b * BLOCK: (b + 1) * BLOCK].contiguous())
         outs.append(chz.read())
         chz.close()
     assert outs[0][0].tobytes() == outs[1][0].tobytes() and outs[0][1].tobytes() == outs[1][1].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bps,streams", [(1, 1), (2, 1), (1, 2)])
+def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
+    """The default mode: the per-bin discriminator and the 6/5 resampler run inside the decoder kernel (two launches per
+    submit, the 48 kS/s rows never exist).  Frames of every bin == the oracle's (or_chan.c -> or_channel, real input), for
+    RS41 (4:1 class) and M10 (2:1 class) bins, one and two blocks per submit, one and two streams per object."""
+    import torch
+    from sdrpp_radiosonde_amd.batch import SondeChannelizer
+    bins_active = [9, 130, 257, 500]
+    scenes = [synth.make_wideband_rs41(bins_active, 10 * BLOCK, seed=50 + s, ebn0_db=33.0, device="cuda:0")[0] for s in range(streams)]
+    types = np.zeros(512 * streams, dtype=np.uint8)
+    m10_bins = [7, 23]                             # two silent bins run the M10 class kernel: mixed classes behind one channelizer
+    for s_ in range(streams):
+        types[[512 * s_ + k for k in m10_bins]] = 3
+    chz = SondeChannelizer(types=types, blocks_per_submit=bps, n_streams=streams)
+    assert chz.fused
+    got = []
+    for b in range(10 // bps):
+        blk = [sc[b * bps * BLOCK: (b + 1) * bps * BLOCK] for sc in scenes]
+        chz.submit(torch.stack(blk).contiguous() if streams > 1 else blk[0].contiguous())
+        got.append(chz.frames())
+    got = np.concatenate(got)
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    refs = []
+    for s_, sc in enumerate(scenes):
+        dec, _ = _oracle_decode_wideband(oracle, sc.cpu().numpy(), bins_active + m10_bins, types=types[:512])
+        for k in bins_active + m10_bins:
+            r = dec[k].frames().copy()
+            r["channel"] = 512 * s_ + k
+            refs.append(r)
+    ref = np.concatenate(refs)
+    assert len(ref) >= len(bins_active) * streams and key(got).tobytes() == key(ref).tobytes()
+    # bits and loop state of an M10-class bin too (no frames there: the frame comparison alone would not see that kernel)
+    rb = dec[7].bits()                             # (dec: the last stream's oracle channels)
+    c7 = 512 * (streams - 1) + 7
+    assert chz.batch.nbits(c7) == len(rb) > 4000 and np.array_equal(chz.batch.read_bits(c7, len(rb) - 4000, 4000), rb[-4000:])
+    st, rs = chz.batch.state(c7), dec[7].state()
+    assert (st["t_next"], st["period"]) == (rs["t_next"], rs["period"])
