@@ -313,6 +313,120 @@ __global__ __launch_bounds__(P8_NT, 4) void sd_pfb8_kernel(const float2 *__restr
 	}
 }
 
+// ---- PFB, third form (round 3; NOT the default: measured slower than the 8-step form, kept for the record and the A/B):
+// one 1024-thread workgroup per THREE consecutive 8-step groups of one stream, wave-specialised:
+// waves 0-7 (thread = bin residue) fold group g + 1 out of the staged window while waves 8-15 (wave = time step) run the FFTs
+// of group g, transpose them through the FFT buffer and store.  The window of the 24 steps (8192 + 23*250 samples, 111.5 KB)
+// is staged once and never overwritten -- the FFT buffer is separate (36.9 KB) -- so the fold, which is bound by LDS
+// bandwidth (every step reads its 8192 samples), and the FFT, which is bound by VALU issue, overlap inside the workgroup;
+// window samples are re-read 2.3 x (8-step form: 5 x).  Four workgroup barriers per group hand the FFT buffer back and forth.
+// Arithmetic, operand order and tables are those of the other two forms (bit-identical bins: tests/test_channelizer.py).
+#define PP_G     3                                     // groups per workgroup
+#define PP_NT    1024
+#define PP_WIN   (CH_L + (PP_G * P8_S - 1) * CH_D)     // 13942 samples
+static_assert((PP_WIN + P8_S * PFB_FB + CH_M / 2) * sizeof(float2) <= 160 * 1024, "window + FFT buffer + twiddles in LDS");
+static_assert(PP_WIN % 2 == 0, "16-byte staging loads");
+
+__global__ __launch_bounds__(PP_NT) void sd_pfbp_kernel(const float2 *__restrict__ iq_all, size_t stream_stride,
+                                                         const float2 *__restrict__ hist_in_all, float2 *__restrict__ hist_out_all,
+                                                         const float *__restrict__ h, const float2 *__restrict__ tw,
+                                                         float2 *__restrict__ bins_all, uint32_t n_steps)
+{
+	__shared__ __attribute__((aligned(16))) float2 s_x[PP_WIN];
+	__shared__ __attribute__((aligned(16))) float2 s_f[P8_S * PFB_FB];
+	__shared__ float2 s_tw[CH_M / 2];
+	const int tid = threadIdx.x, lane = tid & 63;
+	const bool folder = tid < CH_M;                            // wave-uniform role: waves 0-7 fold, waves 8-15 transform and store
+	const int r = tid & (CH_M - 1), fw = (tid >> 6) & 7;      // bin residue (fold) / bin (store); FFT wave = step inside the group
+	const uint32_t n_groups = n_steps / P8_S, g0 = blockIdx.x * PP_G, sidx = blockIdx.y;
+	const int ng = (int)min((uint32_t)PP_G, n_groups - g0);
+	const uint32_t m0 = g0 * P8_S;
+	const float2 *iq = iq_all + (size_t)sidx * stream_stride;
+	const float2 *hist_in = hist_in_all + (size_t)sidx * CH_H;
+	float2 *bins = bins_all + (size_t)sidx * CH_M * n_steps;
+	{	// stage the window of the ng groups: all loads first, then all LDS stores
+		const long p0 = (long)m0 * CH_D - CH_H;                       // stream position of window sample 0 (even)
+		const int need = (CH_L + (ng * P8_S - 1) * CH_D) / 2;         // float4s this workgroup's steps read
+		const float4 *src_iq = reinterpret_cast<const float4 *>(iq) + p0 / 2;
+		const float4 *src_h = reinterpret_cast<const float4 *>(hist_in) + (CH_H + p0) / 2;
+		float4 *dst = reinterpret_cast<float4 *>(s_x);
+		constexpr int NQ = (PP_WIN / 2 + PP_NT - 1) / PP_NT;
+		float4 tmp[NQ];
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			const int i = tid + PP_NT * q;
+			tmp[q] = i < need ? (p0 + 2 * (long)i < 0 ? src_h[i] : src_iq[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			const int i = tid + PP_NT * q;
+			if (i < need) dst[i] = tmp[q];
+		}
+	}
+	float hr[CH_T];
+	if (folder) {
+#pragma unroll
+		for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
+	} else if (tid - CH_M < CH_M / 2) {
+		s_tw[tid - CH_M] = tw[tid - CH_M];
+	}
+	__syncthreads();
+	if (blockIdx.x == gridDim.x - 1) {     // the last CH_H samples of [history | block] are the next submit's history
+		const float4 *tail = reinterpret_cast<const float4 *>(s_x + ng * P8_S * CH_D);
+		float4 *ho = reinterpret_cast<float4 *>(hist_out_all + (size_t)sidx * CH_H);
+		for (int i = tid; i < CH_H / 2; i += PP_NT) ho[i] = tail[i];
+	}
+	// fold of one group (SPEC 3.5: v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc), t ascending)
+	float2 v[P8_S];
+	auto fold = [&](int g) {
+#pragma unroll
+		for (int q = 0; q < P8_S; q++) {
+			const float2 *xs = s_x + (g * P8_S + q) * CH_D + r;
+			float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+			for (int t = 0; t < CH_T; t++) {
+				const float2 xv = xs[t * CH_M];
+				ar = __builtin_fmaf(hr[t], xv.x, ar);
+				ai = __builtin_fmaf(hr[t], xv.y, ai);
+			}
+			v[q] = make_float2(ar, ai);
+		}
+	};
+	if (folder) fold(0);
+	for (int g = 0; g < ng; g++) {
+		__syncthreads();                   // (A) the FFT buffer is free: the store waves have read the previous group's tile
+		if (folder) {
+#pragma unroll
+			for (int q = 0; q < P8_S; q++) {   // rotate + bit-reverse into the buffer of the step
+				const uint32_t shift = ((m0 + (uint32_t)(g * P8_S + q)) * CH_D) & (CH_M - 1);
+				const uint32_t pos = ((uint32_t)r + shift) & (CH_M - 1);
+				s_f[q * PFB_FB + pfb_pad((int)(__brev(pos) >> 23))] = v[q];
+			}
+		}
+		__syncthreads();                   // (B) the buffers hold group g
+		float2 e0[8];
+		if (folder) {
+			if (g + 1 < ng) fold(g + 1);   // overlaps the other waves' FFTs
+		} else {
+			pfb_fft512(s_f + fw * PFB_FB, s_tw, lane, e0);
+		}
+		__syncthreads();                   // (C) every FFT wave has left its buffer: the output tile aliases them
+		if (!folder) {
+#pragma unroll
+			for (int j = 0; j < 8; j++) s_f[(lane + 64 * j) * P8_OT + fw] = e0[j];
+		}
+		__syncthreads();                   // (D) tile[bin][step] complete
+		if (!folder) {
+			float2 o[P8_S];
+#pragma unroll
+			for (int j = 0; j < P8_S; j++) o[j] = s_f[r * P8_OT + j];
+			float4 *dst = reinterpret_cast<float4 *>(bins + (size_t)r * n_steps + m0 + g * P8_S);
+#pragma unroll
+			for (int j = 0; j < P8_S / 2; j++) dst[j] = make_float4(o[2 * j].x, o[2 * j].y, o[2 * j + 1].x, o[2 * j + 1].y);
+		}
+	}
+}
+
 // ---- per bin: discriminator at 40 kS/s + 6/5 polyphase resampler to 48 kS/s.  One workgroup per bin.
 __global__ __launch_bounds__(256) void sd_disc_resamp_kernel(const float2 *__restrict__ bins, uint32_t n_steps,
                                                               const float *__restrict__ g, float2 *__restrict__ iq_last,
@@ -367,7 +481,10 @@ struct SondeChannelizer {
 	uint32_t n_steps = 0, n_streams = 1;
 	bool fused = false;                    // the decoder kernel takes the bins themselves (discriminator + resampler in its load path): two launches per submit
 	SdBinsIn *d_bins_in = nullptr;
-	int pfb_form = 8;                      // steps per filter-bank workgroup: 8 (two workgroups per CU) or 20 (SONDE_PFB_FORM=20: the round-2 kernel, one stream)
+	// steps per filter-bank workgroup (SONDE_PFB_FORM): 8 (two workgroups per CU; the default: 8 streams 136 us per submit), 24
+	// (wave-specialised, one workgroup per CU: 165 us -- its 111 KB staging burst is not overlapped with anything) or 20 (the
+	// round-2 kernel, one stream only); measured in profiles/r3_notes.md
+	int pfb_form = 8;
 	hipStream_t last_stream = nullptr;     // a submit on another stream waits for the previous one (the state is carried)
 	hipEvent_t ev_xs = nullptr;
 	SondeBatch *batch = nullptr;
@@ -442,7 +559,7 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 	c->device = device;
 	c->n_streams = n_streams;
 	c->n_steps = 5120u * blocks_per_submit;                  // 5120 steps = 1.28 M wideband samples = 6144 samples at 48 kS/s
-	if (const char *e = getenv("SONDE_PFB_FORM")) c->pfb_form = (atoi(e) == 20 && n_streams == 1) ? 20 : 8;
+	if (const char *e = getenv("SONDE_PFB_FORM")) c->pfb_form = (atoi(e) == 20 && n_streams == 1) ? 20 : (atoi(e) == 24 ? 24 : 8);
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
 	const size_t nb = (size_t)n_streams * CH_M;              // bins of all streams: the decoder batch's channels, stream-major
 	SondeBatchConfig cfg;
@@ -526,8 +643,11 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 	if (c->pfb_form == 20)
 		hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(PFB_NT), 0, stream, (const float2 *)iq_dev, c->d_hist[c->n_blocks & 1],
 		                   c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
-	else
+	else if (c->pfb_form == 8)
 		hipLaunchKernelGGL(sd_pfb8_kernel, dim3(c->n_steps / P8_S, c->n_streams), dim3(P8_NT), 0, stream, (const float2 *)iq_dev, n_samples,
+		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
+	else
+		hipLaunchKernelGGL(sd_pfbp_kernel, dim3((c->n_steps / P8_S + PP_G - 1) / PP_G, c->n_streams), dim3(PP_NT), 0, stream, (const float2 *)iq_dev, n_samples,
 		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
 	c->n_blocks++;
 	if (timed) (void)hipEventRecord(c->ev[1], stream);

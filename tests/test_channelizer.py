@@ -174,19 +174,20 @@ def test_hip_channelizer_three_streams_in_one_object(oracle, monkeypatch):
 
 @pytest.mark.gpu
 def test_pfb_forms_give_identical_bins(oracle, monkeypatch):
-    """The 8-step filter-bank kernel (two workgroups per CU, the default) and the round-2 20-step kernel (SONDE_PFB_FORM=20)
-    produce the same bins and rows, bit for bit."""
+    """The three filter-bank kernels -- 8 steps per workgroup, two workgroups per CU (the default); 24 steps, wave-specialised
+    (SONDE_PFB_FORM=24); the round-2 20-step kernel (SONDE_PFB_FORM=20) -- produce the same bins and rows, bit for bit."""
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
     iq, _ = synth.make_wideband_rs41([77, 400], 2 * BLOCK, seed=41, ebn0_db=30.0, device="cuda:0")
     outs = []
-    for form in ("8", "20"):
+    for form in ("8", "24", "20"):
         monkeypatch.setenv("SONDE_PFB_FORM", form)
         chz = SondeChannelizer(fused=False)
         for b in range(2):
             chz.submit(iq[b * BLOCK: (b + 1) * BLOCK].contiguous())
         outs.append(chz.read())
         chz.close()
-    assert outs[0][0].tobytes() == outs[1][0].tobytes() and outs[0][1].tobytes() == outs[1][1].tobytes()
+    for o in outs[1:]:
+        assert outs[0][0].tobytes() == o[0].tobytes() and outs[0][1].tobytes() == o[1].tobytes()
 
 
 @pytest.mark.gpu
