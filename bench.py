@@ -364,6 +364,8 @@ def measured_traffic(args):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this process is itself being profiled (rocprofv3 environment present): no nested counter passes"
     C = args.channels or 1024
     vals = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
