@@ -84,7 +84,7 @@ def parse_args():
     ap.add_argument("--sonde-type", type=int, default=0, help="all channels of this SONDE_* type (1 DFM09, 2 iMS-100, 3 M10; not the headline workload)")
     ap.add_argument("--wideband", action="store_true", help="BASELINE configs[3]: 10 MS/s IQ -> 512-bin channelizer -> per-bin demod+FEC")
     ap.add_argument("--wb-streams", type=int, default=1, help="--wideband: independent 10 MS/s streams processed per step")
-    ap.add_argument("--wb-blocks", type=int, default=1, choices=(1, 2), help="--wideband: blocks of 1 280 000 samples (0.128 s) per submit")
+    ap.add_argument("--wb-blocks", type=int, default=1, choices=(1, 2, 4, 8), help="--wideband: blocks of 1 280 000 samples (0.128 s) per submit")
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
                     "4 for runs of fewer than 64 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
                     "(profiles/r2_notes.md), inside the timed region: every 8th costs 0.6 %% of the step")
@@ -520,14 +520,16 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
         others["mix4096_joined"]["workload"] = "the same, every submit joined into the caller's stream (flags 0)"
         others["shard8192"] = small_run("rs41", 8192, 24, 5, 0, args, local_rank, dev, barrier, stream)
         others["shard8192"]["workload"] = "BASELINE configs[4], one GPU's shard: 8192 RS41 channels x 49152 samples (T = 1 s) per step"
-        for S in (1, 8):
+        for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8x4", 8, 4)):
             import copy
             a = copy.copy(args)
-            a.wb_streams, a.steps, a.warmup, a.ramp_ms = S, max(20, min(args.steps, 50)), max(5, min(args.warmup, 10)), min(args.ramp_ms, 100.0)
+            a.wb_streams, a.wb_blocks = S, B
+            a.steps, a.warmup, a.ramp_ms = max(20, min(args.steps, 50)), max(5, min(args.warmup, 10)), min(args.ramp_ms, 100.0)
             w = run_wideband(a, rank, local_rank, world, dev, barrier, reduce_max_sum)
-            others["wideband" if S == 1 else "wideband8"] = {
+            others[name] = {
                 "workload": "BASELINE configs[3]: " + w["config"]["workload"], "ms_per_step": w["ms_per_step"], "value": w["value"],
-                "unit": w["unit"], "realtime_streams": w["realtime_streams"], "kernel_ms": w["kernel_ms"], "steps": a.steps, "warmup": a.warmup}
+                "unit": w["unit"], "realtime_streams": w["realtime_streams"], "us_per_stream_block": round(w["ms_per_step"] * 1e3 / (S * B), 2),
+                "kernel_ms": w["kernel_ms"], "steps": a.steps, "warmup": a.warmup}
         out["other_configs"] = others
         ls = small_run("rs41", C, args.tiles, args.blocks, args.flags, args, local_rank, dev, barrier, stream, ebn0=9.0)
         out["low_snr"] = {"ebn0": 9.0, "ms_per_step": ls["ms_per_step"], "step_frac": ls["step_frac"], "kernel_ms": ls["kernel_ms"],

@@ -225,7 +225,7 @@ float sonde_ims100_temp(uint32_t f, float c0, float c1, float c2);
  * aligned); the filter bank reads the block in place, so it must stay untouched until the submit's kernels have run
  * (stream order, as for sonde_batch_submit). */
 typedef struct SondeChannelizer SondeChannelizer;
-int         sonde_chan_create(const uint8_t *types /* 512 entries or NULL = RS41 */, uint32_t blocks_per_submit /* 1..2 */,
+int         sonde_chan_create(const uint8_t *types /* 512 entries or NULL = RS41 */, uint32_t blocks_per_submit /* 1..8; 1..2 with AFSK bins or unfused */,
                               int device, SondeChannelizer **out);
 /* The same for n_streams wideband streams per submit (one launch of each stage over all streams: grid.y = stream): types has
  * n_streams * 512 entries (stream-major) or is NULL; sonde_chan_submit then takes n_streams blocks laid out back to back,

@@ -553,7 +553,9 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 
 extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out)
 {
-	if (!out || blocks_per_submit == 0 || blocks_per_submit > 2 || n_streams == 0 || n_streams > 64) return -1;   // LDS: (16 + 5120 q) floats per bin
+	// up to 8 blocks per submit when the decoder takes the bins itself; the stand-alone discriminator + resampler kernel stages
+	// (16 + 5120 q) floats per bin in LDS: 1-2 blocks
+	if (!out || blocks_per_submit == 0 || blocks_per_submit > 8 || n_streams == 0 || n_streams > 64) return -1;
 	*out = nullptr;
 	SondeChannelizer *c = new SondeChannelizer;
 	c->device = device;
@@ -575,7 +577,7 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 	const size_t hist_bytes = (size_t)n_streams * CH_H * sizeof(float2);
 	bool ok = hipMalloc((void **)&c->d_hist[0], hist_bytes) == hipSuccess && hipMalloc((void **)&c->d_hist[1], hist_bytes) == hipSuccess &&
 	          hipMalloc((void **)&c->d_bins, nb * c->n_steps * sizeof(float2)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_out48, nb * n_out * sizeof(float)) == hipSuccess &&
+	          (blocks_per_submit > 2 || hipMalloc((void **)&c->d_out48, nb * n_out * sizeof(float)) == hipSuccess) &&
 	          hipMalloc((void **)&c->d_h, CH_L * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_tw, CH_M * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_g, RS_UP * RS_TAPS * sizeof(float)) == hipSuccess &&
@@ -593,6 +595,7 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 		ok = hipMalloc((void **)&c->d_bins_in, sizeof(bi)) == hipSuccess && hipMemcpy(c->d_bins_in, &bi, sizeof(bi), hipMemcpyHostToDevice) == hipSuccess;
 		// fused unless a bin's sonde type needs 48 kS/s rows (AFSK) or the host asks for the rows (sonde_chan_set_fused, SONDE_CHAN_UNFUSED)
 		c->fused = sd_batch_bins_capable(c->batch) && !getenv("SONDE_CHAN_UNFUSED");
+		if (!c->fused && blocks_per_submit > 2) ok = false;      // (AFSK bins: the three-kernel form, 1-2 blocks per submit)
 	}
 	if (!ok) { sonde_chan_destroy(c); return -1; }
 	*out = c;
@@ -610,7 +613,7 @@ extern "C" uint32_t sonde_chan_streams(const SondeChannelizer *c) { return c ? c
 extern "C" int sonde_chan_set_fused(SondeChannelizer *c, int on)
 {
 	if (!c) return -1;
-	if (c->n_blocks == 0) c->fused = on && sd_batch_bins_capable(c->batch);
+	if (c->n_blocks == 0 && (on || c->d_out48)) c->fused = on && sd_batch_bins_capable(c->batch);      // (> 2 blocks per submit: fused only)
 	return c->fused ? 1 : 0;
 }
 

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		constexpr int PER_WAVE = SD_TILE / DEC / 4;              // decimated samples a wave produces per tile: 128 (4:1) or 256 (2:1)
 		const uint32_t J0 = 2048u * (uint32_t)tile + 512u * (uint32_t)kw;
 		const uint32_t m_lo = J0 / 6u;
-#pragma unroll 1
+#pragma unroll 1                 // (unrolled: 3.6 x slower -- 1.12 against 0.31 ms for 4096 bins x 12 tiles: the second pass's operands spill)
 		for (int a = 0; a < 2; a++) {
 			uint32_t m = m_lo + (uint32_t)lane + 64u * a;
 			if (6u * m >= J0 + 512u) m = m_lo;                                   // no output of this wave: stay inside the scratch

@@ -191,7 +191,7 @@ def test_pfb_forms_give_identical_bins(oracle, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bps,streams", [(1, 1), (2, 1), (1, 2)])
+@pytest.mark.parametrize("bps,streams", [(1, 1), (2, 1), (1, 2), (5, 1)])
 def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
     """The default mode: the per-bin discriminator and the 6/5 resampler run inside the decoder kernel (two launches per
     submit, the 48 kS/s rows never exist).  Frames of every bin == the oracle's (or_chan.c -> or_channel, real input), for
