@@ -27,9 +27,10 @@
 
 typedef float sd_f32x4 __attribute__((ext_vector_type(4)));
 
+// min(max(v, lo), hi) as ONE v_med3_f32 (equal for every non-NaN v; the fminf / fmaxf pair costs a canonicalising v_max_f32 more)
 __device__ __forceinline__ float sd_clamp(float v, float lo, float hi)
 {
-	return __builtin_fminf(__builtin_fmaxf(v, lo), hi);
+	return __builtin_amdgcn_fmed3f(v, lo, hi);
 }
 
 // Integer wave reduction with DPP (VALU, no LDS crossbar): rows of 16, then row broadcasts; the total

@@ -127,7 +127,10 @@ def test_batch_decoder_cpp(tmp_path, oracle):
 
 
 def test_ims100_b1_fields(oracle):
-    """ims100_decode (main.hpp:38, row a6): GPS, time, T/RH fragments of an iMS-100 / RS-11G stream (README.md:14-15)."""
+    """ims100_decode (main.hpp:38, row a6): GPS, time, T/RH fragments of an iMS-100 / RS-11G stream (README.md:14-15).
+    SELF-REFERENTIAL (ADVICE r2): the field layout this parser assumes is the repo's own and the generator (synth.py) shares it;
+    this test pins the parser against the generator, not against a recorded sonde -- the parser is marked experimental.
+    """
     n = 2048 * 60
     sb = synth.make_batch(2, 1, n, seed=33, ebn0_db=26.0)
     frags = _run_b1("ims100", _discriminate(oracle, sb.iq.numpy()[0]), 4096)
@@ -180,7 +183,10 @@ def test_imet_xdata_b1(oracle):
 
 
 def test_mrzn1_b1_fields(oracle):
-    """mrzn1_decode (main.hpp:42; README.md:19: GPS + temperature)."""
+    """mrzn1_decode (main.hpp:42; README.md:19: GPS + temperature).
+    SELF-REFERENTIAL (ADVICE r2): the field layout this parser assumes is the repo's own and the generator (synth.py) shares it;
+    this test pins the parser against the generator, not against a recorded sonde -- the parser is marked experimental.
+    """
     n = 2048 * 120
     sb = synth.make_batch(6, 1, n, seed=37, ebn0_db=26.0)
     frags = _run_b1("mrzn1", _discriminate(oracle, sb.iq.numpy()[0]), 4096)

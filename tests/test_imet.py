@@ -194,7 +194,10 @@ def test_c50_gpu_bit_exact(oracle, snr):
 
 @pytest.mark.gpu
 def test_b1_c50_decoder(oracle):
-    """c50_decoder_init / c50_decode (main.hpp:41; README.md:17: GPS + temperature)."""
+    """c50_decoder_init / c50_decode (main.hpp:41; README.md:17: GPS + temperature).
+    SELF-REFERENTIAL (ADVICE r2): the field layout this parser assumes is the repo's own and the generator (synth.py) shares it;
+    this test pins the parser against the generator, not against a recorded sonde -- the parser is marked experimental.
+    """
     import calendar
     L = _lib.load()
     n = 16384 * 10
@@ -225,6 +228,8 @@ def test_b1_c50_decoder(oracle):
 
 
 def test_c50_parser_fields():
+    """SELF-REFERENTIAL (ADVICE r2): the field layout this parser assumes is the repo's own and the generator (synth.py) shares it;
+    this test pins the parser against the generator, not against a recorded sonde -- the parser is marked experimental."""
     lib = _lib.load()
     h = lib.sonde_parser_create(5)
     out = (_lib.SondeData * 4)()
