@@ -387,7 +387,11 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	{
 		b->fuse_fec = (cfg->flags & SONDE_FLAG_SPLIT_FEC) ? 0u : 1u;
 		for (int k = 0; k < 2; k++) {
-			const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts2[k], b->max_frames, b->fuse_fec, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames2[k] };
+			// one residency of the GPU: 4 demod workgroups (39.7 KB of LDS, 8 waves each) per CU
+			hipDeviceProp_t prop;
+			CHK(hipGetDeviceProperties(&prop, cfg->device));
+			const uint32_t loop_wg = getenv("SONDE_NO_LOOP_FEC") ? 0u : 4u * (uint32_t)prop.multiProcessorCount;
+			const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts2[k], b->max_frames, b->fuse_fec, loop_wg, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames2[k] };
 			CHK(hipMemcpy(b->d_fo2[k], &fo, sizeof(fo), hipMemcpyHostToDevice));
 			CHK(hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming));
 		}

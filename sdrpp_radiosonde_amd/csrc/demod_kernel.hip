@@ -71,6 +71,7 @@ struct DemodLds {
 	float rs_dh[16];
 	uint32_t mirror[SD_MIRROR_WORDS];       // the newest 2048 bits of the bit ring, for the in-kernel sync search (K4)
 	SdSyncRun k4;                           // K4's state between steps (wave 3 only)
+	SdFecJob fec;                           // the in-loop decoder of clean RS41 frames (wave 2 only, sd_rsdec.h)
 };
 
 // samples (i, i+1) of a tile, i even, into buffer b
@@ -266,6 +267,20 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	const bool fec_here = is_rs41 && fuse;     // workgroup-uniform
 #endif
 	EpiTabs &et = *reinterpret_cast<EpiTabs *>(&s.B[1][SD_EPI_TAB_OFF]);
+	// Round 3: clean frames can be decoded INSIDE the tile loop, by round wave 2, a step per round (sd_rs41_loop_step); its
+	// work area sits in the part of A[1] no decimated tile uses (the bins path keeps its scratch there).
+	// Only where it pays (interleaved A/B, tools/ab_repeat.sh, profiles/r3_notes.md): launches whose workgroups are ALL resident at
+	// once -- their epilogues coincide, nothing else streams meanwhile: 1024 x 96 tiles -1.6 % at 14 dB, -1.1 % at 9 dB -- and long
+	// enough (>= 48 tiles; at 24 the steps of the 1.6 frames a submit completes stall as much as they save).  In launches of several
+	// generations the epilogues overlap other workgroups' streaming for free and the steps only stall: 4096 x 96 tiles +7 %.
+#ifndef SD_NO_LOOP_FEC
+	const bool fec_loop = fec_here && !BINS && n_tiles >= 48 && gridDim.x <= fo->loop_fec_max_wg;
+#else
+	constexpr bool fec_loop = false;
+#endif
+	FramerLds &loop_wl = *reinterpret_cast<FramerLds *>(&s.A[1][1100]);
+	static_assert(sizeof(FramerLds) <= (SD_BUF - 1100) * sizeof(float), "in-loop FEC work area");
+	if (tid == 3 * 64 - 1) { s.fec.frame = 0; s.fec.phase = 0; s.fec.done_mask = 0; }      // (wave 2: the wave that uses it)
 	if (fec_here && is_rs41 && !is_k) {
 		// GF(2^8) tables for the epilogue: one 16-byte global load per round-wave thread now, hidden behind the first tile's loads
 		static_assert(GF_EXP2 / 16 + 512 / 16 + RS_R * 8 * 4 / 16 <= SD_WG, "the round waves load the GF tables");
@@ -669,6 +684,12 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 					// K4 instead of spinning while the lead wave runs the loop filter: the search works on the bits the
 					// PREVIOUS publish announced (one round behind; the epilogue catches up)
 					if (k4) k4_run(sd_uniform64(s.k4.wp_seen));
+					// the in-loop decoder of clean RS41 frames: one step per round on round wave 2, which would otherwise only wait
+					// for the lead wave's loop filter (a real call: sd_rsdec.h says why)
+#ifndef SD_NO_LOOP_FEC
+					if (fec_loop && rwave == 2) sd_rs41_loop_step(s.fec, s.k4, et.tabs, et.swar, loop_wl, ring_g, ring_mask,
+					                                              fo->frames + (size_t)ch * fo->max_frames, ch, fo->max_frames, lane);
+#endif
 					while (__hip_atomic_load(&s.pub.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1u)
 						__builtin_amdgcn_s_sleep(2);
 					t_next = s.pub.t_next; period = s.pub.period; bias = s.pub.bias; K = s.pub.K;
@@ -712,7 +733,9 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			swar.a_lo = sw[0]; swar.a_hi = sw[1]; swar.b_lo = sw[2]; swar.b_hi = sw[3]; swar.c = sw[4];
 			const unsigned long long *dg = reinterpret_cast<const unsigned long long *>((const SdFrameDesc *)fo->descs + (size_t)ch * max_frames);
 			SondeFrame *fout = fo->frames + (size_t)ch * max_frames;
+			const uint32_t done_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.fec.done_mask);      // records the loop has written
 			for (uint32_t k = (uint32_t)wave; k < nfr; k += SD_WGT / 64) {
+				if (k < 32u && ((done_mask >> k) & 1u)) continue;
 				// the descriptor: from K4's list in LDS, or (beyond its first entries) from HBM, where wave 3 of this workgroup
 				// stored it a moment ago: agent-scope loads (L2), like the ring words
 				unsigned long long d0, d1;

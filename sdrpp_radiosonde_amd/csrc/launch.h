@@ -12,6 +12,8 @@
 struct SdFramerOut {
 	SdFramerState *fstates; void *descs; uint32_t *counts; uint32_t max_frames;
 	uint32_t fuse_fec;                      // 1: the demod kernel decodes the listed frames in its epilogue; 0: sd_rsdec_rs41_kernel does
+	uint32_t loop_fec_max_wg;               // launches of at most this many workgroups (= one residency of the GPU) and >= 48 tiles decode clean
+	                                        // RS41 frames inside the tile loop (sd_rsdec.h sd_rs41_loop_step); 0: never
 	const uint8_t *gf_exp, *gf_log; const uint32_t *gf_swar;
 	const uint8_t *gf64;                    // GF(2^6) tables of the iMS-100 BCH decoder
 	SondeFrame *frames;

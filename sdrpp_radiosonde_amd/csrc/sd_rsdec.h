@@ -84,17 +84,25 @@ __device__ __forceinline__ uint32_t gf_swar_mul(uint32_t s, const GfSwar &t)
 // One syndrome S_j = r(alpha^j) of the codeword cw[0..4W) (zero-padded).  Chain k (byte k of the state) runs over
 // the positions 4m + k with the multiplier alpha^(4j), so one aligned word of the codeword feeds all four chains
 // (a broadcast LDS read: the lanes of a codeword share the address); then S = U0 + a^j U1 + a^2j U2 + a^3j U3.
-__device__ __forceinline__ uint32_t syndrome_swar(const FramerTabs &tb, const uint8_t *cw, int W, int j, const GfSwar &t)
+// (in two pieces so that the in-loop decoder of the demod kernel can stop half way: the chain state u is all there is to carry)
+__device__ __forceinline__ uint32_t syndrome_swar_part(const uint8_t *cw, int w_hi, int w_lo, uint32_t u, const GfSwar &t)
 {
 	const uint32_t *cww = reinterpret_cast<const uint32_t *>(cw);
-	uint32_t u = 0;
 #pragma unroll 4
-	for (int w = W - 1; w >= 0; w--) u = gf_swar_mul(u, t) ^ cww[w];
+	for (int w = w_hi - 1; w >= w_lo; w--) u = gf_swar_mul(u, t) ^ cww[w];
+	return u;
+}
+__device__ __forceinline__ uint32_t syndrome_swar_finish(const FramerTabs &tb, uint32_t u, int j)
+{
 	uint32_t syn = u & 0xFFu;
 	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[(u >> 8) & 0xFFu] + (uint32_t)j];
 	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[(u >> 16) & 0xFFu] + 2u * (uint32_t)j];
 	syn ^= (uint32_t)tb.exp2[(uint32_t)tb.log2[u >> 24] + 3u * (uint32_t)j];
 	return syn;
+}
+__device__ __forceinline__ uint32_t syndrome_swar(const FramerTabs &tb, const uint8_t *cw, int W, int j, const GfSwar &t)
+{
+	return syndrome_swar_finish(tb, syndrome_swar_part(cw, W, 0, 0u, t), j);
 }
 
 #ifdef SD_EPI_TIMESTAMPS       // stage k of the corrector reached: time stamp into the unused tail of the second codeword buffer
@@ -348,76 +356,56 @@ __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int
 }
 
 
-// One listed frame, start to finish, by one wave.  COHERENT: the ring words were written earlier in THIS launch by
-// another wave of the workgroup (the FEC epilogue of the demod kernel): read them with agent-scope loads, which are
-// served by the L2 and cannot hit a stale line of this CU's vector L1.
+// ---- the pieces of one frame's way through K5 / K6 (shared by the one-call decoder below and by the in-loop decoder)
+// K5: extract + de-whiten, four bytes per lane and step (the frame lengths are even, the word past the end is written
+// whole and never read beyond flen).  COHERENT: the ring words were written earlier in THIS launch by another wave of
+// the workgroup: read them with agent-scope loads, which are served by the L2 and cannot hit a stale line of this CU's vector L1.
 template <bool COHERENT>
-__device__ __forceinline__ void sd_rs41_decode_frame(const FramerTabs &tabs, FramerLds &s, const GfSwar &swar,
-	const uint32_t *__restrict__ ring, uint32_t mask, const SdFrameDesc d, SondeFrame *__restrict__ fr, uint32_t ch, int lane)
+__device__ __forceinline__ void sd_rs41_extract(FramerLds &s, const uint32_t *__restrict__ ring, uint32_t mask, const SdFrameDesc d, int lane)
 {
 	const int flen = d.flen;
-#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
-	const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-	unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
-#define SD_TS(x) do { __builtin_amdgcn_s_waitcnt(0); x = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SD_TS(x)
-#endif
-	// K5: extract + de-whiten, four bytes per lane and step (the frame lengths are even, the word past the end
-	// is written whole and never read beyond flen)
-	{
-		const uint32_t winv = d.inv ? 0xFFFFFFFFu : 0u;
-		const uint32_t *mask32 = reinterpret_cast<const uint32_t *>(c_rs41_mask);
-		uint32_t *frame32 = reinterpret_cast<uint32_t *>(s.frame);
-		for (int i = lane; 4 * i < flen; i += 64) {
-			const uint64_t p = d.fstart + 32ull * (uint64_t)i;
-			const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
-			uint32_t r0, r1;
-			if (COHERENT) {
-				r0 = __hip_atomic_load(ring + (w & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				r1 = __hip_atomic_load(ring + ((w + 1) & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			} else {
-				r0 = ring[w & mask];
-				r1 = ring[(w + 1) & mask];
-			}
-			const uint64_t lo = (uint64_t)r0 | ((uint64_t)r1 << 32);
-			frame32[i] = (uint32_t)(lo >> sh) ^ winv ^ mask32[i & 15];
+	const uint32_t winv = d.inv ? 0xFFFFFFFFu : 0u;
+	const uint32_t *mask32 = reinterpret_cast<const uint32_t *>(c_rs41_mask);
+	uint32_t *frame32 = reinterpret_cast<uint32_t *>(s.frame);
+	for (int i = lane; 4 * i < flen; i += 64) {
+		const uint64_t p = d.fstart + 32ull * (uint64_t)i;
+		const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+		uint32_t r0, r1;
+		if (COHERENT) {
+			r0 = __hip_atomic_load(ring + (w & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			r1 = __hip_atomic_load(ring + ((w + 1) & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			r0 = ring[w & mask];
+			r1 = ring[(w + 1) & mask];
 		}
+		const uint64_t lo = (uint64_t)r0 | ((uint64_t)r1 << 32);
+		frame32[i] = (uint32_t)(lo >> sh) ^ winv ^ mask32[i & 15];
 	}
-	WAVE_SYNC();
-	SD_TS(ts1);
-	// K6: de-interleave into two shortened codewords, a word at a time: codeword c holds its 24 parity bytes (frame bytes
-	// 8 + 24c ..) at positions 0..23 and the message bytes frame[56 + 2i + c] at position 24 + i, i.e. word 6 + m of codeword c
-	// gathers bytes c, 2 + c of frame word 14 + 2m and of frame word 15 + 2m (one v_perm_b32 each; the byte-wise loop cost a
-	// quarter of this stage's instructions).  Bytes behind the message (the odd length of the extended frame) are zeroed;
-	// nothing reads a codeword beyond word (n + 3) / 4.
+}
+// K6, first step: de-interleave into two shortened codewords, a word at a time: codeword c holds its 24 parity bytes (frame
+// bytes 8 + 24c ..) at positions 0..23 and the message bytes frame[56 + 2i + c] at position 24 + i, i.e. word 6 + m of codeword c
+// gathers bytes c, 2 + c of frame word 14 + 2m and of frame word 15 + 2m (one v_perm_b32 each; the byte-wise loop cost a
+// quarter of this stage's instructions).  Bytes behind the message (the odd length of the extended frame) are zeroed;
+// nothing reads a codeword beyond word (n + 3) / 4.  Returns n, the codeword length.
+__device__ __forceinline__ int sd_rs41_deinterleave(FramerLds &s, int flen, int lane)
+{
 	const int msglen = (flen - 56) / 2;
-	const int n = RS_R + msglen;
-	{
-		const uint32_t *frame32 = reinterpret_cast<const uint32_t *>(s.frame);
-		uint32_t *cw0 = reinterpret_cast<uint32_t *>(s.cw[0]), *cw1 = reinterpret_cast<uint32_t *>(s.cw[1]);
-		if (lane < RS_R / 4) { cw0[lane] = frame32[2 + lane]; cw1[lane] = frame32[2 + RS_R / 4 + lane]; }
-		const int valid = msglen - 4 * lane;                      // message bytes in this lane's word
-		if (valid > 0) {
-			const uint32_t f0 = frame32[14 + 2 * lane], f1 = frame32[15 + 2 * lane];
-			const uint32_t keep = valid >= 4 ? 0xFFFFFFFFu : (1u << (8 * valid)) - 1u;
-			cw0[RS_R / 4 + lane] = __builtin_amdgcn_perm(f1, f0, 0x06040200u) & keep;
-			cw1[RS_R / 4 + lane] = __builtin_amdgcn_perm(f1, f0, 0x07050301u) & keep;
-		}
+	const uint32_t *frame32 = reinterpret_cast<const uint32_t *>(s.frame);
+	uint32_t *cw0 = reinterpret_cast<uint32_t *>(s.cw[0]), *cw1 = reinterpret_cast<uint32_t *>(s.cw[1]);
+	if (lane < RS_R / 4) { cw0[lane] = frame32[2 + lane]; cw1[lane] = frame32[2 + RS_R / 4 + lane]; }
+	const int valid = msglen - 4 * lane;                      // message bytes in this lane's word
+	if (valid > 0) {
+		const uint32_t f0 = frame32[14 + 2 * lane], f1 = frame32[15 + 2 * lane];
+		const uint32_t keep = valid >= 4 ? 0xFFFFFFFFu : (1u << (8 * valid)) - 1u;
+		cw0[RS_R / 4 + lane] = __builtin_amdgcn_perm(f1, f0, 0x06040200u) & keep;
+		cw1[RS_R / 4 + lane] = __builtin_amdgcn_perm(f1, f0, 0x07050301u) & keep;
 	}
-	WAVE_SYNC();
-	SD_TS(ts2);
-	rs255_decode_pair(tabs, s, n, lane, swar);
-	SD_TS(ts3);
-	for (int c = 0; c < 2; c++) {
-		if (s.status[c] > 0) {
-			for (int kk = lane; kk < n; kk += 64) {
-				if (kk < RS_R) s.frame[8 + RS_R * c + kk] = s.cw[c][kk];
-				else s.frame[56 + 2 * (kk - RS_R) + c] = s.cw[c][kk];
-			}
-		}
-	}
-	WAVE_SYNC();
+	return RS_R + msglen;
+}
+// the frame record: header fields from s.status, the frame bytes zero-padded to SONDE_FRAME_MAX
+__device__ __forceinline__ void sd_rs41_write_record(const FramerLds &s, const SdFrameDesc d, SondeFrame *__restrict__ fr, uint32_t ch, int lane)
+{
+	const int flen = d.flen;
 	if (lane == 0) {
 		fr->channel = ch;
 		fr->type = SONDE_RS41;
@@ -433,6 +421,112 @@ __device__ __forceinline__ void sd_rs41_decode_frame(const FramerTabs &tabs, Fra
 		if (rem > 0 && rem < 4) wd &= (1u << (8 * rem)) - 1u;
 		reinterpret_cast<uint32_t *>(fr->data)[i] = wd;
 	}
+}
+
+// ---- the in-loop decoder of the demod kernel (round 3), used for launches of ONE generation of workgroups:
+// CLEAN frames leave the kernel while it is still streaming.  Round wave 2 -- which otherwise only waits for the lead wave's loop filter -- takes one step of this state machine per
+// timing-loop round: extract + de-whiten | de-interleave + first half of the 48 syndrome chains | second half + the all-zero
+// test | write the record.  A frame whose syndromes are not all zero is left to the epilogue (the corrector's fast paths take
+// 4-20 k cycles, its general path 25 k: several tile periods of one wave, which would hold up the workgroup's barrier), and so
+// is whatever the loop did not get to.  At 14 dB 96 % of the frames are clean.
+// What was measured (profiles/r3_notes.md, 1024 channels x 96 tiles, ms per step, one box per line):
+//   * inlined into the round loop, on the K4 wave: 0.2834 against 0.2692 without (the loop's register allocation spills; even
+//     NEVER run the inlined code costs 0.280 against 0.272); inlined on a discriminator wave: 0.2826 against 0.2683 (the
+//     spill reloads are vector loads: waiting for them drains the tile prefetch);
+//   * as a real function call on round wave 2 (this form): 0.2644 against 0.2697 inlined and 0.2641 without -- kernel 0.2625
+//     against 0.2661 -- and 0.2743 against 0.2805 at 9 dB; on 24-tile launches 0.555 against 0.542 without: the steps of the
+//     1.6 frames a 24-tile submit completes stall more rounds than the epilogue they save, so the kernel runs the loop decoder
+//     only from 48 tiles per submit up;
+//   * tracking the frame word by word as it arrives (chains in arrival order with the multipliers alpha^(-4j), no read-back from
+//     HBM) needs a call EVERY round on the round's critical path: 0.3846 against 0.2686.  Dropped.
+//   * single runs on one box scatter by 1-2 %, which is the size of the effect; interleaved, three runs each (tools/ab_repeat.sh),
+//     without / with: 1024 x 96 tiles 0.2745 / 0.2700 (-1.6 %), at 9 dB 0.2847 / 0.2815 (-1.1 %), 8192 x 24 (gated off by the tile
+//     count) 0.5513 / 0.5505, mix 4096 x 24 0.2888 / 0.2866, but 4096 x 96 tiles 1.0575 / 1.1317 (+7 %): where several generations of
+//     workgroups share the GPU their epilogues overlap the others' streaming anyway and the steps only stall.  Hence the gate:
+//     >= 48 tiles AND a launch that is resident all at once (SdFramerOut.loop_fec_max_wg).
+struct SdFecJob {
+	int32_t  frame;             // index (in K4's list) of the frame in work, or of the next one to look at when phase == 0
+	int32_t  phase;             // 0 idle, 1 extracted, 2 half way through the syndromes, 3 clean: record to write
+	uint32_t done_mask;         // bit k: frame k's record has been written
+	uint32_t usave[2 * RS_R];   // the syndrome chains' states between phases 1 and 2
+};
+__device__ __attribute__((noinline)) void sd_rs41_loop_step(SdFecJob &job, const SdSyncRun &k4, const FramerTabs &tb, const uint32_t *__restrict__ swar_tab,
+	FramerLds &wl, const uint32_t *__restrict__ ring, uint32_t mask, SondeFrame *__restrict__ fout, uint32_t ch, uint32_t max_frames, int lane)
+{
+	const int phase = __builtin_amdgcn_readfirstlane(job.phase), frame = __builtin_amdgcn_readfirstlane(job.frame);
+	const int listed = (int)min(min((uint32_t)__builtin_amdgcn_readfirstlane((int)k4.nout), max_frames), (uint32_t)SD_K4_LIST);
+	if (phase == 0 && frame >= listed) return;                   // nothing new (the usual step)
+	SdFrameDesc d;
+	d.fstart = sd_uniform64(reinterpret_cast<const unsigned long long *>(&k4.list[frame])[0]);
+	d.flen = __builtin_amdgcn_readfirstlane(k4.list[frame].flen);
+	d.inv = __builtin_amdgcn_readfirstlane(k4.list[frame].inv);
+	const int W = (RS_R + (d.flen - 56) / 2 + 3) >> 2, Wh = W >> 1;
+	const int c = lane >= RS_R ? 1 : 0, j = lane - RS_R * c;
+	GfSwar t;
+	int next_phase = 0, next_frame = frame;
+	if (phase == 0) {
+		sd_rs41_extract<true>(wl, ring, mask, d, lane);
+		next_phase = 1;
+	} else if (phase == 1) {
+		(void)sd_rs41_deinterleave(wl, d.flen, lane);
+		WAVE_SYNC();
+		if (lane < 2 * RS_R) {
+			const uint32_t *sw = swar_tab + 8 * j;
+			t.a_lo = sw[0]; t.a_hi = sw[1]; t.b_lo = sw[2]; t.b_hi = sw[3]; t.c = sw[4];
+			job.usave[lane] = syndrome_swar_part(wl.cw[c], W, Wh, 0u, t);
+		}
+		next_phase = 2;
+	} else if (phase == 2) {
+		uint32_t syn = 0;
+		if (lane < 2 * RS_R) {
+			const uint32_t *sw = swar_tab + 8 * j;
+			t.a_lo = sw[0]; t.a_hi = sw[1]; t.b_lo = sw[2]; t.b_hi = sw[3]; t.c = sw[4];
+			syn = syndrome_swar_finish(tb, syndrome_swar_part(wl.cw[c], Wh, 0, job.usave[lane], t), j);
+		}
+		if (__ballot(syn != 0) == 0ull) next_phase = 3;          // clean: the record is the de-whitened frame as it stands
+		else next_frame = frame + 1;                             // dirty: the epilogue's corrector takes it
+	} else {
+		if (lane < 2) wl.status[lane] = 0;
+		WAVE_SYNC();
+		sd_rs41_write_record(wl, d, fout + frame, ch, lane);
+		if (lane == 0) job.done_mask |= 1u << frame;
+		next_frame = frame + 1;
+	}
+	if (lane == 0) { job.phase = next_phase; job.frame = next_frame; }
+	WAVE_SYNC();
+}
+
+// One listed frame, start to finish, by one wave.
+template <bool COHERENT>
+__device__ __forceinline__ void sd_rs41_decode_frame(const FramerTabs &tabs, FramerLds &s, const GfSwar &swar,
+	const uint32_t *__restrict__ ring, uint32_t mask, const SdFrameDesc d, SondeFrame *__restrict__ fr, uint32_t ch, int lane)
+{
+	const int flen = d.flen;
+#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
+	const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+	unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
+#define SD_TS(x) do { __builtin_amdgcn_s_waitcnt(0); x = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SD_TS(x)
+#endif
+	sd_rs41_extract<COHERENT>(s, ring, mask, d, lane);
+	WAVE_SYNC();
+	SD_TS(ts1);
+	const int n = sd_rs41_deinterleave(s, flen, lane);
+	WAVE_SYNC();
+	SD_TS(ts2);
+	rs255_decode_pair(tabs, s, n, lane, swar);
+	SD_TS(ts3);
+	for (int c = 0; c < 2; c++) {
+		if (s.status[c] > 0) {
+			for (int kk = lane; kk < n; kk += 64) {
+				if (kk < RS_R) s.frame[8 + RS_R * c + kk] = s.cw[c][kk];
+				else s.frame[56 + 2 * (kk - RS_R) + c] = s.cw[c][kk];
+			}
+		}
+	}
+	WAVE_SYNC();
+	sd_rs41_write_record(s, d, fr, ch, lane);
 #ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
 	{
 		unsigned long long ts4;
