@@ -86,7 +86,7 @@ def parse_args():
     ap.add_argument("--wb-streams", type=int, default=1, help="--wideband: independent 10 MS/s streams processed per step")
     ap.add_argument("--wb-blocks", type=int, default=1, choices=(1, 2, 4, 8), help="--wideband: blocks of 1 280 000 samples (0.128 s) per submit")
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
-                    "4 for runs of fewer than 64 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
+                    "4 for runs of fewer than 16 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
                     "(profiles/r2_notes.md), inside the timed region: every 8th costs 0.6 %% of the step")
     ap.add_argument("--flags", type=int, default=None, help="SondeBatchConfig.flags (1: wide, 2: FEC as its own kernel, 4: pipelined class streams; "
                     "default 0, with --mix 4)")
@@ -403,7 +403,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
     if args.channels is None:
         args.channels = 4096 if args.mix else 1024
     if args.time_every is None:
-        args.time_every = 8 if args.steps >= 64 else 4
+        args.time_every = 8 if args.steps >= 16 else 4
     if args.flags is None:
         args.flags = FLAG_PIPELINE if args.mix else 0
     C, n = args.channels, args.tiles * 2048
