@@ -224,13 +224,16 @@ static void run_rounds(OrDemod *d)
 		for (int k = 0; k < K; k++) {
 			const int64_t t = d->t_next + (int64_t)k * d->period;
 			y[k] = interp(d, t);
-			m[k] = interp(d, t - (d->period >> 1));
+			m[k] = k < OR_ROUND_MAX ? interp(d, t - (d->period >> 1)) : 0.0f;
 		}
 		for (int k = 0; k < K; k++) {
 			/* Gardner term of symbol k uses the previous symbol of the same round; the first symbol of
 			 * every 64-symbol group contributes nothing (on the GPU a group is one wavefront, and this
 			 * keeps the detector free of cross-wave traffic: 1.6 % fewer terms in a 200-term average) */
-			if (k & 63) {
+			/* rounds of more than 256 symbols (two symbols per lane on the GPU): only the first 256 feed the detector --
+			 * 256 terms per 42.7 ms are plenty for a clock that drifts by ppm, and the second symbol of a lane then needs no
+			 * mid-symbol FIR at all (round 3: a quarter of the M10 class's FIR work) */
+			if ((k & 63) && k < OR_ROUND_MAX) {
 				const float a = y[k - 1] - y[k];
 				const float b = m[k] - d->bias;
 				float e = a * b;
@@ -262,7 +265,7 @@ static void run_rounds(OrDemod *d)
 			 * threshold): no level estimate; move the threshold to the mean so that the next round sees both levels */
 			d->bias = ((float)(S1 + S0) * or_recip((float)K)) * (1.0f / 4096.0f);
 		}
-		float err = ((float)E * or_recip((float)K)) * (1.0f / 1024.0f);
+		float err = ((float)E * or_recip((float)(K > OR_ROUND_MAX ? OR_ROUND_MAX : K))) * (1.0f / 1024.0f);   /* the symbols that fed the detector */
 		err = err * or_recip(d->amp * d->amp);
 		err = clampf(err, -1.0f, 1.0f);
 		const float kp = (float)d->m->period0 * 0.159154943f;   /* 0.5/pi of a symbol, Q16 samples */

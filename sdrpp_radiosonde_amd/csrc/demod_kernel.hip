@@ -501,12 +501,16 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 				const int64_t base = (n0 - IT - SD_LH) << 16;
 				const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)k * (uint32_t)period;
 				y = interp<NT>(s.A[b], s.B[b], s.taps, rel);          // 3.2 symbols of taps (8 at 2.5 samples per symbol)
-				m = interp<NT>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+				// only the first 256 symbols of a round feed the timing detector (SPEC 3.2): the second symbol of a lane needs no
+				// mid-symbol FIR -- a quarter of the FIR work of the two-symbols-per-lane classes (M10: VALU issue 72 -> 66 %)
+				if (h == 0) m = interp<NT>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
 			}
-			const float yprev = __shfl_up(y, 1, 64);
-			float e = (yprev - y) * (m - bias);
-			e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
-			Ei += (act && lane != 0) ? __float2int_rn(e) : 0;        // first symbol of a 64-group: no term (SPEC 3.2)
+			if (h == 0) {
+				const float yprev = __shfl_up(y, 1, 64);
+				float e = (yprev - y) * (m - bias);
+				e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
+				Ei += (act && lane != 0) ? __float2int_rn(e) : 0;    // first symbol of a 64-group: no term (SPEC 3.2)
+			}
 			const bool bit = act && (y > bias);
 			const int Y = __float2int_rn(sd_clamp(y, -8.0f, 8.0f) * 4096.0f);
 			S1i += bit ? Y : 0;
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			// mean of the round so that the next one sees both levels (SPEC 3.2)
 			st.bias = ((float)(S1 + S0) * sd_recip((float)K)) * (1.0f / 4096.0f);
 		}
-		const f32x2 den = {(float)K, st.amp * st.amp};
+		const f32x2 den = {(float)(K > SD_ROUND_MAX ? SD_ROUND_MAX : K), st.amp * st.amp};      // the symbols that fed the detector
 		const f32x2 rd = sd_recip2(den);
 		float err = ((float)E * rd.x) * (1.0f / 1024.0f);
 		err = err * rd.y;
