@@ -84,6 +84,7 @@ def parse_args():
     ap.add_argument("--sonde-type", type=int, default=0, help="all channels of this SONDE_* type (1 DFM09, 2 iMS-100, 3 M10; not the headline workload)")
     ap.add_argument("--wideband", action="store_true", help="BASELINE configs[3]: 10 MS/s IQ -> 512-bin channelizer -> per-bin demod+FEC")
     ap.add_argument("--wb-streams", type=int, default=1, help="--wideband: independent 10 MS/s streams processed per step")
+    ap.add_argument("--wb-overlap", action="store_true", help="--wideband: filter bank and decoder on two internal streams (consecutive submits may overlap)")
     ap.add_argument("--wb-blocks", type=int, default=1, choices=(1, 2, 4, 8), help="--wideband: blocks of 1 280 000 samples (0.128 s) per submit")
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
                     "4 for runs of fewer than 16 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
@@ -585,7 +586,7 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
 
     S = args.wb_streams
-    chan = SondeChannelizer(blocks_per_submit=args.wb_blocks, device=local_rank, n_streams=S)      # ONE object: every stage is one launch over all S streams
+    chan = SondeChannelizer(blocks_per_submit=args.wb_blocks, device=local_rank, n_streams=S, overlap=getattr(args, "wb_overlap", False))      # ONE object: every stage is one launch over all S streams
     nwb = chan.samples_per_submit
     bins_active = list(range(8, 504, 8))
     # a 1.024 s scene (8 blocks of 0.128 s) with 16 RS41 transmitters, cycled block by block so that the per-bin streams

@@ -237,6 +237,13 @@ uint32_t    sonde_chan_streams(const SondeChannelizer *c);
  * kernel of their own (then sonde_chan_read can return the rows: parity tests).  Call before the first submit; returns the mode
  * in force (1 fused, 0 not). */
 int         sonde_chan_set_fused(SondeChannelizer *c, int on);
+/* Option (fused mode only, off by default; also SONDE_CHAN_OVERLAP in the environment): the filter bank runs on an internal
+ * stream, the decoder on another, the bins are double-buffered, so the filter bank of submit k+1 may run beside the decoder
+ * of submit k.  The caller's stream is made to wait (on the device) for the filter bank only -- the last reader of the
+ * caller's block -- and the frames come with sonde_batch_sync / sonde_batch_frames_of on sonde_chan_batch() as always; the
+ * decoder is NOT ordered into the caller's stream.  Measured: +1-2 % at 8 streams x 4-8 blocks per submit, a loss at one
+ * stream.  Call before the first submit; returns the mode in force. */
+int         sonde_chan_set_overlap(SondeChannelizer *c, int on);
 void        sonde_chan_destroy(SondeChannelizer *c);
 uint32_t    sonde_chan_samples_per_submit(const SondeChannelizer *c);
 int         sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t n_samples, void *stream);

@@ -161,7 +161,7 @@ class SondeChannelizer:
     """Wideband front-end (BASELINE config 4): n_streams x 10 MS/s complex IQ -> 512 bins each -> per-bin decode; every stage
     is one launch over all streams.  submit() takes [samples_per_submit, 2] (one stream) or [n_streams, samples_per_submit, 2]."""
 
-    def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0, n_streams: int = 1, fused: bool | None = None):
+    def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0, n_streams: int = 1, fused: bool | None = None, overlap: bool | None = None):
         self.L = _lib.load()
         self._types = None
         self.n_streams = int(n_streams)
@@ -176,6 +176,8 @@ class SondeChannelizer:
         self.h = h
         # fused (default where possible): discriminator + resampler inside the decoder kernel; fused=False keeps the 48 kS/s rows (read())
         self.fused = bool(self.L.sonde_chan_set_fused(self.h, 1 if fused is None or fused else 0))
+        # overlap (an option, off by default): filter bank of submit k+1 beside the decoder of submit k, on internal streams
+        self.overlap = bool(self.L.sonde_chan_set_overlap(self.h, 1)) if overlap else False
         self.samples_per_submit = int(self.L.sonde_chan_samples_per_submit(self.h))
         self.n_steps = self.samples_per_submit // 250
         self.batch = SondeBatch.__new__(SondeBatch)          # borrowed view of the embedded 512-channel batch

@@ -216,12 +216,18 @@ static_assert(P8_WIN % 2 == 0 && (P8_S * CH_D) % 2 == 0, "16-byte staging loads"
 __global__ __launch_bounds__(P8_NT, 4) void sd_pfb8_kernel(const float2 *__restrict__ iq_all, size_t stream_stride,
                                                             const float2 *__restrict__ hist_in_all, float2 *__restrict__ hist_out_all,
                                                             const float *__restrict__ h, const float2 *__restrict__ tw,
-                                                            float2 *__restrict__ bins_all, uint32_t n_steps)
+                                                            float2 *__restrict__ bins_all, uint32_t n_steps, uint32_t xcd_map)
 {
 	__shared__ __attribute__((aligned(16))) float2 s_x[P8_WIN];
 	float2 *const s_tw = s_x + P8_S * PFB_FB;                 // written once the window is dead
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t m0 = blockIdx.x * P8_S, sidx = blockIdx.y;
+	// Workgroups go to the 8 XCDs round robin (linear id mod 8; gridDim.x is a multiple of 8): XCD x takes the x-th eighth of the
+	// block's step groups, so that the workgroups resident on one XCD are neighbours in time and the 5 x overlap of their
+	// windows is served by that XCD's L2 (in launch order neighbours sat on 8 different XCDs and every window came from HBM / MALL)
+	// Measured (tools/r3_pfb_xcd.sh): 8 streams 104 -> 97 us, one stream x 4 blocks 57 -> 51.5 us, but one stream x one block
+	// (640 workgroups: 1.25 generations) 21.0 -> 22.9 us: the host asks for it from two generations on (xcd_map).
+	const uint32_t grp = xcd_map ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+	const uint32_t m0 = grp * P8_S, sidx = blockIdx.y;
 	const float2 *iq = iq_all + (size_t)sidx * stream_stride;
 	const float2 *hist_in = hist_in_all + (size_t)sidx * CH_H;
 	float2 *bins = bins_all + (size_t)sidx * CH_M * n_steps;
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(P8_NT, 4) void sd_pfb8_kernel(const float2 *__restr
 #pragma unroll
 	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
 	__syncthreads();
-	if (blockIdx.x == gridDim.x - 1) {     // the last CH_H samples of [history | block] are the next submit's history
+	if (grp == gridDim.x - 1) {     // the last CH_H samples of [history | block] are the next submit's history
 		const float4 *tail = reinterpret_cast<const float4 *>(s_x + (P8_WIN - CH_H));
 		float4 *ho = reinterpret_cast<float4 *>(hist_out_all + (size_t)sidx * CH_H);
 		for (int i = tid; i < CH_H / 2; i += P8_NT) ho[i] = tail[i];
@@ -300,17 +306,27 @@ __global__ __launch_bounds__(P8_NT, 4) void sd_pfb8_kernel(const float2 *__restr
 #pragma unroll
 	for (int j = 0; j < 8; j++) s_x[(lane + 64 * j) * P8_OT + wave] = e0[j];
 	__syncthreads();
-	{
+#ifdef PFB_AB_ROWSTORE      // the first form of this phase: thread = bin, four 16-byte stores into its own row: every store
+	{                          // instruction touches 64 rows (40 KB apart), 16 bytes each
 		float2 o[P8_S];
 #pragma unroll
 		for (int j = 0; j < P8_S; j++) o[j] = s_x[tid * P8_OT + j];
 		float4 *dst = reinterpret_cast<float4 *>(bins + (size_t)tid * n_steps + m0);
-#ifdef PFB_AB_NOSTORE
-		if (o[0].x == 1.2345e-30f)
-#endif
 #pragma unroll
 		for (int j = 0; j < P8_S / 2; j++) dst[j] = make_float4(o[2 * j].x, o[2 * j].y, o[2 * j + 1].x, o[2 * j + 1].y);
 	}
+#else
+	// four lanes per bin row: a store instruction writes 16 whole 64-byte runs
+#pragma unroll
+	for (int k = 0; k < P8_S / 2; k++) {
+		const int idx = tid + P8_NT * k, bin = idx >> 2, part = idx & 3;
+		const float2 o0 = s_x[bin * P8_OT + 2 * part], o1 = s_x[bin * P8_OT + 2 * part + 1];
+#ifdef PFB_AB_NOSTORE
+		if (o0.x == 1.2345e-30f)
+#endif
+		*reinterpret_cast<float4 *>(bins + (size_t)bin * n_steps + m0 + 2 * part) = make_float4(o0.x, o0.y, o1.x, o1.y);
+	}
+#endif
 }
 
 // ---- PFB, third form (round 3; NOT the default: measured slower than the 8-step form, kept for the record and the A/B):
@@ -487,6 +503,17 @@ struct SondeChannelizer {
 	int pfb_form = 8;
 	hipStream_t last_stream = nullptr;     // a submit on another stream waits for the previous one (the state is carried)
 	hipEvent_t ev_xs = nullptr;
+	// overlapped form (an OPTION: SONDE_CHAN_OVERLAP / sonde_chan_set_overlap(c, 1); fused mode only): the filter bank runs on
+	// s_pfb, the decoder on s_dec, the bins are double-buffered, so that the filter bank of submit k+1 may run beside the decoder
+	// of submit k.  Measured (profiles/r3_notes.md): no gain at one stream (43.9 -> 48.9 us per block: the two kernels do not
+	// co-reside, two filter-bank workgroups take a CU's LDS, and the event hand-overs cost), +1-2 % at 8 streams x 4-8 blocks.
+	// The caller's stream only waits for the filter bank (the last reader of its block); results come with sonde_batch_sync.
+	uint32_t xcd_map = 0;                  // 8-step filter bank: XCD-aware step-group order (from two generations of workgroups on)
+	bool overlap = false;
+	hipStream_t s_pfb = nullptr, s_dec = nullptr;
+	hipEvent_t ev_in = nullptr, ev_pfb[2] = {}, ev_dec[2] = {};
+	float2 *d_bins_b = nullptr;            // the second bins buffer (allocated at the first overlapped submit)
+	float2 *d_bins_last = nullptr;         // the bins of the last submit (sonde_chan_read)
 	SondeBatch *batch = nullptr;
 	float2 *d_hist[2] = {}, *d_bins = nullptr, *d_tw = nullptr, *d_iqlast = nullptr;
 	float *d_h = nullptr, *d_g = nullptr, *d_dhist = nullptr, *d_out48 = nullptr;
@@ -546,6 +573,11 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 	sonde_batch_destroy(c->batch);
 	for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->ev_xs) (void)hipEventDestroy(c->ev_xs);
+	if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+	for (int i = 0; i < 2; i++) { if (c->ev_pfb[i]) (void)hipEventDestroy(c->ev_pfb[i]); if (c->ev_dec[i]) (void)hipEventDestroy(c->ev_dec[i]); }
+	if (c->s_pfb) (void)hipStreamDestroy(c->s_pfb);
+	if (c->s_dec) (void)hipStreamDestroy(c->s_dec);
+	(void)hipFree(c->d_bins_b);
 	(void)hipFree(c->d_hist[0]); (void)hipFree(c->d_hist[1]); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_iqlast);
 	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48); (void)hipFree(c->d_bins_in);
 	delete c;
@@ -562,6 +594,7 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 	c->n_streams = n_streams;
 	c->n_steps = 5120u * blocks_per_submit;                  // 5120 steps = 1.28 M wideband samples = 6144 samples at 48 kS/s
 	if (const char *e = getenv("SONDE_PFB_FORM")) c->pfb_form = (atoi(e) == 20 && n_streams == 1) ? 20 : (atoi(e) == 24 ? 24 : 8);
+	c->xcd_map = (c->n_steps / P8_S) % 8 == 0 && (size_t)(c->n_steps / P8_S) * n_streams > 1024 && !getenv("SONDE_PFB_NOXCD");
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
 	const size_t nb = (size_t)n_streams * CH_M;              // bins of all streams: the decoder batch's channels, stream-major
 	SondeBatchConfig cfg;
@@ -596,6 +629,7 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 		// fused unless a bin's sonde type needs 48 kS/s rows (AFSK) or the host asks for the rows (sonde_chan_set_fused, SONDE_CHAN_UNFUSED)
 		c->fused = sd_batch_bins_capable(c->batch) && !getenv("SONDE_CHAN_UNFUSED");
 		if (!c->fused && blocks_per_submit > 2) ok = false;      // (AFSK bins: the three-kernel form, 1-2 blocks per submit)
+		c->overlap = c->fused && getenv("SONDE_CHAN_OVERLAP");
 	}
 	if (!ok) { sonde_chan_destroy(c); return -1; }
 	*out = c;
@@ -617,6 +651,28 @@ extern "C" int sonde_chan_set_fused(SondeChannelizer *c, int on)
 	return c->fused ? 1 : 0;
 }
 
+// on = 1: filter bank and decoder on two internal streams, bins double-buffered, so that consecutive submits may overlap
+// (fused mode only); on = 0 (the default): both kernels in the caller's stream.  Before the first submit only.  Returns the mode.
+extern "C" int sonde_chan_set_overlap(SondeChannelizer *c, int on)
+{
+	if (!c) return -1;
+	if (c->n_blocks == 0) c->overlap = on && c->fused;
+	return c->overlap ? 1 : 0;
+}
+
+static bool chan_overlap_setup(SondeChannelizer *c)
+{
+	if (c->s_pfb) return true;
+	const size_t nb = (size_t)c->n_streams * CH_M;
+	bool ok = hipStreamCreateWithFlags(&c->s_pfb, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->s_dec, hipStreamNonBlocking) == hipSuccess &&
+	          hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess &&
+	          hipMalloc((void **)&c->d_bins_b, nb * c->n_steps * sizeof(float2)) == hipSuccess;
+	for (int i = 0; i < 2 && ok; i++)
+		ok = hipEventCreateWithFlags(&c->ev_pfb[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess &&
+		     hipEventCreateWithFlags(&c->ev_dec[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+	return ok;
+}
+
 extern "C" uint32_t sonde_chan_samples_per_submit(const SondeChannelizer *c) { return c ? c->n_steps * CH_D : 0; }
 extern "C" SondeBatch *sonde_chan_batch(SondeChannelizer *c) { return c ? c->batch : nullptr; }
 
@@ -636,6 +692,36 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 	}
 	const bool timed = !c->ev_pending && (c->n_submits++ % 8) == 0;
 	if ((uintptr_t)iq_dev & 15u) return -1;       // 16-byte loads straight from the caller's block(s)
+	c->overlap = c->overlap && c->fused;
+	if (c->overlap) {
+		if (!chan_overlap_setup(c)) return -1;
+		const int b = (int)(c->n_blocks & 1);
+		float2 *bins = b ? c->d_bins_b : c->d_bins;
+		// the block is ready where the caller's stream stands now; bins[b] is free once the decoder of two submits ago is done
+		if (hipEventRecord(c->ev_in, stream) != hipSuccess || hipStreamWaitEvent(c->s_pfb, c->ev_in, 0) != hipSuccess) return -1;
+		if (c->n_blocks >= 2 && hipStreamWaitEvent(c->s_pfb, c->ev_dec[b], 0) != hipSuccess) return -1;
+		if (timed) (void)hipEventRecord(c->ev[0], c->s_pfb);
+		if (c->pfb_form == 8)
+			hipLaunchKernelGGL(sd_pfb8_kernel, dim3(c->n_steps / P8_S, c->n_streams), dim3(P8_NT), 0, c->s_pfb, (const float2 *)iq_dev, n_samples,
+			                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map);
+		else if (c->pfb_form == 24)
+			hipLaunchKernelGGL(sd_pfbp_kernel, dim3((c->n_steps / P8_S + PP_G - 1) / PP_G, c->n_streams), dim3(PP_NT), 0, c->s_pfb, (const float2 *)iq_dev, n_samples,
+			                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, bins, c->n_steps);
+		else
+			hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / PFB_S), dim3(PFB_NT), 0, c->s_pfb, (const float2 *)iq_dev, c->d_hist[c->n_blocks & 1],
+			                   c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, bins, c->n_steps);
+		c->n_blocks++;
+		c->d_bins_last = bins;
+		if (timed) { (void)hipEventRecord(c->ev[1], c->s_pfb); (void)hipEventRecord(c->ev[2], c->s_pfb); c->ev_pending = true; }
+		if (hipEventRecord(c->ev_pfb[b], c->s_pfb) != hipSuccess) return -1;
+		// the filter bank is the last reader of the caller's block: work queued on the caller's stream behind this submit may
+		// overwrite it; the decoder waits for the bins on its own stream
+		if (hipStreamWaitEvent(stream, c->ev_pfb[b], 0) != hipSuccess || hipStreamWaitEvent(c->s_dec, c->ev_pfb[b], 0) != hipSuccess) return -1;
+		if (hipGetLastError() != hipSuccess) return -1;
+		c->last_stream = stream;
+		if (sd_batch_submit_bins(c->batch, bins, c->n_steps, c->n_steps, c->d_bins_in, (void *)c->s_dec) != 0) return -1;
+		return hipEventRecord(c->ev_dec[b], c->s_dec) == hipSuccess ? 0 : -1;
+	}
 	// the front-end kernels carry state too (window history, discriminator history): a submit on another stream waits for
 	// the previous one BEFORE the filter bank starts (sonde_batch_submit orders only the decoder behind them)
 	if (c->n_blocks && stream != c->last_stream) {
@@ -648,11 +734,12 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		                   c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
 	else if (c->pfb_form == 8)
 		hipLaunchKernelGGL(sd_pfb8_kernel, dim3(c->n_steps / P8_S, c->n_streams), dim3(P8_NT), 0, stream, (const float2 *)iq_dev, n_samples,
-		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
+		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps, c->xcd_map);
 	else
 		hipLaunchKernelGGL(sd_pfbp_kernel, dim3((c->n_steps / P8_S + PP_G - 1) / PP_G, c->n_streams), dim3(PP_NT), 0, stream, (const float2 *)iq_dev, n_samples,
 		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps);
 	c->n_blocks++;
+	c->d_bins_last = c->d_bins;
 	if (timed) (void)hipEventRecord(c->ev[1], stream);
 	if (!c->fused)
 		hipLaunchKernelGGL(sd_disc_resamp_kernel, dim3(CH_M * c->n_streams), dim3(256), (RS_TAPS + c->n_steps) * sizeof(float), stream,
@@ -692,7 +779,7 @@ extern "C" int sonde_chan_read(SondeChannelizer *c, float *bins /* [512][n_steps
 	if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
 	const size_t nb = (size_t)c->n_streams * CH_M;
-	if (bins && hipMemcpy(bins, c->d_bins, nb * c->n_steps * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if (bins && hipMemcpy(bins, c->d_bins_last ? c->d_bins_last : c->d_bins, nb * c->n_steps * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	if (out48 && c->fused) return -1;      // the rows are never materialised in fused mode: sonde_chan_set_fused(c, 0) before the first submit
 	if (out48 && hipMemcpy(out48, c->d_out48, nb * n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return 0;

@@ -228,3 +228,42 @@ def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
     assert chz.batch.nbits(c7) == len(rb) > 4000 and np.array_equal(chz.batch.read_bits(c7, len(rb) - 4000, 4000), rb[-4000:])
     st, rs = chz.batch.state(c7), dec[7].state()
     assert (st["t_next"], st["period"]) == (rs["t_next"], rs["period"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams", [1, 2])
+def test_overlapped_submits_equal_serial(streams):
+    """The fused channelizer can overlap consecutive submits (option: filter bank on one internal stream, decoder on another,
+    two bins buffers).  A host that keeps two submits in flight, and refills ONE staging block on its stream right behind
+    each submit (the library makes that stream wait for the filter bank, the block's last reader), gets the frames of the
+    serial mode (both kernels in the caller's stream, frames fetched after every submit: what the oracle test above checks)."""
+    import torch
+    from sdrpp_radiosonde_amd.batch import SondeChannelizer
+    bins_active = [9, 130, 257, 500]
+    NBLK = 10
+    scenes = [synth.make_wideband_rs41(bins_active, NBLK * BLOCK, seed=60 + s, ebn0_db=33.0, device="cuda:0")[0] for s in range(streams)]
+    blocks = [torch.stack([sc[b * BLOCK: (b + 1) * BLOCK] for sc in scenes]).contiguous() if streams > 1 else scenes[0][b * BLOCK: (b + 1) * BLOCK].contiguous()
+              for b in range(NBLK)]
+    ser = SondeChannelizer(n_streams=streams)
+    assert ser.fused and not ser.overlap
+    want = []
+    for blk in blocks:
+        ser.submit(blk)
+        want.append(ser.frames())
+    ser.close()
+    assert sum(len(w) for w in want) >= len(bins_active) * streams
+    ovl = SondeChannelizer(n_streams=streams, overlap=True)
+    assert ovl.fused and ovl.overlap
+    stage = torch.empty_like(blocks[0])
+    st = torch.cuda.current_stream().cuda_stream
+    ovl.batch.ticket()                                  # per-submit completion events from here on
+    got = []
+    for b, blk in enumerate(blocks):
+        stage.copy_(blk)                                # overwrites the block of the previous submit, in stream order
+        ovl.submit(stage, st)
+        if b >= 1:
+            got.append(ovl.batch.frames_of(b))          # the frames of the submit before this one (tickets count from 1)
+    got.append(ovl.batch.frames_of(NBLK))
+    ovl.close()
+    for b in range(NBLK):
+        assert got[b].tobytes() == want[b].tobytes(), b
