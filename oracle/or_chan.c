@@ -65,6 +65,30 @@ void or_resamp_taps(int up, double fs_up_hz, double cutoff_hz, float *g /* up * 
 }
 void or_chan_resamp_taps(float *g /* 6*16 */) { or_resamp_taps(OR_RS_L, 240000.0, 18000.0, g); }
 
+/* SPEC 3.5b (round 3): behind the channelizer the 6/5 resampler and the boxcar decimator of SPEC 3.0 (4:1 or 2:1) are ONE
+ * polyphase filter when the product runs them inside the decoder kernel (its default, "fused" mode): decimated sample n of a
+ * block is z[n] = sum_k fmaf(G[n mod 3][k], d[b(n) - k], acc), k = 0 .. KT-1 ascending, b(n) = floor(5 (dec n + dec - 1) / 6)
+ * the newest discriminator sample it reads, KT = 19 (4:1) or 17 (2:1), and the composite row
+ * G[phi][k] = (float)((1/dec) sum_{i < dec} g[5 j mod 6][k - (b - floor(5 j / 6))], j = dec phi + i, terms outside 0..15 dropped)
+ * summed in double from the float taps g.  (The rows repeat every 3 decimated samples: 12 or 6 resampler outputs, 10 or 5
+ * discriminator samples.)  It is the same filter as "resample, then average" up to rounding -- 19 multiply-adds per decimated
+ * sample instead of 64 -- and no 48 kS/s row exists. */
+int or_chan_composite_kt(int dec) { return dec == 4 ? 19 : 17; }
+void or_chan_composite_taps(const float *g /* 6*16 */, int dec, float *G /* 3 * OR_RS_KT_LD (20) */)
+{
+	for (int phi = 0; phi < 3; phi++) {
+		const int j0 = dec * phi, b = (5 * (j0 + dec - 1)) / 6;
+		for (int k = 0; k < OR_RS_KT_LD; k++) {
+			double sum = 0.0;
+			for (int i = 0; i < dec; i++) {
+				const int j = j0 + i, t = k - (b - (5 * j) / 6);
+				if (t >= 0 && t < OR_RS_T) sum += (double)g[((5 * j) % 6) * OR_RS_T + t];
+			}
+			G[phi * OR_RS_KT_LD + k] = (float)(sum / (double)dec);
+		}
+	}
+}
+
 /* ---- VFO front-end (SURVEY 8 rows a1 + a2 at the reference's own rates): what sits between the VFO and the decoder in
  * /root/reference/src/main.cpp:55-60 -- IQ at the sonde type's VFO bandwidth (supportedTypes[], main.hpp:44-52: 10, 15, 20
  * or 50 kS/s) -> dsp::demod::FM -> dsp::RationalResampler to 48 kS/s (24/5, 16/5, 12/5, 24/25).  Cutoff: 0.45 of the
@@ -165,6 +189,13 @@ void or_chan_free(OrChan *c) { if (c) { free(c->hist); free(c); } }
  * if out48 != NULL, n_steps*6/5 real samples at 48 kS/s ([512][n_steps*6/5]); n_steps % 5 == 0. */
 void or_chan_block(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48)
 {
+	or_chan_block2(c, iq, n_steps, bins, out48, NULL, NULL);
+}
+
+/* The same, plus (decs != NULL) the decimated rows of SPEC 3.5b: bin k with decs[k] = 2 or 4 gets n_steps*6/5/decs[k] samples
+ * at outdec[k * (n_steps*6/5/2)] (row stride: the 2:1 length); decs[k] = 0 skips the bin. */
+void or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48, const uint8_t *decs, float *outdec)
+{
 	const size_t H = OR_CH_L - OR_CH_D, N = n_steps * OR_CH_D;
 	float *buf = malloc(2 * (H + N) * sizeof(float));
 	memcpy(buf, c->hist, 2 * H * sizeof(float));
@@ -192,18 +223,33 @@ void or_chan_block(OrChan *c, const float *iq, size_t n_steps, float *bins, floa
 	}
 	memcpy(c->hist, buf + 2 * N, 2 * H * sizeof(float));   /* last L-D samples of [hist|block] */
 	free(buf);
-	if (out48) {
+	if (out48 || (decs && outdec)) {
 		const size_t n_out = n_steps * OR_RS_L / OR_RS_M;
 		float *d = malloc((OR_RS_T + n_steps) * sizeof(float));
+		float G2[3 * OR_RS_KT_LD], G4[3 * OR_RS_KT_LD];
+		or_chan_composite_taps(c->g, 2, G2);
+		or_chan_composite_taps(c->g, 4, G4);
 		for (int k = 0; k < OR_CH_M; k++) {
 			memcpy(d, c->dhist[k], OR_RS_T * sizeof(float));
 			or_discriminate(bl + (size_t)k * n_steps * 2, n_steps, d + OR_RS_T, c->iq_last[k]);
-			for (size_t j = 0; j < n_out; j++) {
+			for (size_t j = 0; out48 && j < n_out; j++) {
 				const size_t i0 = (j * OR_RS_M) / OR_RS_L;
 				const int p = (int)((j * OR_RS_M) % OR_RS_L);
 				float acc = 0.0f;
 				for (int t = 0; t < OR_RS_T; t++) acc = fmaf(c->g[p * OR_RS_T + t], d[OR_RS_T + i0 - t], acc);
 				out48[(size_t)k * n_out + j] = acc;
+			}
+			if (decs && outdec && decs[k]) {
+				const size_t dec = decs[k];
+				const float *G = dec == 4 ? G4 : G2;
+				const int kt = or_chan_composite_kt((int)dec);
+				for (size_t n = 0; n < n_out / dec; n++) {
+					const size_t b = (5 * (dec * n + dec - 1)) / 6;
+					const float *row = G + (n % 3) * OR_RS_KT_LD;
+					float acc = 0.0f;
+					for (int t = 0; t < kt; t++) acc = fmaf(row[t], d[OR_RS_T + b - t], acc);      /* b - t >= -16: the carried history */
+					outdec[(size_t)k * (n_out / 2) + n] = acc;
+				}
 			}
 			memcpy(c->dhist[k], d + n_steps, OR_RS_T * sizeof(float));
 		}

@@ -382,7 +382,7 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 	const int dec = d->m->decim, it = OR_TILE / dec;
 	float tile[OR_TILE], z[2 * OR_TILE];
 	for (size_t off = 0; off + OR_TILE <= n; off += OR_TILE) {
-		if (is_iq) {
+		if (is_iq == 1) {
 			const float *x = src + 2 * off;
 			if (dec == 4) {
 				for (int m = 0; m < it; m++) {
@@ -399,6 +399,10 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 			} else {
 				or_discriminate(x, (size_t)it, tile, d->iq_last);
 			}
+		} else if (is_iq == 2) {
+			/* real input already decimated by this type's factor (SPEC 3.5b: the channelizer's composite filter): n still
+			 * counts 48 kS/s samples, src holds n / dec */
+			memcpy(tile, src + off / (size_t)dec, sizeof(float) * (size_t)it);
 		} else {
 			const float *x = src + off;
 			if (dec == 4) {

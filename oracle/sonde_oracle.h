@@ -142,6 +142,7 @@ size_t     or_batch_run(int type, const float *iq, size_t nch, size_t n, int nth
 #define OR_RS_L    6            /* resampler: up 6 */
 #define OR_RS_M    5            /*            down 5 : 40 kS/s -> 48 kS/s */
 #define OR_RS_T    16           /* taps per resampler phase */
+#define OR_RS_KT_LD 20          /* row stride of the composite (resampler + boxcar) taps, SPEC 3.5b: 19 or 17 in use */
 typedef struct OrChan OrChan;
 void    or_chan_proto(float *h);
 void    or_chan_twiddles(float *tw);
@@ -157,6 +158,9 @@ void    or_fft512(float *re, float *im, const float *tw);
 OrChan *or_chan_new(void);
 void    or_chan_free(OrChan *c);
 void    or_chan_block(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48);
+void    or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48, const uint8_t *decs, float *outdec);
+int     or_chan_composite_kt(int dec);
+void    or_chan_composite_taps(const float *g, int dec, float *G /* 3 * OR_RS_KT_LD */);
 
 /* ---- post-FEC derived values, restating /root/reference/src/decode/decoder.hpp:132-174 ---- */
 float or_dewpt(float temp, float rh);

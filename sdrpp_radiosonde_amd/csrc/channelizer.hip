@@ -516,7 +516,7 @@ struct SondeChannelizer {
 	float2 *d_bins_last = nullptr;         // the bins of the last submit (sonde_chan_read)
 	SondeBatch *batch = nullptr;
 	float2 *d_hist[2] = {}, *d_bins = nullptr, *d_tw = nullptr, *d_iqlast = nullptr;
-	float *d_h = nullptr, *d_g = nullptr, *d_dhist = nullptr, *d_out48 = nullptr;
+	float *d_h = nullptr, *d_g = nullptr, *d_gc = nullptr, *d_dhist = nullptr, *d_out48 = nullptr;
 	// kernel timing (HIP events on the submit stream), sampled: every 8th submit
 	hipEvent_t ev[3] = {};
 	unsigned long n_submits = 0, n_blocks = 0;
@@ -524,6 +524,24 @@ struct SondeChannelizer {
 	int n_timed = 0;
 	bool ev_pending = false;
 };
+
+// SPEC 3.5b: the 6/5 resampler and the decoder's boxcar decimator (dec = 2 or 4) as one polyphase filter: row phi = n mod 3 of
+// decimated sample n, tap k against d[b(n) - k], b(n) = floor(5 (dec n + dec - 1) / 6): the mean of the dec resampler rows
+// involved, each shifted by how much older its newest input is, summed in double (oracle/or_chan.c or_chan_composite_taps)
+static void composite_rows(const std::vector<float> &g, int dec, float *G /* 3 * SD_RS_KT_LD */)
+{
+	for (int phi = 0; phi < 3; phi++) {
+		const int newest = (5 * (dec * phi + dec - 1)) / 6;
+		for (int k = 0; k < SD_RS_KT_LD; k++) {
+			double acc = 0.0;
+			for (int j = dec * phi; j < dec * phi + dec; j++) {
+				const int t = k - (newest - (5 * j) / 6);
+				if (t >= 0 && t < RS_TAPS) acc += (double)g[((5 * j) % RS_UP) * RS_TAPS + t];
+			}
+			G[phi * SD_RS_KT_LD + k] = (float)(acc / (double)dec);
+		}
+	}
+}
 
 static void make_tables(std::vector<float> &h, std::vector<float> &tw, std::vector<float> &g)
 {
@@ -579,7 +597,7 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 	if (c->s_dec) (void)hipStreamDestroy(c->s_dec);
 	(void)hipFree(c->d_bins_b);
 	(void)hipFree(c->d_hist[0]); (void)hipFree(c->d_hist[1]); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_iqlast);
-	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48); (void)hipFree(c->d_bins_in);
+	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48); (void)hipFree(c->d_bins_in); (void)hipFree(c->d_gc);
 	delete c;
 }
 
@@ -624,8 +642,12 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 	for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence) == hipSuccess;     // timing only, same device
 	ok = ok && hipEventCreateWithFlags(&c->ev_xs, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
 	if (ok) {
-		const SdBinsIn bi = { c->d_g, reinterpret_cast<float *>(c->d_iqlast), c->d_dhist };
-		ok = hipMalloc((void **)&c->d_bins_in, sizeof(bi)) == hipSuccess && hipMemcpy(c->d_bins_in, &bi, sizeof(bi), hipMemcpyHostToDevice) == hipSuccess;
+		float gc[2 * 3 * SD_RS_KT_LD];
+		composite_rows(g, 2, gc);
+		composite_rows(g, 4, gc + 3 * SD_RS_KT_LD);
+		ok = hipMalloc((void **)&c->d_gc, sizeof(gc)) == hipSuccess && hipMemcpy(c->d_gc, gc, sizeof(gc), hipMemcpyHostToDevice) == hipSuccess;
+		const SdBinsIn bi = { c->d_gc, reinterpret_cast<float *>(c->d_iqlast), c->d_dhist };
+		ok = ok && hipMalloc((void **)&c->d_bins_in, sizeof(bi)) == hipSuccess && hipMemcpy(c->d_bins_in, &bi, sizeof(bi), hipMemcpyHostToDevice) == hipSuccess;
 		// fused unless a bin's sonde type needs 48 kS/s rows (AFSK) or the host asks for the rows (sonde_chan_set_fused, SONDE_CHAN_UNFUSED)
 		c->fused = sd_batch_bins_capable(c->batch) && !getenv("SONDE_CHAN_UNFUSED");
 		if (!c->fused && blocks_per_submit > 2) ok = false;      // (AFSK bins: the three-kernel form, 1-2 blocks per submit)

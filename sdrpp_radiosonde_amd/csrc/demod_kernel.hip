@@ -67,7 +67,7 @@ struct DemodLds {
 	// what the lead round wave (wave 0) computes once per round and the other round waves pick up:
 	// the PI loop filter runs on one wave instead of four (it is ~35 % of a round wave's VALU work)
 	struct { long long t_next; int period; float bias; int K; unsigned flag; unsigned long long wpos; } pub;
-	alignas(16) float rs_g[96];                         // SD_IN_BINS: the 6 x 16 taps of the 6/5 resampler; rs_dh: the 16 carried discriminator samples
+	alignas(16) float rs_g[64];                         // SD_IN_BINS: the 3 x 20 composite taps (SPEC 3.5b); rs_dh: the 16 carried discriminator samples
 	float rs_dh[16];
 	uint32_t mirror[SD_MIRROR_WORDS];       // the newest 2048 bits of the bit ring, for the in-kernel sync search (K4)
 	SdSyncRun k4;                           // K4's state between steps (wave 3 only)
@@ -80,6 +80,12 @@ __device__ __forceinline__ void store_pair(DemodLds &s, int b, uint32_t i, float
 	*reinterpret_cast<float2 *>(&s.A[b][SD_LH + i]) = make_float2(d0, d1);
 	s.B[b][SD_LH + i - 1] = d0;
 	s.B[b][SD_LH + i] = d1;
+}
+
+// v of the lane below, lane 0: `first` (DPP wave_shr:1, GFX9; lanes without a source keep the old value)
+__device__ __forceinline__ float sd_wave_shr1(float v, float first)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
 }
 
 // one sample i of a tile into buffer b
@@ -200,7 +206,9 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	if (is_k) {
 		if (BINS) {
 			load_bins(0, wa);
+#ifdef BINS_AB_TWOSETS
 			if (n_tiles > 1) load_bins(1, wb);
+#endif
 		} else {
 			load_vec(0, va);
 			if (n_tiles > 1) load_vec(1, vb);
@@ -376,102 +384,87 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		if (IS_IQ) last_iq = make_float2(cx, cy);      // wave 7: the last (decimated) sample of the tile
 	};
 
-	// SD_IN_BINS: discriminator at 40 kS/s into a wave-private LDS scratch, then the 6/5 polyphase resampler evaluated where
-	// the decimated samples of this wave need it, the boxcar average of the real-input path (SPEC 3.0), straight into buffer b.
-	// Scratch: the part of a tile buffer a decimated tile never uses (DEC 4: 580 of 2116 floats, DEC 2: 1092), one buffer per wave.
-	// plus a 512-float staging row for the resampler's outputs.  Wave 3 of a 4:1 instantiation shares B[1] with the FEC tables
-	// (at 1100): its scratch sits at B[1][600..1048), its staging row in A[0][584..1096).
+	// SD_IN_BINS: discriminator at 40 kS/s into a wave-private LDS scratch, then the composite resampler + decimator (SPEC 3.5b)
+	// straight into buffer b.  Scratch: the part of a tile buffer a decimated tile never uses (DEC 4: from 584, DEC 2: from 1096),
+	// one buffer per wave, 476 floats read (written: 457).  Wave 3 of a 4:1 instantiation shares B[1] with the FEC tables (at 1100):
+	// its scratch sits at B[1][600..1076).
 	float *const bscr = !BINS ? nullptr : (kw == 0 ? &s.A[0][1100] : kw == 1 ? &s.A[1][1100] : kw == 2 ? &s.B[0][1100] : &s.B[1][DEC == 4 ? 600 : 1100]);
-	float *const bstg = !BINS ? nullptr : (kw == 0 ? &s.A[0][1548] : kw == 1 ? &s.A[1][1548] : kw == 2 ? &s.B[0][1548] : (DEC == 4 ? &s.A[0][584] : &s.B[1][1548]));
 	static_assert(!BINS || DEC == 4 || DEC == 2, "the bins path needs the free part of a decimated tile buffer");
-	static_assert(SD_LH + SD_TILE / 2 + 4 <= 1100 && 1100 + 64 * NB2 <= 1548 && 1548 + 512 <= SD_BUF && 600 + 64 * NB2 <= SD_EPI_TAB_OFF &&
-	              SD_LH + SD_TILE / 4 + 4 <= 584 && 584 + 512 <= 1100 && (1548 % 4) == 0 && (584 % 4) == 0, "scratch and staging regions");
+	static_assert(SD_LH + SD_TILE / 2 + 4 <= 1100 && 1100 + 10 * 45 + 26 <= SD_BUF && 600 + 10 * 45 + 26 <= SD_EPI_TAB_OFF && 9 + 64 * NB2 <= 10 * 45 + 26 &&
+	              SD_LH + SD_TILE / 4 + 4 <= 600, "scratch regions");
 	float2 bins_last = make_float2(0.0f, 0.0f);
 	if (BINS && is_k) {
-		// the resampler's taps: every discriminator wave writes the same 96 values (identical stores may race), then reads them
-		// behind its own stores; the first wave of the block also needs the carried history
-		const float gv0 = bins_in->g[lane], gv1 = lane < 32 ? bins_in->g[64 + lane] : 0.0f;
-		s.rs_g[lane] = gv0;
-		if (lane < 32) s.rs_g[64 + lane] = gv1;
+		// the composite taps of this decimation (3 rows of 20): every discriminator wave writes the same 60 values (identical
+		// stores may race), then reads them behind its own stores; the first wave of the block also needs the carried history
+		if (lane < 3 * SD_RS_KT_LD) s.rs_g[lane] = bins_in->g[(DEC == 4 ? 3 * SD_RS_KT_LD : 0) + lane];
 		if (kw == 0) {
 			if (lane < 16) s.rs_dh[lane] = bins_in->dhist[(size_t)ch * 16 + lane];
 			bins_last = reinterpret_cast<const float2 *>(bins_in->iq_last)[ch];
 		}
 	}
-	auto k1_bins = [&](int b, int tile, const float2 (&w)[NB2]) {
-		const int ilo = bins_ilo(tile);
+	auto k1_bins = [&](int b, int tile, float2 (&w)[NB2]) {
 		const bool first = tile == 0 && kw == 0;                 // wave-uniform: the block's first wave (ilo = -15)
+		// the scratch holds d[10 a_grp - 16 ..]: load element e is d[ilo - 1 + e], ilo - 1 = 10 a_grp - 16 + shift, shift = floor(5 r / 6) <= 9
+		const uint32_t J0 = 2048u * (uint32_t)tile + 512u * (uint32_t)kw;
+		const uint32_t a_grp = J0 / 12u;
+		const int shift = (int)((5u * (J0 - 12u * a_grp)) / 6u);
 		float cx = 0.0f, cy = 0.0f;
 #pragma unroll
 		for (int q = 0; q < NB2; q++) {
-			float px = __shfl_up(w[q].x, 1, 64), py = __shfl_up(w[q].y, 1, 64);
-			if (lane == 0) { px = cx; py = cy; }
+			// lane l takes lane l - 1's sample, lane 0 the carry: one DPP move each (wave_shr:1; __shfl_up is a ds_bpermute)
+			float px = sd_wave_shr1(w[q].x, cx), py = sd_wave_shr1(w[q].y, cy);
 			if (q == 0 && first && lane == 16) { px = bins_last.x; py = bins_last.y; }      // element 16 is x[0]: its predecessor is carried
 			float d = sd_disc(w[q].x, w[q].y, px, py);
 			if (q == 0 && first && lane < 16) d = s.rs_dh[lane];                             // elements 1..15 are d[-15..-1]: carried
-			bscr[lane + 64 * q] = d;
+			bscr[shift + lane + 64 * q] = d;
 			cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[q].x), 63));
 			cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[q].y), 63));
 		}
+#ifndef BINS_AB_TWOSETS
+		// the bin samples are consumed: the next tile's go out into the same registers now (ONE register set: with two, tiles
+		// requested two phases ahead as in the HBM-bound instantiations, the 80-VGPR allocation spilled inside this loop)
+		if (tile + 1 < n_tiles) load_bins(tile + 1, w);
+#endif
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		// The resampler: lane <-> m computes the six outputs j = 6 m + c, c = 0..5: tap row p_c = 5c mod 6 (the same for every
-		// lane: broadcast LDS reads) against d[5 m + floor(5c/6) - t], i.e. 20 consecutive d's per lane, read from LDS once (lanes 5 floats
-		// apart: conflict-free) and indexed statically.  (One lane per output with 32 lane-dependent LDS reads each -- and a
-		// phase-major variant with 16 -- were LDS-bound: 110-118 us for 4096 bins x 3 tiles against 56 + 58 us for the two kernels
-		// this replaces; profiles/r3_notes.md.)  The outputs pass through a wave-private staging row so that the
-		// boxcar average of the real-input path (SPEC 3.0) finds its DEC consecutive outputs in one aligned read.
+		// SPEC 3.5b: resampler and boxcar decimator as ONE polyphase filter, z[n] = sum_k fmaf(G[n mod 3][k], d[b(n) - k], acc),
+		// k < KT ascending, b(n) = floor(5 (DEC n + DEC - 1) / 6).  Lane <-> group u: the NC decimated samples n = NC u + c that
+		// the ten discriminator samples d[10 u .. 10 u + 9] complete (12 resampler outputs: 3 samples at 4:1, 6 at 2:1); it
+		// reads d[10 u - 16 .. 10 u + 9] from LDS once (13 eight-byte reads, lanes 40 bytes apart) and indexes them
+		// statically; the tap row of sample c is the same for every lane: broadcast reads.  19 (17) multiply-adds per
+		// decimated sample where "resample, then average" took 64 (32) plus a staging row: profiles/r3_notes.md.
 		constexpr int PER_WAVE = SD_TILE / DEC / 4;              // decimated samples a wave produces per tile: 128 (4:1) or 256 (2:1)
-		const uint32_t J0 = 2048u * (uint32_t)tile + 512u * (uint32_t)kw;
-		const uint32_t m_lo = J0 / 6u;
-#pragma unroll 1                 // (unrolled: 3.6 x slower -- 1.12 against 0.31 ms for 4096 bins x 12 tiles: the second pass's operands spill)
-		for (int a = 0; a < 2; a++) {
-			uint32_t m = m_lo + (uint32_t)lane + 64u * a;
-			if (6u * m >= J0 + 512u) m = m_lo;                                   // no output of this wave: stay inside the scratch
-			// the six outputs of this m read d[5m - 15 .. 5m + 4]: 20 LDS reads per lane instead of 96
-			const float *dp = &bscr[(int)(5u * m) - 15 - (ilo - 1)];
-			float dv[20];
+		constexpr int NC = 12 / DEC, KT = DEC == 4 ? 19 : 17;
+		const uint32_t N0 = J0 / (uint32_t)DEC;
+		{
+			const int ul = lane < 45 ? lane : 45;                                // 43-44 groups carry outputs of this wave
+			const float2 *dp = reinterpret_cast<const float2 *>(bscr + 10 * ul);
+			float dv[26];
 #pragma unroll
-			for (int k = 0; k < 20; k++) dv[k] = dp[k];
+			for (int k = 0; k < 13; k++) { const float2 t2 = dp[k]; dv[2 * k] = t2.x; dv[2 * k + 1] = t2.y; }
 #pragma unroll
-			for (int c = 0; c < 6; c++) {
-				const int pc = (5 * c) % 6, fc = (5 * c) / 6;
-				// the tap row from LDS, one address for the whole wave, read OUTSIDE the divergent part (as global loads the
-				// compiler put them behind vmcnt(0) inside it: a memory round trip per phase that also drained the tile prefetch)
-				float gt[16];
+			for (int c = 0; c < NC; c++) {
+				constexpr int BO4[3] = {2, 5, 9}, BO2[6] = {0, 2, 4, 5, 7, 9};
+				const int bo = (DEC == 4 ? BO4[c % 3] : BO2[c]) + 16;          // dv index of d[b(n)]
+				float gt[20];
 #pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const float4 g4 = *reinterpret_cast<const float4 *>(&s.rs_g[16 * pc + 4 * q]);
+				for (int q = 0; q < 5; q++) {
+					const float4 g4 = *reinterpret_cast<const float4 *>(&s.rs_g[SD_RS_KT_LD * (c % 3) + 4 * q]);
 					gt[4 * q] = g4.x; gt[4 * q + 1] = g4.y; gt[4 * q + 2] = g4.z; gt[4 * q + 3] = g4.w;
 				}
 				float acc = 0.0f;
 #pragma unroll
-				for (int t = 0; t < 16; t++) acc = __builtin_fmaf(gt[t], dv[15 + fc - t], acc);
-				const uint32_t jr = 6u * m + (uint32_t)c - J0;                   // output index inside the wave's span (wraps below J0)
-				if (jr < 512u) bstg[jr] = acc;
+				for (int t = 0; t < KT; t++) acc = __builtin_fmaf(gt[t], dv[bo - t], acc);
+				const uint32_t jr = (uint32_t)NC * (a_grp + (uint32_t)ul) + (uint32_t)c - N0;      // index inside the wave's span (wraps below N0)
+				if (jr < (uint32_t)PER_WAVE && lane < 45) store_one(s, b, (uint32_t)PER_WAVE * (uint32_t)kw + jr, acc);
 			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-#pragma unroll
-		for (int h = 0; h < PER_WAVE / 64; h++) {
-			const uint32_t n = (uint32_t)lane + 64u * h;
-			float z;
-			if (DEC == 4) {
-				const float4 o = *reinterpret_cast<const float4 *>(&bstg[4u * n]);
-				z = ((o.x + o.y) + (o.z + o.w)) * 0.25f;
-			} else {
-				const float2 o = *reinterpret_cast<const float2 *>(&bstg[2u * n]);
-				z = (o.x + o.y) * 0.5f;
-			}
-			store_one(s, b, (uint32_t)PER_WAVE * (uint32_t)kw + n, z);
 		}
 		if (tile == n_tiles - 1 && kw == 3) {
 			// the block's last wave: carry the last 16 discriminator samples and the last bin sample to the next submit
 			// (read by the first wave at the top of the next launch; every barrier of this launch lies in between)
 			// for this wave J0 = n_out - 512, so ilo = bins_n - 442: x[bins_n - 1] is element 442 (lane 58 of load 6), d[bins_n - 16] element 427
 			constexpr int E_LAST = 442;
-			if (lane < 16) bins_in->dhist[(size_t)ch * 16 + lane] = bscr[E_LAST - 15 + lane];
+			if (lane < 16) bins_in->dhist[(size_t)ch * 16 + lane] = bscr[shift + E_LAST - 15 + lane];
 			if (lane == (E_LAST & 63)) reinterpret_cast<float2 *>(bins_in->iq_last)[ch] = w[E_LAST >> 6];
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -618,10 +611,17 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	};
 	if (is_k) {
 		// register set A holds the even tiles, set B the odd ones (the arguments are literals at every call: static register sets)
+#ifdef BINS_AB_TWOSETS
 		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, va, pa, qa); };
 		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wb); else k1_tile(b, vb, pb, qb); };
 		auto ldA = [&](int tile) { if constexpr (BINS) load_bins(tile, wa); else load_tile(tile, va, pa, qa); };
 		auto ldB = [&](int tile) { if constexpr (BINS) load_bins(tile, wb); else load_tile(tile, vb, pb, qb); };
+#else
+		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, va, pa, qa); };
+		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, vb, pb, qb); };
+		auto ldA = [&](int tile) { if constexpr (!BINS) load_tile(tile, va, pa, qa); };
+		auto ldB = [&](int tile) { if constexpr (!BINS) load_tile(tile, vb, pb, qb); };
+#endif
 		if (!BINS) {
 			load_prev(0, pa, qa);          // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
 			if (n_tiles > 1) load_prev(1, pb, qb);

@@ -73,6 +73,8 @@ def lib():
     L.or_chan_new.restype = C.c_void_p
     L.or_chan_free.argtypes = [C.c_void_p]
     L.or_chan_block.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, f32p]
+    L.or_chan_block2.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, f32p, C.c_void_p, f32p]
+    L.or_chan_composite_taps.argtypes = [f32p, C.c_int, f32p]
     L.or_chan_proto.argtypes = [f32p]
     L.or_chan_twiddles.argtypes = [f32p]
     L.or_chan_resamp_taps.argtypes = [f32p]
@@ -148,6 +150,11 @@ class Channel:
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
         n = x.size // 2 if is_iq else x.size
         self.L.or_channel_feed(self.h, fptr(x), n, 1 if is_iq else 0)
+
+    def feed_decimated(self, z: np.ndarray, dec: int):
+        """Real input already decimated by the type's factor `dec` (SPEC 3.5b: the channelizer's composite filter)."""
+        z = np.ascontiguousarray(z, dtype=np.float32).reshape(-1)
+        self.L.or_channel_feed(self.h, fptr(z), z.size * dec, 2)
 
     def frames(self) -> np.ndarray:
         n = self.L.or_channel_nframes(self.h)

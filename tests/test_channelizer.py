@@ -54,23 +54,61 @@ def test_channelizer_isolates_a_tone(oracle):
     assert np.allclose(out48[k, 500:], 4 * df / 40000, atol=2e-3)      # atan2q: |error| <= 2.5e-3 rad = 1.6e-3 quadrant (SPEC 3.1)
 
 
-def _oracle_decode_wideband(oracle, iq_np, bins_active, types=None):
+def _oracle_decode_wideband(oracle, iq_np, bins_active, types=None, composite=False):
+    """composite=False: 48 kS/s rows (SPEC 3.5) fed to the channels' real-input path (what the product's unfused mode does);
+    composite=True: the decimated rows of SPEC 3.5b (resampler + boxcar as one filter: the product's default, fused mode)."""
     L = oracle.lib()
     nblk = iq_np.shape[0] // BLOCK
     ch = L.or_chan_new()
     dec = {k: oracle.Channel(int(types[k]) if types is not None else 0, k) for k in bins_active}
-    out48 = np.zeros((512, STEPS * 6 // 5), dtype=np.float32)
+    n_out = STEPS * 6 // 5
+    out48 = np.zeros((512, n_out), dtype=np.float32)
+    decs = np.zeros(512, dtype=np.uint8)
+    for k in bins_active:
+        decs[k] = 2 if (types is not None and int(types[k]) == 3) else 4          # M10: 2:1, the other GFSK types: 4:1 (SPEC 3.0)
+    outdec = np.zeros((512, n_out // 2), dtype=np.float32)
     first = None
     for b in range(nblk):
         blk = np.ascontiguousarray(iq_np[b * BLOCK: (b + 1) * BLOCK]).reshape(-1)
         bins = np.zeros((512, STEPS, 2), dtype=np.float32) if b == 0 else None
-        L.or_chan_block(ch, oracle.fptr(blk), STEPS, oracle.fptr(bins.reshape(-1)) if b == 0 else None, oracle.fptr(out48.reshape(-1)))
+        L.or_chan_block2(ch, oracle.fptr(blk), STEPS, oracle.fptr(bins.reshape(-1)) if b == 0 else None, oracle.fptr(out48.reshape(-1)),
+                         decs.ctypes.data, oracle.fptr(outdec.reshape(-1)))
         if b == 0:
-            first = (bins, out48.copy())
+            first = (bins, out48.copy(), outdec.copy())
         for k in bins_active:
-            dec[k].feed(out48[k], is_iq=False)
+            if composite:
+                dec[k].feed_decimated(outdec[k, :n_out // int(decs[k])], int(decs[k]))
+            else:
+                dec[k].feed(out48[k], is_iq=False)
     L.or_chan_free(ch)
     return dec, first
+
+
+def test_composite_rows_are_resample_then_average(oracle):
+    """SPEC 3.5b against SPEC 3.5 + 3.0: the composite filter's decimated rows equal the boxcar average of the 48 kS/s rows up
+    to rounding (both are sums of the same 64 / 32 products), the composite taps sum to one per row, and a scene decodes
+    through either path to the same frames."""
+    bins_active = [100, 333]
+    iq, truth = synth.make_wideband_rs41(bins_active, 10 * BLOCK, seed=6, ebn0_db=32.0)
+    types = np.zeros(512, dtype=np.uint8)
+    types[333] = 3                                          # a 2:1 row too (no M10 signal there: the arithmetic is what is compared)
+    a, first = _oracle_decode_wideband(oracle, iq.numpy(), bins_active, types=types, composite=False)
+    c, _ = _oracle_decode_wideband(oracle, iq.numpy(), bins_active, types=types, composite=True)
+    _, out48, outdec = first
+    n_out = out48.shape[1]
+    box4 = out48[100].astype(np.float64).reshape(-1, 4).mean(axis=1)
+    box2 = out48[333].astype(np.float64).reshape(-1, 2).mean(axis=1)
+    assert np.abs(outdec[100, :n_out // 4] - box4).max() < 4e-6 and np.abs(outdec[333, :n_out // 2] - box2).max() < 4e-6
+    L = oracle.lib()
+    g = np.zeros(96, dtype=np.float32)
+    L.or_chan_resamp_taps(oracle.fptr(g))
+    for d in (2, 4):
+        G = np.zeros(60, dtype=np.float32)
+        L.or_chan_composite_taps(oracle.fptr(g), d, oracle.fptr(G))
+        assert np.abs(G.reshape(3, 20).astype(np.float64).sum(axis=1) - 1.0).max() < 1e-6
+        assert (G.reshape(3, 20)[:, 19 if d == 4 else 17:] == 0).all()
+    fa, fc = a[100].frames(), c[100].frames()
+    assert len(fa) >= 1 and np.array_equal(fa["data"], fc["data"]) and np.array_equal(fa["bitpos"], fc["bitpos"])
 
 
 def test_oracle_decodes_rs41_out_of_a_wideband_scene(oracle):
@@ -126,7 +164,7 @@ def test_hip_channelizer_two_blocks_per_submit_equals_oracle(oracle):
         chz.submit(iq[2 * b * BLOCK: 2 * (b + 1) * BLOCK])             # a view: no copy on either side
         got.append(chz.frames())
     got = np.concatenate(got)
-    dec, _ = _oracle_decode_wideband(oracle, iq.cpu().numpy(), bins_active)
+    dec, _ = _oracle_decode_wideband(oracle, iq.cpu().numpy(), bins_active, composite=True)
     ref = np.concatenate([dec[k].frames() for k in bins_active])
     act = got[np.lexsort((got["bitpos"], got["channel"]))]
     assert len(ref) >= len(bins_active) and act.tobytes() == ref.tobytes()
@@ -193,8 +231,9 @@ def test_pfb_forms_give_identical_bins(oracle, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("bps,streams", [(1, 1), (2, 1), (1, 2), (5, 1)])
 def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
-    """The default mode: the per-bin discriminator and the 6/5 resampler run inside the decoder kernel (two launches per
-    submit, the 48 kS/s rows never exist).  Frames of every bin == the oracle's (or_chan.c -> or_channel, real input), for
+    """The default mode: the per-bin discriminator and the composite resampler + decimator (SPEC 3.5b) run inside the decoder
+    kernel (two launches per submit, the 48 kS/s rows never exist).  Frames of every bin == the oracle's (or_chan.c
+    or_chan_block2 -> or_channel, pre-decimated input), for
     RS41 (4:1 class) and M10 (2:1 class) bins, one and two blocks per submit, one and two streams per object."""
     import torch
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
@@ -215,7 +254,7 @@ def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
     key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
     refs = []
     for s_, sc in enumerate(scenes):
-        dec, _ = _oracle_decode_wideband(oracle, sc.cpu().numpy(), bins_active + m10_bins, types=types[:512])
+        dec, _ = _oracle_decode_wideband(oracle, sc.cpu().numpy(), bins_active + m10_bins, types=types[:512], composite=True)
         for k in bins_active + m10_bins:
             r = dec[k].frames().copy()
             r["channel"] = 512 * s_ + k
