@@ -334,8 +334,10 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     """One of the non-headline configurations, measured in this process: a compact record for other_configs / low_snr."""
     import copy
     a = copy.copy(args)
-    a.steps = steps or max(20, min(args.steps, 100))
-    a.warmup = warmup or max(5, min(args.warmup, 20))
+    # (their own step counts, stated in the record: the pipelined class streams need a few steps to fill and one to drain,
+    # which a 20-step region would charge at 3-5 %)
+    a.steps = steps or max(60, min(args.steps, 100))
+    a.warmup = warmup or max(10, min(args.warmup, 20))
     a.ramp_ms = min(args.ramp_ms, 100.0)
     blocks, types = make_blocks(kind, C, tiles, NB, args.ebn0 if ebn0 is None else ebn0, dev, seed=1000)
     m = measure(blocks, types, flags, a, local_rank, barrier, stream)
@@ -525,7 +527,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
             import copy
             a = copy.copy(args)
             a.wb_streams, a.wb_blocks = S, B
-            a.steps, a.warmup, a.ramp_ms = max(20, min(args.steps, 50)), max(5, min(args.warmup, 10)), min(args.ramp_ms, 100.0)
+            a.steps, a.warmup, a.ramp_ms = max(40, min(args.steps, 50)), max(8, min(args.warmup, 10)), min(args.ramp_ms, 100.0)
             w = run_wideband(a, rank, local_rank, world, dev, barrier, reduce_max_sum)
             others[name] = {
                 "workload": "BASELINE configs[3]: " + w["config"]["workload"], "ms_per_step": w["ms_per_step"], "value": w["value"],
@@ -533,7 +535,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                 "kernel_ms": w["kernel_ms"], "steps": a.steps, "warmup": a.warmup}
         out["other_configs"] = others
         ls = small_run("rs41", C, args.tiles, args.blocks, args.flags, args, local_rank, dev, barrier, stream, ebn0=9.0)
-        out["low_snr"] = {"ebn0": 9.0, "ms_per_step": ls["ms_per_step"], "step_frac": ls["step_frac"], "kernel_ms": ls["kernel_ms"],
+        out["low_snr"] = {"ebn0": 9.0, "steps": ls["steps"], "ms_per_step": ls["ms_per_step"], "step_frac": ls["step_frac"], "kernel_ms": ls["kernel_ms"],
                           "frames_per_step_steady": ls["frames_per_step_steady"],
                           "note": "the headline workload at Eb/N0 9 dB: most frames need the Reed-Solomon corrector's general path"}
     return out

@@ -170,7 +170,8 @@ long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t c
  * the framer/FEC kernels behind it (0 if there are none) over the TIMED submits since the previous call of this function
  * (at most the last 128), from HIP events recorded on the submit stream around each launch.  Synchronises.
  * Every event record is a bubble of a few microseconds in the command stream, so by default only every 8th submit is
- * timed; sonde_batch_set_timing changes that (1 = every submit, 0 = none) and restarts the count, so the next submit is timed. */
+ * timed (the last of each group of eight, plus the first submit of the batch's life); sonde_batch_set_timing changes that
+ * (1 = every submit, 0 = none) and restarts the count: the every_n-th submit after it is the next one timed. */
 int  sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *framer_ms);
 int  sonde_batch_set_timing(SondeBatch *b, int every_n);
 /* Mixed batches (several demodulator classes, one kernel each on the library's own streams): the average device time (ms) of

@@ -516,7 +516,9 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	HIPCHK(hipSetDevice(b->device));
 	hipStream_t stream = (hipStream_t)stream_;
 	const int n_tiles = (int)(n_samples / SONDE_TILE);
-	const bool timed = b->timing_every > 0 && b->n_submits % (unsigned long)b->timing_every == 0;
+	// the LAST submit of every group of timing_every -- never the first one behind sonde_batch_set_timing's synchronize, where the
+	// host has just been idle -- and the very first submit of the batch's life (a one-submit host still gets a figure)
+	const bool timed = b->timing_every > 0 && (b->n_submits % (unsigned long)b->timing_every == (unsigned long)b->timing_every - 1 || b->tickets == 0);
 	b->n_submits++;
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	if (timed) HIPCHK(hipEventRecord(ev[0], stream));

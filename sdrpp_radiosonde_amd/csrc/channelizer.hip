@@ -712,7 +712,8 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		}
 		c->ev_pending = false;
 	}
-	const bool timed = !c->ev_pending && (c->n_submits++ % 8) == 0;
+	const bool timed = !c->ev_pending && ((c->n_submits % 8) == 7 || c->n_blocks == 0);      // (as sonde_batch_submit: never the first submit behind a synchronize)
+	c->n_submits++;
 	if ((uintptr_t)iq_dev & 15u) return -1;       // 16-byte loads straight from the caller's block(s)
 	c->overlap = c->overlap && c->fused;
 	if (c->overlap) {
