@@ -620,7 +620,7 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
     samples_per_step = S * nwb * world
     msps = samples_per_step * args.steps / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
-    alg_bytes = nwb * 8                                   # one stream's block read once (PFB kernel)
+    alg_bytes = S * nwb * 8                               # every stream's block read once (the filter-bank launch covers all S streams)
     achieved = alg_bytes / (pfb_ms * 1e-3) / 1e9
     return {
         "metric": "wideband IQ Msamples/s through channelizer+demod+FEC @ 10 MS/s/stream",
@@ -637,7 +637,9 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
         "kernel_ms": {"pfb_fft": round(pfb_ms, 4), "disc_resample": round(rs_ms, 4), "demod": round(dem_ms, 4), "framer_fec": round(fr_ms, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "algorithmic_bytes": alg_bytes, "kernel": "sd_pfb_kernel (8 B per wideband sample read once)",
-                     "note": "one 80 MB/s stream is latency-bound, nowhere near the HBM roofline; frac is reported for completeness"},
+                     "written_bytes": S * (nwb // 250) * 512 * 8,
+                     "note": "algorithmic bytes = the wideband samples read once; the launch also WRITES 16.4 B per sample (the bins) and re-reads its "
+                             "5 x overlapping windows through the L2; one 80 MB/s stream is latency-bound, nowhere near the HBM roofline"},
     }
 
 
