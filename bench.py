@@ -552,10 +552,19 @@ def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
     cyc = NB > 1 and cyclic_ok(n, NB)
     if not cyc:
         NB = 1                                   # no seamless cycle of this shape: one block, re-submitted
-    ns = None
+    ns, fallback = None, ""
     if not args.scatter_torch:
         from sdrpp_radiosonde_amd.shard import NativeShard
-        ns = NativeShard(local_rank)
+        try:
+            ns = NativeShard(local_rank)
+        except Exception as e:                     # (library missing / communicator refused: the same on every rank)
+            fallback = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([1 if ns is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:                    # every rank takes the same path: torch.distributed's scatter (RCCL as well)
+            ns, args.scatter_torch = None, True
+            if rank == 0:
+                print(f"bench: native scatter unavailable ({fallback or 'another rank failed'}); using torch.distributed scatter", file=sys.stderr)
     blocks, ms = [], 0.0
     for k in range(NB):
         full = None
