@@ -140,7 +140,10 @@ void sonde_batch_destroy(SondeBatch *b);
  * samples: DEVICE pointer, channel-major; channel c starts at element c*channel_stride
  * (elements = complex samples for IQ, floats for REAL).  n_samples % SONDE_TILE == 0.
  * stream: hipStream_t (NULL = default stream).  Asynchronous.  Submits are ordered among themselves even across
- * streams (per-channel state is carried).  The frames of a submit live until the submit after the next one starts. */
+ * streams (per-channel state is carried).  The frames of a submit live until the submit after the next one starts.
+ * Layout advice (measured): the kernel streams every channel's row at once, so a channel stride whose BYTE size is a
+ * multiple of 2 MiB (e.g. 262 144 complex samples) puts all rows on the same HBM channels and costs about 8 %; pad the stride
+ * (any odd multiple of 512 KiB is fine) or pick another block length. */
 int  sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream);
 /* Same, from HOST memory (staged through an internal pinned/device buffer; PCIe-inclusive). */
 int  sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride);
