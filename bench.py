@@ -94,7 +94,10 @@ def parse_args():
     ap.add_argument("--no-others", action="store_true", help="headline only: skip the other BASELINE configurations (other_configs), the low-SNR "
                     "line and the rocprofv3 traffic passes that the default run appends")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # the sub-run rocprofv3 --pmc wraps (roofline.traffic)
-    ap.add_argument("--stride-pad", type=int, default=0, help="experiment: extra samples between channels in HBM")
+    ap.add_argument("--stride-pad", type=int, default=0, help="experiment: extra samples between channels in HBM (overrides --row-stride)")
+    ap.add_argument("--row-stride", choices=("pow2", "contiguous"), default="pow2",
+                    help="layout of the resident IQ blocks: rows on the library's recommended channel stride (sonde_row_stride: the next power of "
+                         "two in bytes, 2 MiB for the headline's 1.5 MiB rows; measured 2.3-5.5 %% faster, profiles/r3_stride_sweep.txt) or back to back")
     ap.add_argument("--scatter", action="store_true", help="(the default with --gpus > 1) ingest on rank 0 and scatter IQ shards over RCCL before timing")
     ap.add_argument("--scatter-torch", action="store_true", help="scatter through torch.distributed instead of libsonde_rccl.so")
     ap.add_argument("--rank-local", action="store_true", help="--gpus > 1: every rank generates its own shard (no scatter): kernel scaling without xGMI time")
@@ -111,7 +114,7 @@ def cpu_baseline(iq, C, n, args):
     import oracle_lib
     cores = effective_cpus()
     cc = args.cpu_channels or C
-    host_iq = iq[:cc].cpu().numpy()
+    host_iq = iq[:cc].contiguous().cpu().numpy()           # (the resident block may be a view of a padded allocation)
     # ---- one thread: channels one at a time until >= 1.2 s have been spent
     oracle_lib.batch_run(0, host_iq[:1, :2048 * 4], nthreads=1)            # load the library, touch the code
     t1, c1 = 0.0, 0
@@ -330,6 +333,23 @@ def alg_bytes_of(C, n):
     return C * n * 8 + C * (n * 4800 // 48000) // 8
 
 
+def restride(blocks, args):
+    """The resident blocks on the channel stride asked for (--row-stride / --stride-pad): views [C, n, 2] of padded allocations."""
+    from sdrpp_radiosonde_amd.batch import strided_rows
+    n = blocks[0].shape[1]
+    if args.stride_pad:
+        st = n + args.stride_pad
+    elif getattr(args, "row_stride", "pow2") == "pow2":
+        st = None                                   # the library's recommendation
+    else:
+        return blocks
+    out = []
+    for i in range(len(blocks)):
+        out.append(strided_rows(blocks[i], st))
+        blocks[i] = None                            # free the contiguous copy before the next block is padded
+    return out
+
+
 def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream, ebn0=None, steps=None, warmup=None):
     """One of the non-headline configurations, measured in this process: a compact record for other_configs / low_snr."""
     import copy
@@ -340,12 +360,14 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     a.warmup = warmup or max(10, min(args.warmup, 20))
     a.ramp_ms = min(args.ramp_ms, 100.0)
     blocks, types = make_blocks(kind, C, tiles, NB, args.ebn0 if ebn0 is None else ebn0, dev, seed=1000)
+    blocks = restride(blocks, args)
     m = measure(blocks, types, flags, a, local_rank, barrier, stream)
+    stride_samples = int(blocks[0].stride(0) // 2)
     del blocks
     torch.cuda.empty_cache()
     n = tiles * 2048
     ms = m["dt"] / a.steps * 1e3
-    rec = {"channels": C, "samples_per_channel": n, "blocks_cycled": NB, "flags": flags, "steps": a.steps, "warmup": a.warmup,
+    rec = {"channels": C, "samples_per_channel": n, "channel_stride_samples": stride_samples, "blocks_cycled": NB, "flags": flags, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 4), "value": round(C * n / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s",
            "step_frac": round(alg_bytes_of(C, n) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "frames_per_step_steady": round(m["nfr_step"], 2)}
@@ -420,11 +442,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
         blocks, types, scatter = scattered_blocks(args, rank, local_rank, world, dev, dist, barrier)
     else:
         blocks, types = make_blocks(kind, C, args.tiles, args.blocks, args.ebn0, dev, seed=1000 + rank, first_channel=rank * C)
-    if args.stride_pad:
-        padded = [torch.empty((C, n + args.stride_pad, 2), dtype=torch.float32, device=dev) for _ in blocks]
-        for pb, bk in zip(padded, blocks):
-            pb[:, :n] = bk
-        blocks = [pb[:, :n] for pb in padded]
+    blocks = restride(blocks, args)
     m = measure(blocks, types, args.flags, args, local_rank, barrier, stream)
     if args.pmc_child:
         return None
@@ -492,6 +510,9 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                                 f"RS41-SG x {C} channels/GPU x {n} samples per step (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)")
                                + (f"; {len(blocks)} consecutive blocks of a continuous signal resident in HBM, cycled" if len(blocks) > 1 else ""),
                    "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{world}", "flags": args.flags,
+                   "channel_stride_samples": int(blocks[0].stride(0) // 2),
+                   "layout": ("rows back to back" if int(blocks[0].stride(0) // 2) == n else
+                              f"rows {int(blocks[0].stride(0) // 2) * 8 // 1024} KiB apart (sonde_row_stride; --row-stride contiguous puts them back to back)"),
                    "ingest": "rank-local" if scatter is None else scatter["ingest"]},
         "frames_per_s": round(nfr_total * args.steps / dt, 1),
         "frames_per_step_steady": round(nfr_total, 2),
@@ -534,6 +555,15 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                 "unit": w["unit"], "realtime_streams": w["realtime_streams"], "us_per_stream_block": round(w["ms_per_step"] * 1e3 / (S * B), 2),
                 "kernel_ms": w["kernel_ms"], "steps": a.steps, "warmup": a.warmup}
         out["other_configs"] = others
+        if getattr(args, "row_stride", "pow2") == "pow2" and not args.stride_pad:
+            # the same workload with the rows back to back, measured in this run: what the layout is worth
+            import copy
+            ac = copy.copy(args)
+            ac.row_stride = "contiguous"
+            cl = small_run("rs41", C, args.tiles, args.blocks, args.flags, ac, local_rank, dev, barrier, stream)
+            out["contiguous_layout"] = {"channel_stride_samples": cl["channel_stride_samples"], "steps": cl["steps"], "ms_per_step": cl["ms_per_step"],
+                                        "step_frac": cl["step_frac"], "kernel_ms": cl["kernel_ms"],
+                                        "note": "the headline workload with its rows back to back (--row-stride contiguous)"}
         ls = small_run("rs41", C, args.tiles, args.blocks, args.flags, args, local_rank, dev, barrier, stream, ebn0=9.0)
         out["low_snr"] = {"ebn0": 9.0, "steps": ls["steps"], "ms_per_step": ls["ms_per_step"], "step_frac": ls["step_frac"], "kernel_ms": ls["kernel_ms"],
                           "frames_per_step_steady": ls["frames_per_step_steady"],

@@ -53,7 +53,7 @@ FLAG_PIPELINE = 4        # mixed batches: class streams are not joined into the 
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them
 ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
-    "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_class_ms", "sonde_batch_read_bits",
+    "sonde_row_stride", "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_class_ms", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_test_rs255", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
     "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp", "sonde_rs41_pressure", "sonde_ozone_mpa",
     "sonde_m10_temp", "sonde_m10_rh", "sonde_m20_temp", "sonde_ims100_temp",
@@ -151,6 +151,8 @@ def load() -> C.CDLL:
     L.sonde_chan_create_multi.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
     L.sonde_chan_set_fused.argtypes = [vp, C.c_int]
     L.sonde_chan_set_overlap.argtypes = [vp, C.c_int]
+    L.sonde_row_stride.argtypes = [C.c_size_t, C.c_int]
+    L.sonde_row_stride.restype = C.c_size_t
     L.sonde_chan_streams.argtypes = [vp]
     L.sonde_chan_streams.restype = C.c_uint32
     L.sonde_chan_destroy.argtypes = [vp]

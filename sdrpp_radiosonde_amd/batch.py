@@ -157,6 +157,25 @@ class SondeBatch:
         return dict(t_next=t.value, period=p.value, bias=b.value, amp=a.value, yprev=y.value)
 
 
+def row_stride(n_samples: int, iq: bool = True) -> int:
+    """Channel stride (in samples) the library recommends for rows of n_samples: the next power of two in bytes (HBM channel
+    spread of rows streamed side by side; include/sonde_abi.h sonde_row_stride)."""
+    return int(_lib.load().sonde_row_stride(int(n_samples), INPUT_IQ if iq else _lib.INPUT_REAL))
+
+
+def strided_rows(x, stride: int | None = None):
+    """A copy of the device tensor x = [C, n, 2] (or [C, n]) whose rows lie `stride` samples apart (default: row_stride), as a
+    view of the padded allocation: what submit() takes."""
+    import torch
+    n = x.shape[1]
+    st = stride or row_stride(n, iq=x.dim() == 3)
+    if st == n:
+        return x
+    buf = torch.empty((x.shape[0], st) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+    buf[:, :n] = x
+    return buf[:, :n]
+
+
 class SondeChannelizer:
     """Wideband front-end (BASELINE config 4): n_streams x 10 MS/s complex IQ -> 512 bins each -> per-bin decode; every stage
     is one launch over all streams.  submit() takes [samples_per_submit, 2] (one stream) or [n_streams, samples_per_submit, 2]."""

@@ -378,3 +378,30 @@ def test_pipelined_submits_tickets_and_stream_changes(oracle):
     got = np.concatenate(want)
     key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
     assert key(got).tobytes() == key(ref).tobytes()
+
+
+def test_rows_on_the_recommended_stride_and_host_staging(oracle):
+    """Layout is the host's choice (channel_stride): rows on the library's recommended stride (sonde_row_stride: the next
+    power of two in bytes -- what bench.py keeps resident and what sonde_batch_submit_host stages into) decode to the frames,
+    bits and loop state of the back-to-back layout, which the tests above tie to the oracle."""
+    from sdrpp_radiosonde_amd.batch import row_stride, strided_rows
+    C, n = 5, TILE * 36
+    assert row_stride(n) == 131072 and row_stride(TILE * 96) == 262144 and row_stride(TILE) == TILE and row_stride(TILE * 96, iq=False) == 262144
+    sb = synth.make_rs41_batch(C, n, seed=77, ebn0_db=16.0)
+    outs = []
+    for mode in ("contiguous", "strided", "host"):
+        b = SondeBatch(C, n)
+        if mode == "host":
+            b.submit_host(sb.iq.numpy())
+        else:
+            x = _dev(sb.iq)
+            if mode == "strided":
+                x = strided_rows(x)
+                assert x.stride(0) == 2 * 131072 and tuple(x.shape) == (C, n, 2)
+            b.submit(x)
+        fr = b.frames()
+        outs.append((fr.tobytes(), [b.read_bits(c, 0, b.nbits(c)).tobytes() for c in range(C)], [b.state(c)["t_next"] for c in range(C)]))
+        b.close()
+    assert len(outs[0][0]) > 0 and outs[0] == outs[1] == outs[2]
+    ref = np.concatenate([ch.frames() for ch in _oracle_channels(oracle, sb.iq.numpy())])
+    assert np.frombuffer(outs[0][0], dtype=ref.dtype).tobytes() == ref.tobytes()
