@@ -9,7 +9,9 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // TM: tile-major layout [step][row][16 KB] instead of row-major [row][step][16 KB]: ch_f4 is then the number of rows * 1024
-template <int DEPTH, bool TM = false>
+// PF > 0: besides the DEPTH register sets, the lines of the tile PF steps ahead are touched by one discarded dword per 128-byte
+// line (an L2 prefetch: no registers held)
+template <int DEPTH, bool TM = false, int PF = 0, bool NT = true>
 __global__ __launch_bounds__(512) void streams(const f4 *src, size_t ch_f4, int steps, float *sink)
 {
 	extern __shared__ float dyn_lds[];                  // only there to limit the workgroups per CU
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(512) void streams(const f4 *src, size_t ch_f4, int 
 #pragma unroll
 		for (int d = 0; d < DEPTH; d++)
 #pragma unroll
-			for (int r = 0; r < NLD; r++) v[d][r] = __builtin_nontemporal_load(p + (size_t)d * step_f4 + 64 * (NLD * kw + r) + lane);
+			for (int r = 0; r < NLD; r++) v[d][r] = NT ? __builtin_nontemporal_load(p + (size_t)d * step_f4 + 64 * (NLD * kw + r) + lane) : p[(size_t)d * step_f4 + 64 * (NLD * kw + r) + lane];
 		for (int s = 0; s < steps; s += DEPTH) {
 #pragma unroll
 			for (int d = 0; d < DEPTH; d++) {
@@ -34,7 +36,13 @@ __global__ __launch_bounds__(512) void streams(const f4 *src, size_t ch_f4, int 
 				for (int r = 0; r < NLD; r++) acc += v[d][r];
 				if (s + d + DEPTH < steps) {
 #pragma unroll
-					for (int r = 0; r < NLD; r++) v[d][r] = __builtin_nontemporal_load(p + (size_t)(s + d + DEPTH) * step_f4 + 64 * (NLD * kw + r) + lane);
+					for (int r = 0; r < NLD; r++) v[d][r] = NT ? __builtin_nontemporal_load(p + (size_t)(s + d + DEPTH) * step_f4 + 64 * (NLD * kw + r) + lane) : p[(size_t)(s + d + DEPTH) * step_f4 + 64 * (NLD * kw + r) + lane];
+				}
+				if (PF > 0 && s + d + PF < steps && lane < 32) {
+					// this wave's 4 KB of the tile PF steps ahead: 32 lines of 128 bytes, one dword each
+					const float *q = reinterpret_cast<const float *>(p + (size_t)(s + d + PF) * step_f4 + 64 * NLD * kw) + 32 * lane;
+					float junk;
+					asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(q) : "memory");
 				}
 				__syncthreads();
 			}
@@ -86,6 +94,17 @@ int main()
 		printf("tile-major [step][row][16 KB] depth 3: "); ms = timeit([&] { streams<3, true><<<C, 512>>>(buf, (size_t)C * 1024, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
 		printf("tile-major [step][row][16 KB] depth 4: "); ms = timeit([&] { streams<4, true><<<C, 512>>>(buf, (size_t)C * 1024, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
 		printf("row-major 2 MiB depth 2 (again):       "); ms = timeit([&] { streams<2><<<C, 512>>>(buf, (size_t)2048 * 1024 / 16, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
+	}
+	{
+		const size_t st = (size_t)2048 * 1024 / 16;
+		float ms;
+		printf("2 MiB depth 2 + L2 prefetch 3 ahead: "); ms = timeit([&] { streams<2, false, 3><<<C, 512>>>(buf, st, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
+		printf("2 MiB depth 2 + L2 prefetch 4 ahead: "); ms = timeit([&] { streams<2, false, 4><<<C, 512>>>(buf, st, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
+		printf("2 MiB depth 2 + L2 prefetch 6 ahead: "); ms = timeit([&] { streams<2, false, 6><<<C, 512>>>(buf, st, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
+		printf("2 MiB depth 2 plain loads + L2 prefetch 3 ahead: "); ms = timeit([&] { streams<2, false, 3, false><<<C, 512>>>(buf, st, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
+		printf("2 MiB depth 2 plain loads, no prefetch:          "); ms = timeit([&] { streams<2, false, 0, false><<<C, 512>>>(buf, st, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
+		printf("2 MiB depth 3 plain loads, no prefetch:          "); ms = timeit([&] { streams<3, false, 0, false><<<C, 512>>>(buf, st, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
+		printf("2 MiB depth 2 (again):               "); ms = timeit([&] { streams<2><<<C, 512>>>(buf, st, steps, sink); }); printf("%.0f GB/s\n", gb / (ms * 1e-3));
 	}
 	// bytes in flight per CU: workgroups per CU (limited by dynamic LDS) x depth x 16 KB; rows 2 MiB apart
 	{
