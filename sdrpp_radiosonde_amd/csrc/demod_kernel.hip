@@ -340,8 +340,8 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				const float zx = q.x + q.z, zy = q.y + q.w;
-				float px = __shfl_up(zx, 1, 64), py = __shfl_up(zy, 1, 64);
-				if (lane == 0) { px = cx; py = cy; }
+				// (lane l takes lane l - 1's sample, lane 0 the carry: one DPP move each; __shfl_up is a ds_bpermute on the LDS pipe)
+				const float px = sd_wave_shr1(zx, cx), py = sd_wave_shr1(zy, cy);
 				store_one(s, b, (uint32_t)(128 * kw + 64 * g + lane), sd_disc(zx, zy, px, py));
 				cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zx), 63));
 				cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zy), 63));
@@ -356,14 +356,12 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 				if (dec2) {
 					// one float4 = two input samples = one decimated sample z, index fi
 					const float zx = v[r].x + v[r].z, zy = v[r].y + v[r].w;
-					float px = __shfl_up(zx, 1, 64), py = __shfl_up(zy, 1, 64);
-					if (lane == 0) { px = cx; py = cy; }
+					const float px = sd_wave_shr1(zx, cx), py = sd_wave_shr1(zy, cy);
 					store_one(s, b, fi, sd_disc(zx, zy, px, py));
 					cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zx), 63));
 					cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zy), 63));
 				} else {
-					float px = __shfl_up(v[r].z, 1, 64), py = __shfl_up(v[r].w, 1, 64);
-					if (lane == 0) { px = cx; py = cy; }
+					const float px = sd_wave_shr1(v[r].z, cx), py = sd_wave_shr1(v[r].w, cy);
 					const float d0 = sd_disc(v[r].x, v[r].y, px, py);
 					const float d1 = sd_disc(v[r].z, v[r].w, v[r].x, v[r].y);
 					store_pair(s, b, 2u * fi, d0, d1);
@@ -499,7 +497,7 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 				if (h == 0) m = interp<NT>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
 			}
 			if (h == 0) {
-				const float yprev = __shfl_up(y, 1, 64);
+				const float yprev = sd_wave_shr1(y, 0.0f);            // (lane 0's term is not used)
 				float e = (yprev - y) * (m - bias);
 				e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
 				Ei += (act && lane != 0) ? __float2int_rn(e) : 0;    // first symbol of a 64-group: no term (SPEC 3.2)
