@@ -78,8 +78,10 @@ struct DemodLds {
 __device__ __forceinline__ void store_pair(DemodLds &s, int b, uint32_t i, float d0, float d1)
 {
 	*reinterpret_cast<float2 *>(&s.A[b][SD_LH + i]) = make_float2(d0, d1);
+#ifdef SD_BCOPY
 	s.B[b][SD_LH + i - 1] = d0;
 	s.B[b][SD_LH + i] = d1;
+#endif
 }
 
 // v of the lane below, lane 0: `first` (DPP wave_shr:1, GFX9; lanes without a source keep the old value)
@@ -92,7 +94,9 @@ __device__ __forceinline__ float sd_wave_shr1(float v, float first)
 __device__ __forceinline__ void store_one(DemodLds &s, int b, uint32_t i, float d0)
 {
 	s.A[b][SD_LH + i] = d0;
+#ifdef SD_BCOPY
 	s.B[b][SD_LH + i - 1] = d0;
+#endif
 }
 
 // y(pos) = (sum_{j even} H[p][j] d[n+16-j]) + (sum_{j odd} H[p][j] d[n+16-j]), each an fmaf chain with j
@@ -105,13 +109,25 @@ __device__ __forceinline__ float interp(const float *A, const float *B, const fl
 	const uint32_t top = (rel >> 16) + NT / 2;                          // buffer index of d for j = 0
 	const float *h = taps + ((rel >> 11) & (SD_NPHASE - 1)) * SD_TAPS_LD;
 	// pair i holds (d[top-1-2i], d[top-2i]); it is 8-byte aligned in A when top is odd, in B otherwise
+#ifndef SD_BCOPY
+	// pairs at any alignment, read as two dwords each (ds_read2_b32).  Rounds 1-2 kept a second copy B of every tile, shifted by
+	// one sample, so that a pair was one aligned 8-byte read in A or in B: two to three LDS stores per sample instead of one
+	// (mixed batch -2.5 %, 4096 x 96 tiles -1.7 %, headline unchanged without it: profiles/r3_notes.md)
+	const float *lo = A + (top - (NT - 1));
+#else
 	const float *lo = (top & 1u) ? (A + (top - (NT - 1))) : (B + (top - NT));
+#endif
 	f32x2 acc = {0.0f, 0.0f};                                           // (odd chain, even chain)
 #pragma unroll
 	for (int q = 0; q < NT / 4; q++) {
 		const float4 hv = *reinterpret_cast<const float4 *>(h + 4 * q);
+#ifndef SD_BCOPY
+		const float2 v0 = make_float2(lo[(NT - 2) - 4 * q], lo[(NT - 1) - 4 * q]);
+		const float2 v1 = make_float2(lo[(NT - 4) - 4 * q], lo[(NT - 3) - 4 * q]);
+#else
 		const float2 v0 = *reinterpret_cast<const float2 *>(lo + (NT - 2) - 4 * q);
 		const float2 v1 = *reinterpret_cast<const float2 *>(lo + (NT - 4) - 4 * q);
+#endif
 		const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
 		const f32x2 d0 = {v0.x, v0.y}, d1 = {v1.x, v1.y};
 		acc = pk_fma(h0, d0, acc);
@@ -236,7 +252,9 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		if (tid < SD_LH) {
 			const float hv = hist[(size_t)ch * SD_HIST + tid];
 			s.A[0][tid] = hv;
+#ifdef SD_BCOPY
 			if (tid) s.B[0][tid - 1] = hv;
+#endif
 		}
 		if (tid == 0) {
 			s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
@@ -632,7 +650,9 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		for (int tile = 0; tile < n_tiles; tile += 2) {
 			if (tile + 1 < n_tiles) {
 				if (t < SD_LH) s.A[1][t] = s.A[0][IT + t];            // history roll into the other buffer
+#ifdef SD_BCOPY
 				else if (t < 2 * SD_LH - 1) s.B[1][t - SD_LH] = s.B[0][IT + t - SD_LH];
+#endif
 				k1B(1, tile + 1);
 				if (tile + 3 < n_tiles) ldB(tile + 3);
 			}
@@ -640,7 +660,9 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			if (tile + 1 >= n_tiles) break;
 			if (tile + 2 < n_tiles) {
 				if (t < SD_LH) s.A[0][t] = s.A[1][IT + t];
+#ifdef SD_BCOPY
 				else if (t < 2 * SD_LH - 1) s.B[0][t - SD_LH] = s.B[1][IT + t - SD_LH];
+#endif
 				k1A(0, tile + 2);
 				if (tile + 4 < n_tiles) ldA(tile + 4);
 			}
