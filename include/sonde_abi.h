@@ -126,8 +126,11 @@ typedef struct {
  * its own predecessor only, so the tail of one class (last workgroups draining, frame decoder) overlaps the next submit of
  * the others.  The caller's stream orders the INPUT only (the kernels start once work queued on it before the submit has
  * finished); completion is observed through sonde_batch_sync / sonde_batch_frames_of, NOT through the caller's stream:
- * the sample buffer of submit t must stay untouched until sonde_batch_sync / frames_of(t) has returned.  No effect on
- * batches of one class (one kernel on the caller's stream). */
+ * the sample buffer of submit t must stay untouched until sonde_batch_sync / frames_of(t) has returned.
+ * Batches of ONE sonde type (round 4): the channel list is cut into two launch units that keep their own streams the same way, so
+ * that the last, part-filled generation of workgroups of one unit's submit t runs beside the other unit's submit t + 1: a
+ * throughput that no longer depends on the channel count being a multiple of 1024 (1250 channels x 1 s: 0.56 -> 0.74 of the HBM
+ * peak), for hosts that keep two or more submits queued. */
 #define SONDE_FLAG_PIPELINE  4u
 
 typedef struct SondeBatch SondeBatch;

@@ -35,6 +35,7 @@
 #define AT_C3 -0.18171308934688568f    /* 0xBE3A12FF */
 #define AT_C5  0.04842534288764f       /* 0x3D4659A7 */
 
+static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 static inline uint32_t f2u(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
 static inline float u2f(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
 
@@ -53,13 +54,17 @@ float or_recip(float x)
 	return r;
 }
 
-/* atan2q(y, x) = atan2(y, x) * 2/pi, in [-2, 2], |error| <= 2.5e-3 rad.  NaN / Inf inputs are outside the contract;
- * atan2q(0, 0) = +-0.5 (the divisor is floored at 1e-30). */
+/* atan2q(y, x) = atan2(y, x) * 2/pi, in [-2, 2], |error| <= 2.5e-3 rad.  NaN / Inf inputs are outside the contract.
+ * atan2q(0, 0) = 0 (round 4): the divisor s = |x| + |y| is floored at AT_FLOOR and the numerator is taken from
+ * it, d = s - 2|y| (= |x| - |y| up to one rounding of s), so that at (0, 0) r = AT_FLOOR * rc(AT_FLOOR); AT_FLOOR is the
+ * float near 1e-30 for which the seed + one Newton step return its reciprocal so that this product is EXACTLY 1, where the
+ * polynomial is exactly 1/2: a squelched or zero-padded stream reads 0 like any FM demodulator's, not +-1/2. */
+#define AT_FLOOR 6.9721523e-31f     /* 0x0D624260 */
 float or_atan2(float y, float x)
 {
 	const float ax = u2f(f2u(x) & 0x7FFFFFFFu), ay = u2f(f2u(y) & 0x7FFFFFFFu);
-	const float s = fmaxf(ax + ay, 1.0e-30f);
-	const float d = ax - ay;
+	const float s = fmaxf(ax + ay, AT_FLOOR);
+	const float d = fmaf(-2.0f, ay, s);
 	float rc = u2f(0x7EF311C7u - f2u(s));            /* seed: relative error < 5.1 % */
 	const float e = fmaf(-s, rc, 1.0f);
 	rc = fmaf(rc, e, rc);                            /* one Newton step: < 0.26 % */
@@ -85,6 +90,26 @@ void or_discriminate(const float *iq, size_t n, float *d, float *last)
 		const float cross = fmaf(-x1, y0, y1 * x0);
 		const float dot = fmaf(y1, y0, x1 * x0);
 		d[i] = or_atan2(cross, dot);
+		x0 = x1;
+		y0 = y1;
+	}
+	last[0] = x0;
+	last[1] = y0;
+}
+
+/* The same with the product x[n] conj(x[n-1]) turned back by the AFC phasor (c, s) = (1 - u^2, 2u) before the arctangent
+ * (SPEC 3.0b): d[n] = arg(x[n] conj(x[n-1]) (c - j s)).  The phasor's length (1 + u^2) does not matter to an arctangent. */
+static void discriminate_rot(const float *iq, size_t n, float *d, float *last, float u)
+{
+	const float c = fmaf(-u, u, 1.0f), sn = u + u;
+	float x0 = last[0], y0 = last[1];
+	for (size_t i = 0; i < n; i++) {
+		const float x1 = iq[2 * i], y1 = iq[2 * i + 1];
+		const float cross = fmaf(-x1, y0, y1 * x0);
+		const float dot = fmaf(y1, y0, x1 * x0);
+		const float cr = fmaf(-dot, sn, cross * c);
+		const float dr = fmaf(cross, sn, dot * c);
+		d[i] = or_atan2(cr, dr);
 		x0 = x1;
 		y0 = y1;
 	}
@@ -146,6 +171,14 @@ void or_make_taps(const OrModem *m, float taps[OR_NPHASE][OR_NTAPS])
 	}
 }
 
+/* AFC (SPEC 3.0b): state u, rotation angle 2 atan(u) per internal sample; gain per tile on the slicer bias (quadrants), leak
+ * per tile, range +-0.8 (+-77 degrees per sample: +-2.6 kHz at 12 kS/s, +-5.2 kHz at 24 kS/s) */
+#ifndef OR_AFC_GAIN
+#define OR_AFC_GAIN 0.19634954f      /* 0.25 * pi / 4: a quarter of the measured offset per tile (0.125: slower to acquire, 0.4: the lag of 3-4 tiles rings) */
+#endif
+#define OR_AFC_LEAK 0.0078125f       /* 1/128 per tile: the state returns to 0 without a signal (time constant 5.5 s) */
+#define OR_AFC_MAX  0.8f
+
 struct OrDemod {
 	const OrModem *m;
 	float taps[OR_NPHASE][OR_NTAPS];
@@ -160,6 +193,7 @@ struct OrDemod {
 	int32_t period;      /* Q16 samples per symbol */
 	float bias, amp;
 	int32_t nstat;
+	float afc[3];        /* SPEC 3.0b: the AFC states u that the discriminator of the next three tiles will use, oldest first */
 	uint8_t *bits;
 	uint64_t nbits, cap;
 };
@@ -191,7 +225,7 @@ static inline float interp(const OrDemod *d, int64_t pos)
 	return acc_e + acc_o;
 }
 
-static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
 
 static void push_bit(OrDemod *d, int b)
 {
@@ -389,15 +423,15 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 					z[2 * m] = (x[8 * m] + x[8 * m + 2]) + (x[8 * m + 4] + x[8 * m + 6]);
 					z[2 * m + 1] = (x[8 * m + 1] + x[8 * m + 3]) + (x[8 * m + 5] + x[8 * m + 7]);
 				}
-				or_discriminate(z, (size_t)it, tile, d->iq_last);
+				discriminate_rot(z, (size_t)it, tile, d->iq_last, d->afc[0]);
 			} else if (dec == 2) {
 				for (int m = 0; m < it; m++) {
 					z[2 * m] = x[4 * m] + x[4 * m + 2];
 					z[2 * m + 1] = x[4 * m + 1] + x[4 * m + 3];
 				}
-				or_discriminate(z, (size_t)it, tile, d->iq_last);
+				discriminate_rot(z, (size_t)it, tile, d->iq_last, d->afc[0]);
 			} else {
-				or_discriminate(x, (size_t)it, tile, d->iq_last);
+				discriminate_rot(x, (size_t)it, tile, d->iq_last, d->afc[0]);
 			}
 		} else if (is_iq == 2) {
 			/* real input already decimated by this type's factor (SPEC 3.5b: the channelizer's composite filter): n still
@@ -417,6 +451,19 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 			d->ring[(d->n0 + i) & (OR_RING - 1)] = tile[i];
 		d->n0 += it;
 		run_rounds(d);
+		if (is_iq == 1) {
+			/* SPEC 3.0b, AFC: the slicer's threshold `bias` is the mean of the discriminator output, i.e. what is left of the
+			 * carrier offset behind the rotation: a leaky integrator moves the rotation after every tile.  The discriminator
+			 * runs ahead of the timing loop on the GPU (other waves of the workgroup), so the state after tile i is what the
+			 * discriminator of tile i + 3 uses: a three-deep FIFO. */
+			float u = d->afc[2];
+			u = fmaf(-OR_AFC_LEAK, u, u);
+			u = fmaf(OR_AFC_GAIN, d->bias, u);
+			u = clampf(u, -OR_AFC_MAX, OR_AFC_MAX);
+			d->afc[0] = d->afc[1];
+			d->afc[1] = d->afc[2];
+			d->afc[2] = u;
+		}
 	}
 }
 
@@ -434,7 +481,13 @@ void or_demod_state(const OrDemod *d, int64_t *t_next, int32_t *period, float *b
 	if (period) *period = d->period;
 	if (bias) *bias = d->bias;
 	if (amp) *amp = d->amp;
-	if (yprev) *yprev = 0.0f;
+	if (yprev) *yprev = d->afc[2];      /* (round 4: the newest AFC state u, SPEC 3.0b; 0 for real input) */
+}
+
+/* bits produced elsewhere (the conventional yardstick demodulator, or_yardstick.c) into the container the framers read */
+void or_demod_append_bits(OrDemod *d, const uint8_t *b, size_t n)
+{
+	for (size_t i = 0; i < n; i++) push_bit(d, b[i]);
 }
 
 /* internal accessor for the framer */

@@ -133,6 +133,19 @@ OrDemod   *or_channel_demod(OrChannel *c);
  * nthreads<=1: serial.  Used by bench.py cpu_baseline. */
 size_t     or_batch_run(int type, const float *iq, size_t nch, size_t n, int nthreads, OrFrame *out, size_t cap);
 
+/* ---- yardstick: a conventional per-sample GFSK receiver (or_yardstick.c) in front of the same framers / FEC.  Shares no
+ * demodulator arithmetic with or_dsp.c (libm atan2f, AGC, per-symbol Gardner PI loop); GFSK sonde types only.
+ * cutoff_rel: symbol-filter cutoff in symbol rates (<= 0: 1.0); loop_bw: loop noise bandwidth in symbol rates (<= 0: 0.01). */
+typedef struct OrYard OrYard;
+OrYard *or_yard_new(int type, uint32_t channel, float cutoff_rel, float loop_bw);
+void    or_yard_free(OrYard *y);
+void    or_yard_feed(OrYard *y, const float *iq, size_t n);          /* complex IQ at 48 kS/s, any n */
+size_t  or_yard_nframes(const OrYard *y);
+const OrFrame *or_yard_frame(const OrYard *y, size_t i);
+uint64_t or_yard_nbits(const OrYard *y);
+void    or_yard_getbits(const OrYard *y, uint64_t from, size_t count, uint8_t *out);
+size_t  or_yard_batch_run(int type, const float *iq, size_t nch, size_t n, int nthreads, float cutoff_rel, float loop_bw, OrFrame *out, size_t cap);
+
 /* ---- wideband front-end (config 4): 512-bin PFB channelizer + discriminator + 6/5 resampler ---- */
 #define OR_CH_FS   10000000.0   /* wideband sample rate */
 #define OR_CH_M    512          /* bins, spacing 19531.25 Hz */

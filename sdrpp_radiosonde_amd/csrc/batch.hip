@@ -296,7 +296,21 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		b->n_cls[k] = (uint32_t)cls[k].size();
 		if (b->n_cls[k]) { b->n_classes++; b->only_class = k; }
 	}
-	const bool need_lists = n_afsk != 0 || b->n_classes > 1;
+	// Round 4: a ONE-class batch created with SONDE_FLAG_PIPELINE is cut into TWO launch units (halves of the channel list, each
+	// with its own stream from submit to submit).  A workgroup lives for its channel's whole submit, so a launch whose
+	// workgroup count is not a multiple of one residency (4 x 256 CUs) ends with a part-filled generation running alone; with
+	// two units in flight the tail of one unit's submit t overlaps the other unit's submit t + 1.  Measured
+	// (profiles/r4_notes.md): 1250 channels x 24 tiles 0.556 -> 0.743 of the HBM peak, 1280 x 96 0.634 -> 0.799, 1100 x 96
+	// 0.565 -> 0.756, 8192 x 24 0.765 -> 0.782, 1024 x 96 (exactly one residency) 0.779 -> 0.789; three units: equal or worse
+	// (1250 x 24: 0.626); four and more: 0.38-0.63 (more streams than the hardware runs side by side).  SONDE_UNITS overrides.
+	int one_class_units = 1;
+	if ((cfg->flags & SONDE_FLAG_PIPELINE) && n_afsk == 0 && b->n_classes == 1) {
+		int n_types = 0;
+		for (int t = 0; t < SONDE_NTYPES; t++) n_types += !b->chlist[t].empty();
+		one_class_units = (n_types == 1 && b->n_channels >= 512) ? 2 : 1;
+		if (const char *e = getenv("SONDE_UNITS")) one_class_units = std::max(1, std::min(16, atoi(e)));
+	}
+	const bool need_lists = n_afsk != 0 || b->n_classes > 1 || one_class_units > 1;
 	if (n_afsk) {
 		if (cfg->max_samples % (SONDE_TILE * SD_AF_DEC)) { sonde_batch_destroy(b); return fail("sonde_batch_create: with iMet channels max_samples must be a multiple of 16384"); }
 		b->granule = SONDE_TILE * SD_AF_DEC;
@@ -431,6 +445,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 		// pieces per type (pipelined batches): one; SONDE_MIX_CHUNKS overrides for experiments (2-8 pieces measured 6-70 % slower)
 		int R = 1;
 		if (const char *e = getenv("SONDE_MIX_CHUNKS")) R = std::max(1, std::min(16, atoi(e)));
+		if (one_class_units > 1) R = one_class_units;
 		b->n_chunks = pipelined ? R : 1;
 		static const int order[] = { SONDE_M10, SONDE_RS41, SONDE_DFM09, SONDE_IMS100, SONDE_MRZN1 };
 		if (pipelined) {
@@ -560,7 +575,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 		framer_launched = true;
 		return 0;
 	};
-	const bool one_launch = !n_afsk && b->n_classes == 1;
+	const bool one_launch = b->units.empty();
 	if (one_launch) {
 		sd_launch_demod(iq, k_cls_decim[b->only_class], k_cls_nt[b->only_class], b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, bins_in);
@@ -908,7 +923,7 @@ extern "C" int sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *
 	if (period) *period = st.period;
 	if (bias) *bias = st.bias;
 	if (amp) *amp = st.amp;
-	if (yprev) *yprev = st.yprev;
+	if (yprev) *yprev = st.afc[2];          // (round 4: the newest AFC state u, SPEC 3.0b; 0 for real input)
 	return 0;
 }
 

@@ -64,6 +64,7 @@ struct DemodLds {
 	uint32_t chunk[2][18];                  // [round parity]: the round's bits, one ballot per wave (and half), zero-padded
 	uint32_t partial[2];                    // bits already in the ring word that wpos points into (ping-pong)
 	float iq_last[2];
+	float afc_u[4];                         // SPEC 3.0b: AFC state for the discriminator of tile T at [T & 3] (written by the lead wave three tiles earlier)
 	// what the lead round wave (wave 0) computes once per round and the other round waves pick up:
 	// the PI loop filter runs on one wave instead of four (it is ~35 % of a round wave's VALU work)
 	struct { long long t_next; int period; float bias; int K; unsigned flag; unsigned long long wpos; } pub;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
 			s.pub.flag = 0;
 			s.pub.wpos = st.wpos;
+			s.afc_u[0] = st.afc[0]; s.afc_u[1] = st.afc[1]; s.afc_u[2] = st.afc[2];
 		}
 	}
 	// K4: the sync search of the framed sondes runs in here, on round wave 3, over an LDS mirror of the newest ring words
@@ -338,7 +340,15 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	};
 	auto load_tile = [&](int tile, float4 (&v)[NLD], float4 &pv, float4 &pw) { load_vec(tile, v); load_prev(tile, pv, pw); };
 	// K0+K1: (2:1 boxcar decimation,) d[n] = atan2q(z[n] * conj(z[n-1])), straight into buffer b
-	auto k1_tile = [&](int b, const float4 (&v)[NLD], const float4 &pv, const float4 &pw) {
+	// AFC (SPEC 3.0b, IQ input): tile T's products are turned back by the phasor (1 - u^2, 2u), u = the state the lead wave published
+	// three tiles earlier (LDS, written two barriers ago) or, for the first three tiles of a submit, carried in the channel state
+	auto afc_of = [&](int tile) -> float {
+		const float u = tile == 0 ? st.afc[0] : (tile == 1 ? st.afc[1] : (tile == 2 ? st.afc[2] : s.afc_u[tile & 3]));
+		return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u)));
+	};
+	auto k1_tile = [&](int b, int tile, const float4 (&v)[NLD], const float4 &pv, const float4 &pw) {
+		const float afc_u = IS_IQ ? afc_of(tile) : 0.0f;
+		const float rc = __builtin_fmaf(-afc_u, afc_u, 1.0f), rs = afc_u + afc_u;
 		// lane 0's predecessor (decimated) sample; after each load: lane 63's last sample
 		float cx = dec4 ? (pw.x + pw.z) + (pv.x + pv.z) : (dec2 ? pv.x + pv.z : pv.z);
 		float cy = dec4 ? (pw.y + pw.w) + (pv.y + pv.w) : (dec2 ? pv.y + pv.w : pv.w);
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 				const float zx = q.x + q.z, zy = q.y + q.w;
 				// (lane l takes lane l - 1's sample, lane 0 the carry: one DPP move each; __shfl_up is a ds_bpermute on the LDS pipe)
 				const float px = sd_wave_shr1(zx, cx), py = sd_wave_shr1(zy, cy);
-				store_one(s, b, (uint32_t)(128 * kw + 64 * g + lane), sd_disc(zx, zy, px, py));
+				store_one(s, b, (uint32_t)(128 * kw + 64 * g + lane), sd_disc_rot(zx, zy, px, py, rc, rs));
 				cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zx), 63));
 				cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zy), 63));
 			}
@@ -375,13 +385,13 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 					// one float4 = two input samples = one decimated sample z, index fi
 					const float zx = v[r].x + v[r].z, zy = v[r].y + v[r].w;
 					const float px = sd_wave_shr1(zx, cx), py = sd_wave_shr1(zy, cy);
-					store_one(s, b, fi, sd_disc(zx, zy, px, py));
+					store_one(s, b, fi, sd_disc_rot(zx, zy, px, py, rc, rs));
 					cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zx), 63));
 					cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zy), 63));
 				} else {
 					const float px = sd_wave_shr1(v[r].z, cx), py = sd_wave_shr1(v[r].w, cy);
-					const float d0 = sd_disc(v[r].x, v[r].y, px, py);
-					const float d1 = sd_disc(v[r].z, v[r].w, v[r].x, v[r].y);
+					const float d0 = sd_disc_rot(v[r].x, v[r].y, px, py, rc, rs);
+					const float d1 = sd_disc_rot(v[r].z, v[r].w, v[r].x, v[r].y, rc, rs);
 					store_pair(s, b, 2u * fi, d0, d1);
 					cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[r].z), 63));
 					cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[r].w), 63));
@@ -600,6 +610,17 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		st.wpos += (uint64_t)K;
 	};
 
+	// AFC (SPEC 3.0b), lead wave, after the rounds of tile j: the slicer threshold is what is left of the carrier offset behind the
+	// rotation; a leaky integrator moves the state, which the discriminator of tile j + 3 will use
+	float afc_last = st.afc[2];
+	auto afc_step = [&](int j) {
+		float u = __builtin_fmaf(-SD_AFC_LEAK, afc_last, afc_last);
+		u = __builtin_fmaf(SD_AFC_GAIN, st.bias, u);
+		u = sd_clamp(u, -SD_AFC_MAX, SD_AFC_MAX);
+		afc_last = u;
+		if (lane == 0) s.afc_u[(j + 3) & 3] = u;
+	};
+
 	// ---- the two roles run separate loops (so that neither carries the other's live registers) with the
 	// same number of s_barriers: one after the prologue, then `rounds` per tile.  is_k is wave-uniform.
 	auto k4_load = [&]() {         // one lane: the channel's search state into LDS
@@ -628,13 +649,13 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	if (is_k) {
 		// register set A holds the even tiles, set B the odd ones (the arguments are literals at every call: static register sets)
 #ifdef BINS_AB_TWOSETS
-		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, va, pa, qa); };
-		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wb); else k1_tile(b, vb, pb, qb); };
+		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, tile, va, pa, qa); };
+		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wb); else k1_tile(b, tile, vb, pb, qb); };
 		auto ldA = [&](int tile) { if constexpr (BINS) load_bins(tile, wa); else load_tile(tile, va, pa, qa); };
 		auto ldB = [&](int tile) { if constexpr (BINS) load_bins(tile, wb); else load_tile(tile, vb, pb, qb); };
 #else
-		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, va, pa, qa); };
-		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, vb, pb, qb); };
+		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, tile, va, pa, qa); };
+		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, tile, vb, pb, qb); };
 		auto ldA = [&](int tile) { if constexpr (!BINS) load_tile(tile, va, pa, qa); };
 		auto ldB = [&](int tile) { if constexpr (!BINS) load_tile(tile, vb, pb, qb); };
 #endif
@@ -691,7 +712,10 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 				int K;
 				if (r == 0) n0 += IT;                                 // the tile in buffer b is now counted
 				if (lead) {
-					if (pendK >= 0) round_back(pendK, par ^ 1);       // the previous round's update
+					if (pendK >= 0) {
+						round_back(pendK, par ^ 1);                   // the previous round's update
+						if (IS_IQ) afc_step(tile - 1);                // (IQ classes run one round per tile)
+					}
 					if (r == 0) {
 						const int64_t limit = (((n0 - 1 - NT / 2 - SD_MARGIN) << 16) | 0xFFFF);
 						K_total = (st.t_next <= limit) ? (int)((uint32_t)(limit - st.t_next) / (uint32_t)st.period) + 1 : 0;
@@ -726,7 +750,10 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			}
 		}
 		// ---- epilogue of the round role: the last round's update ...
-		if (lead && pendK >= 0) round_back(pendK, (int)((seq & 1u) ^ 1u));
+		if (lead && pendK >= 0) {
+			round_back(pendK, (int)((seq & 1u) ^ 1u));
+			if (IS_IQ) afc_step(n_tiles - 1);
+		}
 		if (lead && lane == 0) s.pub.wpos = st.wpos;
 #ifdef SD_EPI_TIMESTAMPS
 		if (threadIdx.x == 0) s_life[2] = __builtin_amdgcn_s_memtime();
@@ -741,7 +768,7 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	if (tid == 0) {
 		st.n0 = n0;
 		if (IS_IQ) { st.iq_last[0] = s.iq_last[0]; st.iq_last[1] = s.iq_last[1]; }
-		st.yprev = 0.0f;
+		if (IS_IQ) { st.afc[0] = s.afc_u[n_tiles & 3]; st.afc[1] = s.afc_u[(n_tiles + 1) & 3]; st.afc[2] = s.afc_u[(n_tiles + 2) & 3]; }
 		states[ch] = st;
 	}
 

@@ -9,6 +9,7 @@
 #define AT_C1  0.6332877278327942f     // 0x3F221F25
 #define AT_C3 -0.18171308934688568f    // 0xBE3A12FF
 #define AT_C5  0.04842534288764f       // 0x3D4659A7
+#define AT_FLOOR 6.9721523e-31f        // 0x0D624260
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -50,8 +51,10 @@ __device__ __forceinline__ float sd_recip(float x)
 // Scalar on purpose: on gfx950 a v_pk_fma_f32 costs as much VALU time as two v_fmac_f32 (tools/ubench/valu_rate.hip).
 __device__ __forceinline__ float sd_atan2q(float y, float x)
 {
-	const float s = __builtin_fmaxf(__builtin_fabsf(x) + __builtin_fabsf(y), 1.0e-30f);
-	const float d = __builtin_fabsf(x) - __builtin_fabsf(y);
+	// atan2q(0, 0) = 0 (round 4): the divisor is floored at the float for which seed + one Newton step give r = d * rc = exactly 1 at
+	// (0, 0), where the polynomial is exactly 1/2; the numerator comes from the floored sum, d = s - 2|y| (SPEC 3.1, oracle or_atan2)
+	const float s = __builtin_fmaxf(__builtin_fabsf(x) + __builtin_fabsf(y), AT_FLOOR);
+	const float d = __builtin_fmaf(-2.0f, __builtin_fabsf(y), s);
 	float rc = __uint_as_float(0x7EF311C7u - __float_as_uint(s));
 	const float e = __builtin_fmaf(-s, rc, 1.0f);
 	rc = __builtin_fmaf(rc, e, rc);
@@ -63,6 +66,17 @@ __device__ __forceinline__ float sd_atan2q(float y, float x)
 	const float s2 = __uint_as_float((uint32_t)((int32_t)__float_as_uint(x) >> 31) & 0x40000000u);     // 2.0 or 0.0
 	const float q2 = s2 - q;                                                                       // x < 0: 2 - q
 	return __builtin_copysignf(q2, y);
+}
+
+// AFC (SPEC 3.0b): the product x1 conj(x0) turned back by the phasor (c, sn) = (1 - u^2, 2u) before the arctangent; the phasor's
+// length does not matter to an arctangent
+__device__ __forceinline__ float sd_disc_rot(float x1, float y1, float x0, float y0, float c, float sn)
+{
+	const float cross = __builtin_fmaf(-x1, y0, y1 * x0);
+	const float dot = __builtin_fmaf(y1, y0, x1 * x0);
+	const float cr = __builtin_fmaf(-dot, sn, cross * c);
+	const float dr = __builtin_fmaf(cross, sn, dot * c);
+	return sd_atan2q(cr, dr);
 }
 
 // (cross, dot) of x1 * conj(x0): cross = fmaf(-x1, y0, y1*x0), dot = fmaf(y1, y0, x1*x0)  (SPEC 3.1)

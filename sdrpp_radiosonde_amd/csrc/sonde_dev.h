@@ -59,14 +59,18 @@ struct SdChanState {        // demodulator state, one per channel (64 B)
 	int64_t  n0;            // samples consumed
 	uint64_t wpos;          // bits produced
 	int32_t  period;        // Q16
-	float    yprev;         // reserved (0): the Gardner term no longer crosses rounds, SPEC 3.2
+	int32_t  nstat;
 	float    bias;
 	float    amp;
 	float    iq_last[2];    // previous IQ sample (I, Q) of the discriminator
-	int32_t  nstat;
 	int32_t  type;
-	int32_t  pad[2];
+	float    afc[3];        // SPEC 3.0b: the AFC states u the discriminator of the next three tiles uses, oldest first (IQ input)
 };
+static_assert(sizeof(SdChanState) == 64, "SdChanState is 64 bytes");
+// AFC (SPEC 3.0b): rotation 2 atan(u) per internal sample; per tile u <- clamp(u - LEAK u + GAIN bias, +-MAX)
+#define SD_AFC_GAIN 0.19634954f
+#define SD_AFC_LEAK 0.0078125f
+#define SD_AFC_MAX  0.8f
 
 struct SdFramerState {      // framer state, one per channel (32 B)
 	uint64_t rpos;          // the sync search resumes at this absolute bit index

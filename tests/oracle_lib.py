@@ -112,6 +112,8 @@ def lib():
     L.or_afsk_table.argtypes = [f32p]
     L.or_imet_crc.restype = C.c_uint16
     L.or_imet_crc.argtypes = [C.POINTER(C.c_uint8), C.c_size_t]
+    L.or_yard_batch_run.restype = C.c_size_t
+    L.or_yard_batch_run.argtypes = [C.c_int, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t]
     L.or_gf256_init()
     _lib = L
     return L
@@ -135,6 +137,18 @@ def batch_run(sonde_type: int, iq: np.ndarray, nthreads: int = 1, cap_per_channe
     cap = nch * (cap_per_channel or (n // 4096 + 8))      # shortest frame: DFM, 560 chips = 5376 samples
     out = np.zeros(cap, dtype=FRAME_DTYPE)
     total = L.or_batch_run(sonde_type, fptr(iq.reshape(-1)), nch, n, nthreads, out.ctypes.data, cap)
+    assert total <= cap
+    return out[:total]
+
+
+def yard_run(sonde_type: int, iq: np.ndarray, nthreads: int = 1, cutoff_rel: float = 0.0, loop_bw: float = 0.0, cap_per_channel: int = 0) -> np.ndarray:
+    """The conventional yardstick receiver (oracle/or_yardstick.c) over iq = [C, n, 2]: frames in (channel, time) order."""
+    L = lib()
+    iq = np.ascontiguousarray(iq, dtype=np.float32)
+    nch, n = iq.shape[0], iq.shape[1]
+    cap = nch * (cap_per_channel or (n // 4096 + 8))
+    out = np.zeros(cap, dtype=FRAME_DTYPE)
+    total = L.or_yard_batch_run(sonde_type, fptr(iq.reshape(-1)), nch, n, nthreads, cutoff_rel, loop_bw, out.ctypes.data, cap)
     assert total <= cap
     return out[:total]
 

@@ -229,16 +229,18 @@ def test_pfb_forms_give_identical_bins(oracle, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bps,streams", [(1, 1), (2, 1), (1, 2), (5, 1)])
+@pytest.mark.parametrize("bps,streams", [(1, 1), (2, 1), (1, 2), (5, 1), (4, 8)])
 def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
     """The default mode: the per-bin discriminator and the composite resampler + decimator (SPEC 3.5b) run inside the decoder
     kernel (two launches per submit, the 48 kS/s rows never exist).  Frames of every bin == the oracle's (or_chan.c
     or_chan_block2 -> or_channel, pre-decimated input), for
-    RS41 (4:1 class) and M10 (2:1 class) bins, one and two blocks per submit, one and two streams per object."""
+    RS41 (4:1 class) and M10 (2:1 class) bins, one and two blocks per submit, one and two streams per object; (4, 8) = the shape
+    of bench.py's other_configs.wideband8x4: eight streams, four blocks per submit (4096 bins x 12 tiles per decoder launch)."""
     import torch
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
     bins_active = [9, 130, 257, 500]
-    scenes = [synth.make_wideband_rs41(bins_active, 10 * BLOCK, seed=50 + s, ebn0_db=33.0, device="cuda:0")[0] for s in range(streams)]
+    nblk = 12 if bps == 4 else (10 // bps) * bps   # whole submits only: the oracle sees what the channelizer sees
+    scenes = [synth.make_wideband_rs41(bins_active, nblk * BLOCK, seed=50 + s, ebn0_db=33.0, device="cuda:0")[0] for s in range(streams)]
     types = np.zeros(512 * streams, dtype=np.uint8)
     m10_bins = [7, 23]                             # two silent bins run the M10 class kernel: mixed classes behind one channelizer
     for s_ in range(streams):
@@ -246,7 +248,7 @@ def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
     chz = SondeChannelizer(types=types, blocks_per_submit=bps, n_streams=streams)
     assert chz.fused
     got = []
-    for b in range(10 // bps):
+    for b in range(nblk // bps):
         blk = [sc[b * bps * BLOCK: (b + 1) * bps * BLOCK] for sc in scenes]
         chz.submit(torch.stack(blk).contiguous() if streams > 1 else blk[0].contiguous())
         got.append(chz.frames())

@@ -1,0 +1,141 @@
+"""-m gpu: every number of the driver's bench line has a parity test at ITS shape and ITS flags.
+
+bench.py entry                      test here
+other_configs.mix4096               test_mix4096_pipelined_five_blocks_back_to_back   (SONDE_FLAG_PIPELINE, 4096 x 24 tiles x 5 blocks)
+low_snr                             test_headline_shape_at_9_db                        (1024 x 96 tiles, Eb/N0 9 dB)
+other_configs.rt1250, ch1280x96     test_part_filled_last_generation[1250-24-4 / 1280-96-4]  (not a multiple of one residency; pipelined, two units)
+other_configs.wideband8x4           tests/test_channelizer.py::test_fused_channelizer_frames_equal_oracle[4-8]
+
+What a frame stream must equal: /root/reference/src/decode/decoder.hpp:61 (one X_decode call sequence per channel); the oracle
+(oracle/, the CPU restatement) stands for it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sdrpp_radiosonde_amd import synth
+from sdrpp_radiosonde_amd._lib import FLAG_PIPELINE
+from sdrpp_radiosonde_amd.batch import SondeBatch, strided_rows
+
+pytestmark = pytest.mark.gpu
+TILE = 2048
+CORES = os.cpu_count() or 4
+
+
+def _key(a):
+    return a[np.lexsort((a["bitpos"], a["channel"]))]
+
+
+def test_mix4096_pipelined_five_blocks_back_to_back(oracle):
+    """BASELINE configs[2] as bench.py measures it: RS41 / M10 / DFM09 by channel % 3, 4096 channels x 24 tiles per submit,
+    five consecutive blocks, SONDE_FLAG_PIPELINE (every type's kernels keep their own stream and are never joined), rows on
+    the recommended stride.  (a) two submits in flight, frames per ticket: all frames byte for byte the oracle's over the
+    whole 120-tile signal; (b) all five submits queued with NO host interaction in between (the bench's loop): the frames of
+    the last two tickets and every channel's loop state and newest bits equal run (a)'s."""
+    C, tiles, NB = 4096, 24, 5
+    n = tiles * TILE
+    order = (0, 3, 1)
+    types = np.array([order[c % 3] for c in range(C)], dtype=np.uint8)
+    iq = torch.empty((C, NB * n, 2), dtype=torch.float32, device="cuda:0")
+    refs = []
+    for t in order:
+        idx = np.nonzero(types == t)[0]
+        sb = synth.make_batch(int(t), len(idx), NB * n, seed=700 + int(t), ebn0_db=16.0, device="cuda:0")
+        iq[torch.from_numpy(idx).to("cuda:0")] = sb.iq
+        r = oracle.batch_run(int(t), sb.iq.cpu().numpy(), nthreads=CORES)
+        r["channel"] = idx[r["channel"]]
+        refs.append(r)
+        del sb
+    ref = _key(np.concatenate(refs))
+    blocks = [strided_rows(iq[:, k * n: (k + 1) * n].contiguous()) for k in range(NB)]
+    del iq
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+
+    # (a) tickets, two submits in flight
+    b = SondeBatch(C, n, types=types, flags=FLAG_PIPELINE)
+    b.ticket()
+    per_ticket = []
+    for k in range(NB):
+        b.submit(blocks[k], st)
+        if k >= 1:
+            per_ticket.append(b.frames_of(k))
+    per_ticket.append(b.frames_of(NB))
+    got = _key(np.concatenate(per_ticket))
+    assert len(ref) >= 3 * C
+    assert got.tobytes() == ref.tobytes()
+    probe = list(range(0, C, 61))
+    state_a = [b.state(c) for c in probe]
+    nb_a = [b.nbits(c) for c in probe]
+    bits_a = [b.read_bits(c, nb_a[i] - 2000, 2000) for i, c in enumerate(probe)]
+    b.close()
+
+    # (b) the bench's loop: five submits, nothing in between
+    b = SondeBatch(C, n, types=types, flags=FLAG_PIPELINE)
+    for k in range(NB):
+        b.submit(blocks[k], st)
+    f5 = b.frames_of(NB)
+    f4 = b.frames_of(NB - 1)
+    assert f5.tobytes() == per_ticket[NB - 1].tobytes() and f4.tobytes() == per_ticket[NB - 2].tobytes()
+    for i, c in enumerate(probe):
+        assert b.state(c) == state_a[i] and b.nbits(c) == nb_a[i], c
+        assert np.array_equal(b.read_bits(c, nb_a[i] - 2000, 2000), bits_a[i]), c
+    b.close()
+
+
+def test_headline_shape_at_9_db(oracle):
+    """bench.py's low_snr entry: the headline shape (1024 RS41 channels x 96 tiles, one residency, in-loop clean-frame
+    decoder active) at Eb/N0 9 dB, where most frames need the Reed-Solomon corrector's general path in the epilogue and
+    some are beyond it: every record -- corrected, rejected (nerr -1) -- equals the oracle's."""
+    C, n = 1024, 96 * TILE
+    sb = synth.make_rs41_batch(C, n, seed=909, ebn0_db=9.0, device="cuda:0")
+    b = SondeBatch(C, n)
+    b.submit(strided_rows(sb.iq))
+    got = b.frames()
+    ref = oracle.batch_run(0, sb.iq.cpu().numpy(), nthreads=CORES)
+    assert len(ref) >= 4 * C
+    assert got.tobytes() == ref.tobytes()
+    touched = (got["nerr"] != 0).any(axis=1).sum()                # corrected or given up (-1): the corrector's general path ran
+    assert touched >= 0.9 * len(got), (touched, len(got))
+    good = got[(got["nerr"] >= 0).all(axis=1)]
+    assert (got["nerr"] > 0).any(axis=1).sum() >= 0.2 * len(got) and len(good) >= 0.1 * len(got)
+    for f in good[:: max(1, len(good) // 400)]:                   # a sample: FEC-clean frames are transmitted frames
+        assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in sb.frames[f["channel"]])
+
+
+@pytest.mark.parametrize("C,tiles,flags", [(1250, 24, FLAG_PIPELINE), (1280, 96, FLAG_PIPELINE), (1250, 48, 0), (1537, 24, 0)])
+def test_part_filled_last_generation(oracle, C, tiles, flags):
+    """Channel counts that are not a multiple of one residency (4 workgroups x 256 CUs): 1250 x 24 tiles = bench.py's rt1250 (the
+    north_star's per-GPU share of 10^4 channels, one second per submit), 1280 x 96 = ch1280x96, both as the bench runs them:
+    SONDE_FLAG_PIPELINE, i.e. two launch units on their own streams, submits queued back to back (frames per ticket, two in
+    flight); 1537 = 1.5 residencies + 1 and 1250 x 48 joined (flags 0).  Four consecutive submits; frames, bit counts and loop
+    state against the oracle."""
+    n, NS = tiles * TILE, 4
+    sb = synth.make_rs41_batch(C, NS * n, seed=1250 + C, ebn0_db=13.0, device="cuda:0")
+    blocks = [strided_rows(sb.iq[:, k * n: (k + 1) * n].contiguous()) for k in range(NS)]
+    b = SondeBatch(C, n, flags=flags)
+    st = torch.cuda.current_stream().cuda_stream
+    parts = []
+    if flags & FLAG_PIPELINE:
+        b.ticket()
+        for k in range(NS):
+            b.submit(blocks[k], st)
+            if k >= 1:
+                parts.append(b.frames_of(k))
+        parts.append(b.frames_of(NS))
+    else:
+        for k in range(NS):
+            b.submit(blocks[k], st)
+            parts.append(b.frames())
+    got = _key(np.concatenate(parts))
+    host = sb.iq.cpu().numpy()
+    ref = oracle.batch_run(0, host, nthreads=CORES)
+    assert len(ref) >= C * (NS * n // 48000 - 1)
+    assert got.tobytes() == ref.tobytes()
+    for c in (0, 1023, 1024, 1025, C - 1):
+        ch = oracle.Channel(0, c)
+        ch.feed(host[c])
+        rs, gs = ch.state(), b.state(c)
+        assert (gs["t_next"], gs["period"], gs["bias"], gs["amp"]) == (rs["t_next"], rs["period"], rs["bias"], rs["amp"]), c
+        assert b.nbits(c) == len(ch.bits())

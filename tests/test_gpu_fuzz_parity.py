@@ -14,18 +14,21 @@ pytestmark = pytest.mark.gpu
 TILE = 2048
 
 
-@pytest.mark.parametrize("ebn0,seed", [(5.0, 1), (7.5, 2), (10.0, 3), (12.5, 4)])
-def test_mixed_batch_low_snr_bit_exact(ebn0, seed):
-    run_mixed(ebn0, seed, check_coverage=True)
+@pytest.mark.parametrize("ebn0,seed,flags,cfo", [(5.0, 1, 0, 500.0), (7.5, 2, 4, 500.0), (10.0, 3, 0, 2500.0), (12.5, 4, 4, 2000.0)])
+def test_mixed_batch_low_snr_bit_exact(ebn0, seed, flags, cfo):
+    run_mixed(ebn0, seed, check_coverage=True, flags=flags, cfo_max_hz=cfo)
 
 
-def run_mixed(ebn0, seed, check_coverage):
-    """(also driven by tools/fuzz_campaign.py over many seeds)"""
+def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0):
+    """(also driven by tools/fuzz_campaign.py over many seeds)  flags & 4 (SONDE_FLAG_PIPELINE): the submits are queued with two
+    in flight and the frames fetched per ticket; the state is compared at the end.  cfo_max_hz: carrier offsets up to this
+    (the AFC of SPEC 3.0b at work; beyond +-2 kHz frames are lost on both sides alike)."""
     types_cycle = (0, 1, 2, 3, 6)                       # the GFSK family (the AFSK sondes need 16384-sample submits: below)
     per, n_sub, n = 10, 3, TILE * 32
     parts, types = [], []
     for t in types_cycle:
-        sb = synth.make_batch(t, per, n * n_sub, seed=100 * seed + t, ebn0_db=ebn0 + (2.0 if t else 0.0), invert=(t == 1 and seed % 2 == 0))
+        sb = synth.make_batch(t, per, n * n_sub, seed=100 * seed + t, ebn0_db=ebn0 + (2.0 if t else 0.0), invert=(t == 1 and seed % 2 == 0),
+                              cfo_max_hz=cfo_max_hz)
         parts.append(sb.iq)
         types += [t] * per
     iq = torch.cat(parts)
@@ -34,11 +37,34 @@ def run_mixed(ebn0, seed, check_coverage):
     perm = np.random.default_rng(seed).permutation(len(types))
     iq, types = iq[torch.from_numpy(perm)].contiguous(), types[perm]
     C = len(types)
-    b = SondeBatch(C, n, types=types)
+    b = SondeBatch(C, n, types=types, flags=flags)
     dev = iq.cuda()
     chs = [oracle_lib.Channel(int(types[c]), c) for c in range(C)]
     x = iq.numpy()
     total = 0
+    if flags & 4:
+        st_ = torch.cuda.current_stream().cuda_stream
+        b.ticket()
+        parts = []
+        for k in range(n_sub):
+            b.submit(dev[:, k * n:(k + 1) * n].contiguous(), st_)
+            if k >= 1:
+                parts.append(b.frames_of(k))
+        parts.append(b.frames_of(n_sub))
+        for c, ch in enumerate(chs):
+            ch.feed(x[c])
+        got = np.concatenate(parts)
+        ref = np.concatenate([ch.frames() for ch in chs])
+        got = got[np.lexsort((got["bitpos"], got["channel"]))]
+        ref = ref[np.lexsort((ref["bitpos"], ref["channel"]))]
+        assert len(got) == len(ref) and got.tobytes() == ref.tobytes()
+        total = len(got)
+        for c, ch in enumerate(chs):
+            st, rs = b.state(c), ch.state()
+            assert st["t_next"] == rs["t_next"] and st["period"] == rs["period"], c
+            assert np.float32(st["bias"]).tobytes() == np.float32(rs["bias"]).tobytes() and np.float32(st["yprev"]).tobytes() == np.float32(rs["yprev"]).tobytes()
+            assert b.nbits(c) == len(ch.bits())
+        n_sub = 0
     for k in range(n_sub):
         b.submit(dev[:, k * n:(k + 1) * n])
         b.sync()
@@ -56,6 +82,7 @@ def run_mixed(ebn0, seed, check_coverage):
             st, rs = b.state(c), ch.state()
             assert st["t_next"] == rs["t_next"] and st["period"] == rs["period"], (k, c)
             assert np.float32(st["bias"]).tobytes() == np.float32(rs["bias"]).tobytes()
+            assert np.float32(st["yprev"]).tobytes() == np.float32(rs["yprev"]).tobytes()      # (the newest AFC state, SPEC 3.0b)
             assert b.nbits(c) == len(ch.bits())
     b.close()
     if not check_coverage:

@@ -18,7 +18,8 @@ def test_atan2_polynomial_accuracy_and_quadrants(oracle):
     # SPEC 3.1 (round 3): three-term polynomial (7e-4 rad) + ONE Newton step on the reciprocal (0.26 %): <= 2.5e-3 rad
     # the consumer is a low-pass FIR and a hard slicer; sensitivity unchanged (profiles/r3_sensitivity.md)
     assert np.max(np.abs(got - ref)) < 2.5e-3
-    assert abs(L.or_atan2(0.0, 0.0)) == 0.5            # the divisor is floored, r = 0: the diagonal
+    assert L.or_atan2(0.0, 0.0) == 0.0 and L.or_atan2(-0.0, 0.0) == 0.0      # round 4: the floored divisor gives r = exactly 1
+    assert abs(L.or_atan2(0.0, -0.0)) == 2.0                                 # (IEEE atan2(+-0, -0) = +-pi)
     assert abs(L.or_atan2(0.0, 1.0)) < 1.6e-3
     assert abs(L.or_atan2(1.0, 0.0) - 1.0) < 1.6e-3
     assert abs(L.or_atan2(0.0, -1.0) - 2.0) < 1.6e-3
