@@ -492,7 +492,8 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
         blocks, types, scatter = scattered_blocks(args, rank, local_rank, world, dev, dist, barrier)
     else:
         blocks, types = make_blocks(kind, C, args.tiles, args.blocks, args.ebn0, dev, seed=1000 + rank, first_channel=rank * C)
-    blocks = restride(blocks, args)
+    if not (scatter is not None and scatter.get("rows_delivered_strided")):      # (the native scatter delivers strided rows itself)
+        blocks = restride(blocks, args)
     m = measure(blocks, types, args.flags, args, local_rank, barrier, stream)
     if args.pmc_child:
         return None
@@ -627,7 +628,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
             others[name] = {
                 "workload": "BASELINE configs[3]: " + w["config"]["workload"], "ms_per_step": w["ms_per_step"], "value": w["value"],
                 "unit": w["unit"], "realtime_streams": w["realtime_streams"], "us_per_stream_block": round(w["ms_per_step"] * 1e3 / (S * B), 2),
-                "kernel_ms": w["kernel_ms"], "steps": a.steps, "warmup": a.warmup}
+                "step_frac": w["roofline"]["step_frac"], "kernel_ms": w["kernel_ms"], "steps": a.steps, "warmup": a.warmup}
         out["other_configs"] = others
         if getattr(args, "row_stride", "pow2") == "pow2" and not args.stride_pad:
             # the same workload with the rows back to back, measured in this run: what the layout is worth
@@ -654,6 +655,7 @@ def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
     from sdrpp_radiosonde_amd.shard import scatter_iq
     C, n, NB = args.channels, args.tiles * 2048, args.blocks
     cyc = NB > 1 and cyclic_ok(n, NB)
+    strided = getattr(args, "row_stride", "pow2") == "pow2" and not args.stride_pad
     if not cyc:
         NB = 1                                   # no seamless cycle of this shape: one block, re-submitted
     ns, fallback = None, ""
@@ -678,7 +680,10 @@ def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
         torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
-        blk = ns.scatter_iq(full, (C, n, 2), root=0) if ns is not None else scatter_iq(full, C, n, dev, src=0)
+        if ns is not None and strided:
+            blk = ns.scatter_rows(full, world * C, n, root=0)          # straight into rows on the decoder's channel stride: no re-stride copy
+        else:
+            blk = ns.scatter_iq(full, (C, n, 2), root=0) if ns is not None else scatter_iq(full, C, n, dev, src=0)
         torch.cuda.synchronize()
         ms += (time.perf_counter() - t0) * 1e3
         blocks.append(blk)
@@ -688,7 +693,10 @@ def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
     gbs = sent / (ms * 1e-3) / 1e9
     bound = 7 * 153.0                                        # GB/s: all seven xGMI links of the root at once
     return blocks, None, {
-        "ingest": "scatter from rank 0: torch.distributed" if args.scatter_torch else "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)",
+        "ingest": "scatter from rank 0: torch.distributed" if args.scatter_torch else
+                  ("scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv, one per row, straight into rows on the decoder's channel stride)" if strided
+                   else "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)"),
+        "rows_delivered_strided": bool(ns is not None and strided),
         "ms": round(ms, 3), "blocks": NB, "bytes_from_root": sent, "gbs": round(gbs, 2),
         "root_egress_bound_gbs": bound, "frac_of_bound": round(gbs / (bound * min(1.0, (world - 1) / 7.0)), 4),
         "note": "root holds one block of all ranks at a time; outside the timed region"}
@@ -740,19 +748,19 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
         "value": round(msps, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ramp_ms": args.ramp_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{S} x 10 MS/s complex IQ -> 512-bin polyphase channelizer (40 kS/s/bin) -> FM discriminator -> 6/5 resampler "
+        "config": {"workload": f"{S} x 10 MS/s complex IQ -> 512-bin polyphase channelizer (20 kS/s/bin, one phase sample per step) -> FM discriminator (wrapped phase difference) -> 12/5 resampler "
                                f"-> {S} x 512 x 48 kS/s RS41 demod+FEC, one launch per stage over all streams; {nwb} wideband samples per stream per step", "streams_per_gpu": S,
                    "wideband_samples_per_step": nwb},
         "realtime_factor": round(msps * 1e6 / (S * world * 10e6) , 2),
         "realtime_streams": round(msps / 10.0, 1),
-        "narrowband_msps": round(512 * (nwb * 6 // 5 // 250) * S * world * args.steps / dt / 1e6, 3),
+        "narrowband_msps": round(512 * (nwb * 12 // 5 // 500) * S * world * args.steps / dt / 1e6, 3),
         "frames_per_step": round(nfr_total, 2),
         "kernel_ms": {"pfb_fft": round(pfb_ms, 4), "disc_resample": round(rs_ms, 4), "demod": round(dem_ms, 4), "framer_fec": round(fr_ms, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": None, "algorithmic_bytes": alg_bytes, "kernel": "sd_pfb_kernel (8 B per wideband sample read once)",
-                     "written_bytes": S * (nwb // 250) * 512 * 8,
-                     "note": "algorithmic bytes = the wideband samples read once; the launch also WRITES 16.4 B per sample (the bins) and re-reads its "
-                             "5 x overlapping windows through the L2; one 80 MB/s stream is latency-bound, nowhere near the HBM roofline"},
+                     "traffic": None, "algorithmic_bytes": alg_bytes, "kernel": "sd_pfb_kernel (8 B per wideband sample read once)", "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "written_bytes": S * (nwb // 500) * 512 * 4,
+                     "note": "algorithmic bytes = the wideband samples read once; the launch also writes 4.1 B per sample (one phase per bin and step, "
+                             "re-read once by the decoder) and re-reads its overlapping windows through the L2"},
     }
 
 

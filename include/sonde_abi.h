@@ -147,7 +147,8 @@ void sonde_batch_destroy(SondeBatch *b);
  * Layout advice (measured): the kernel streams every channel's row at once, and how far apart the rows lie decides how
  * they spread over the HBM channels: 1024 rows of 1.5 MiB run 2.3-5.5 % faster 2 MiB apart than back to back, while a stride a
  * little off a power of two (2064 KiB) is 7 % slower.  sonde_row_stride() returns the stride (in elements) the library uses for
- * its own staging buffer: the next power of two in bytes. */
+ * its own staging buffer: the next power of two in bytes where that costs at most a third more memory (1.5 MiB rows -> 2 MiB),
+ * else the next odd multiple of 64 KiB (rows of 1.01 MiB -> 1.0625 MiB, not 2 MiB); rows below 64 KiB stay back to back. */
 size_t sonde_row_stride(size_t n_samples, int input_kind);
 int  sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream);
 /* Same, from HOST memory (staged through an internal pinned/device buffer; PCIe-inclusive). */
@@ -227,10 +228,13 @@ float sonde_m20_temp(unsigned adc);
 float sonde_ims100_temp(uint32_t f, float c0, float c1, float c2);
 
 /* ------------------------------------------------------------------ wideband front-end (BASELINE config 4)
- * 10 MS/s complex IQ -> 512-bin polyphase channelizer (19531.25 Hz spacing, 40 kS/s per bin) -> per-bin FM
- * discriminator -> 6/5 rational resampler -> 48 kS/s -> the decoder of the bin's sonde type: the reference's
- * VFO -> dsp::demod::FM -> RationalResampler -> Decoder chain (/root/reference/src/main.cpp:55-68) for every
- * bin at once.  One submit takes blocks_per_submit * 1 280 000 wideband samples (device pointer, complex64, 16-byte
+ * 10 MS/s complex IQ -> 512-bin polyphase channelizer (19531.25 Hz spacing, 20 kS/s per bin; a bin leaves the filter bank as
+ * one PHASE sample per step) -> per-bin FM discriminator (wrapped phase difference) -> 12/5 rational resampler -> 48 kS/s ->
+ * the decoder of the bin's sonde type: the reference's VFO -> dsp::demod::FM -> RationalResampler -> Decoder chain
+ * (/root/reference/src/main.cpp:55-68) for every bin at once.  A bin carries the sondes whose channel is 10-20 kHz wide in the
+ * reference (RS41, DFM, iMS-100, MRZ-N1; iMet-4 and SRS-C50 in the unfused mode); an M10 / M20 channel is 50 kHz wide
+ * (/root/reference/src/main.hpp:48) and does not fit: sonde_chan_create fails for SONDE_M10 bins (use sonde_vfo_* for those).
+ * One submit takes blocks_per_submit * 1 280 000 wideband samples (device pointer, complex64, 16-byte
  * aligned); the filter bank reads the block in place, so it must stay untouched until the submit's kernels have run
  * (stream order, as for sonde_batch_submit). */
 typedef struct SondeChannelizer SondeChannelizer;
@@ -241,10 +245,10 @@ int         sonde_chan_create(const uint8_t *types /* 512 entries or NULL = RS41
  * [n_streams][n_samples] complex64; channel s * 512 + k of sonde_chan_batch() is bin k of stream s. */
 int         sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out);
 uint32_t    sonde_chan_streams(const SondeChannelizer *c);
-/* By default (where every bin's sonde type allows it: no AFSK sonde) the per-bin discriminator and the 6/5 resampler run in
+/* By default (where every bin's sonde type allows it: no AFSK sonde) the per-bin discriminator and the 12/5 resampler run in
  * the decoder kernel's load path: a submit is two launches and the 48 kS/s rows never exist in HBM.  on = 0 keeps them as a
  * kernel of their own (then sonde_chan_read can return the rows: parity tests).  Call before the first submit; returns the mode
- * in force (1 fused, 0 not). */
+ * in force (1 fused, 0 not); on < 0 only asks. */
 int         sonde_chan_set_fused(SondeChannelizer *c, int on);
 /* Option (fused mode only, off by default; also SONDE_CHAN_OVERLAP in the environment): the filter bank runs on an internal
  * stream, the decoder on another, the bins are double-buffered, so the filter bank of submit k+1 may run beside the decoder
@@ -257,7 +261,9 @@ void        sonde_chan_destroy(SondeChannelizer *c);
 uint32_t    sonde_chan_samples_per_submit(const SondeChannelizer *c);
 int         sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t n_samples, void *stream);
 SondeBatch *sonde_chan_batch(SondeChannelizer *c);     /* frames of the 512 bins: sonde_batch_sync / _frames on this */
-int         sonde_chan_read(SondeChannelizer *c, float *bins, float *out48);      /* parity-test introspection */
+/* parity-test introspection: the last submit's per-bin phases ([bins][n_steps] floats, quadrants) and, unfused mode only,
+ * the 48 kS/s rows ([bins][n_steps * 12 / 5]); either pointer may be NULL (out48 != NULL in fused mode is an error) */
+int         sonde_chan_read(SondeChannelizer *c, float *bins, float *out48);
 /* average device time (ms) of the filter-bank kernel, the discriminator + resampler kernel and the decoder kernels over the
  * timed submits (every 8th) since the previous call; synchronises */
 int         sonde_chan_kernel_ms(SondeChannelizer *c, float *pfb_ms, float *disc_resamp_ms, float *demod_ms, float *framer_ms);

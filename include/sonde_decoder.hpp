@@ -188,10 +188,22 @@ public:
 	IqStreamDecoder &operator=(const IqStreamDecoder &) = delete;
 	~IqStreamDecoder() { deinit(); }
 
+	// What a plugin-equivalent host should tolerate is the reference's VFO width (main.hpp:44-52): 20 kHz for iMS-100 and MRZ-N1,
+	// 50 kHz for M10.  At 48 kS/s IQ input the library's default classes decimate those three to 12 / 12 / 24 kS/s (SPEC 3.0) and
+	// the AFC of SPEC 3.0b pulls in +-2.6 / +-2.6 / +-5.2 kHz; SONDE_FLAG_WIDE doubles the rates and the pull-in range at about 2 dB
+	// of sensitivity.  One channel costs nothing either way, so this adaptor defaults to the wide classes for those three types
+	// (ADVICE r3); kFlagsAuto = that choice, any explicit value (0 included) is taken as given.
+	static constexpr uint32_t kFlagsAuto = 0x80000000u;
+	static uint32_t default_flags(int sonde_type)
+	{
+		return (sonde_type == SONDE_IMS100 || sonde_type == SONDE_MRZN1 || sonde_type == SONDE_M10) ? SONDE_FLAG_WIDE : 0u;
+	}
+
 	// sonde_type: SONDE_* (the index into supportedTypes[], main.hpp:44-52).  false: wrong rate or no GPU decoder.
-	bool init(int sonde_type, int samplerate, Callback cb, void *ctx, int device = 0, uint32_t flags = 0)
+	bool init(int sonde_type, int samplerate, Callback cb, void *ctx, int device = 0, uint32_t flags = kFlagsAuto)
 	{
 		deinit();
+		if (flags == kFlagsAuto) flags = default_flags(sonde_type);
 		const uint8_t t = (uint8_t)sonde_type;
 		const bool afsk = sonde_type == SONDE_IMET4 || sonde_type == SONDE_C50;
 		SondeBatchConfig cfg = {};

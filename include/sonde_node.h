@@ -1,0 +1,74 @@
+/* sonde_node.h -- C ABI of the node-level host in libsonde_rccl.so: ONE process, the GPUs of one node, one decoder batch per GPU.
+ *
+ * north_star: "C++ host code ... independent narrowband channels are batched one-per-workgroup and sharded across the 8 GPUs of
+ * one node with an RCCL scatter of IQ blocks over xGMI".  The reference's unit is one module instance per channel, any number
+ * of instances, no shared state (SDRPP_MOD_INFO max instances -1, /root/reference/src/main.cpp:18-24): a node-level host is an
+ * object that owns ALL channels of the node, shards them in contiguous ranges (sonde_shard_range: device d of D gets
+ * [d C / D, (d + 1) C / D), remainders to the first devices), and hands back SondeData fragments with node-wide channel numbers
+ * (the callback of /root/reference/src/main.cpp:320-331, once per channel).
+ *
+ * Data path of one sonde_node_submit(): the IQ of all channels sits on the INGEST device (an SDR front-end attached to one
+ * GPU); every other device receives its shard over xGMI straight into the rows its decoder reads -- rows on the recommended
+ * channel stride (sonde_row_stride), no re-stride copy -- as ONE group of ncclSend (ingest device, one per peer and row run) and
+ * ncclRecv (peers); the ingest device's own shard is a strided device copy, not a send to itself; then every device runs its
+ * own sonde_batch_submit.  There is no other collective: channels are independent.  Frames come back per device straight to
+ * host memory (one process: the host is shared; nothing travels back over xGMI).
+ *
+ * When the ingest rows already lie on the recommended stride (channel_stride == sonde_row_stride(n_samples)) a peer's shard is
+ * one contiguous run (padding included): one send per peer.  Otherwise one send per row.
+ *
+ * All int / long calls: >= 0 ok, negative = error (text: sonde_node_last_error()).  Not thread-safe per object. */
+#ifndef SONDE_NODE_H
+#define SONDE_NODE_H
+#include <stddef.h>
+#include <stdint.h>
+#include "sonde_abi.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SondeNode SondeNode;
+
+typedef struct {
+	uint32_t       n_devices;     /* 1 .. 16 */
+	const int32_t *devices;       /* HIP ordinals, n_devices entries; NULL = 0 .. n_devices - 1 */
+	uint32_t       ingest;        /* index into devices[] of the device that receives the IQ of all channels */
+	uint32_t       n_channels;    /* all channels of the node */
+	const uint8_t *types;         /* n_channels entries of SONDE_*; NULL = all SONDE_RS41 */
+	uint32_t       max_samples;   /* largest samples-per-channel of one submit (multiple of SONDE_TILE) */
+	int32_t        input_kind;    /* SONDE_INPUT_IQ or SONDE_INPUT_REAL */
+	uint32_t       flags;         /* SONDE_FLAG_* of the per-device batches */
+} SondeNodeConfig;
+
+int    sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out);
+void   sonde_node_destroy(SondeNode *n);
+uint32_t sonde_node_devices(const SondeNode *n);
+/* channel range of device index d */
+int    sonde_node_range(const SondeNode *n, uint32_t d, uint32_t *first, uint32_t *count);
+/* the batch of device index d (sonde_batch_* introspection: kernel times, bits, state); owned by the node */
+SondeBatch *sonde_node_batch(SondeNode *n, uint32_t d);
+
+/* samples: DEVICE pointer on the ingest device, channel-major, channel c at element c * channel_stride (as
+ * sonde_batch_submit).  Scatters, then submits on every device.  Asynchronous; the ingest buffer may be reused once
+ * sonde_node_scatter_done() / sonde_node_sync() has returned. */
+int    sonde_node_submit(SondeNode *n, const void *samples, size_t n_samples, size_t channel_stride);
+/* Every device's shard is already resident on that device (rank-local ingest: no scatter): rows[d] = device pointer on device d,
+ * channel-major, channel_stride elements apart. */
+int    sonde_node_submit_local(SondeNode *n, const void *const *rows, size_t n_samples, size_t channel_stride);
+int    sonde_node_scatter_done(SondeNode *n);
+/* wait for every device; returns the frames of the last submit, all devices (or negative) */
+long   sonde_node_sync(SondeNode *n);
+/* the last submit's frames in (node-wide channel, time) order, channel numbers node-wide */
+long   sonde_node_frames(SondeNode *n, SondeFrame *out, size_t cap);
+/* the last submit's telemetry as SondeData fragments with node-wide channel numbers (sonde_batch_poll of every device, merged in
+ * device order); call until it returns 0 */
+long   sonde_node_poll(SondeNode *n, SondeData *out, uint32_t *channel, size_t cap);
+/* device time of the last submit's scatter (ms, on the ingest device's stream; 0 for one device / submit_local), the bytes that
+ * left the ingest device, and the number of ncclSend calls they took */
+int    sonde_node_scatter_stats(SondeNode *n, float *ms, uint64_t *bytes_out, uint32_t *n_sends);
+const char *sonde_node_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -28,6 +28,12 @@ int         sonde_shard_world(const SondeShard *s);
 void        sonde_shard_range(uint32_t n_channels, int world, int rank, uint32_t *first, uint32_t *count);
 /* root holds `world` consecutive blocks of `bytes`; rank r receives block r */
 int         sonde_shard_scatter(SondeShard *s, const void *full_dev /* root only */, void *shard_dev, size_t bytes, int root, void *stream);
+/* Rows into a strided destination: n_rows_total rows of row_bytes on the root (row k at full_dev + k * src_stride_bytes); rank r
+ * receives the rows of sonde_shard_range(n_rows_total, world, r) (unequal shards allowed) at shard_dev + row * dst_stride_bytes,
+ * i.e. straight into rows on the decoder's recommended channel stride (sonde_row_stride): no re-stride copy.  The root's own
+ * shard is a device copy, not a send to itself. */
+int         sonde_shard_scatter_rows(SondeShard *s, const void *full_dev /* root only */, size_t src_stride_bytes, void *shard_dev,
+                                     size_t dst_stride_bytes, size_t row_bytes, uint32_t n_rows_total, int root, void *stream);
 /* every rank sends `bytes`; root receives block r from rank r */
 int         sonde_shard_gather(SondeShard *s, const void *part_dev, size_t bytes, void *all_dev /* root only */, int root, void *stream);
 const char *sonde_shard_last_error(void);

@@ -1,7 +1,10 @@
 /*
  * or_chan.c -- oracle for the wideband front-end (BASELINE config 4):
- *   10 MS/s complex IQ -> 512-bin oversampled polyphase filter bank (decimation 250 -> 40 kS/s per bin)
- *   -> per-bin FM discriminator at 40 kS/s -> real rational resampler 6/5 -> 48 kS/s
+ *   10 MS/s complex IQ -> 512-bin polyphase filter bank (decimation 500 -> 20 kS/s per bin: the bin spacing, 19.53 kHz,
+ *   1.024 x oversampled) -> per-bin instantaneous PHASE phi = atan2q(bin sample) -> FM discriminator as the wrapped phase
+ *   difference d[m] = wrap(phi[m] - phi[m-1]) at 20 kS/s -> real rational resampler 12/5 -> 48 kS/s
+ * (round 4: rounds 2-3 ran the bank at 40 kS/s per bin and stored complex bins -- 16.4 B written and re-read per wideband
+ * sample, 5.2 x the algorithmic traffic; a bin now leaves the filter bank as ONE float per 500 wideband samples)
  * which is the reference's own ordering  VFO channeliser -> dsp::demod::FM -> RationalResampler -> decoder
  * (/root/reference/src/main.cpp:55-60).  Those SDR++ blocks are absent from the reference tree, so the
  * arithmetic is this repo's SPEC.  TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
@@ -63,7 +66,7 @@ void or_resamp_taps(int up, double fs_up_hz, double cutoff_hz, float *g /* up * 
 	}
 	free(tmp);
 }
-void or_chan_resamp_taps(float *g /* 6*16 */) { or_resamp_taps(OR_RS_L, 240000.0, 18000.0, g); }
+void or_chan_resamp_taps(float *g /* 12*16 */) { or_resamp_taps(OR_RS_L, 240000.0, 9000.0, g); }     /* = the VFO front-end's 20 kS/s taps */
 
 /* SPEC 3.5b (round 3): behind the channelizer the 6/5 resampler and the boxcar decimator of SPEC 3.0 (4:1 or 2:1) are ONE
  * polyphase filter when the product runs them inside the decoder kernel (its default, "fused" mode): decimated sample n of a
@@ -73,16 +76,19 @@ void or_chan_resamp_taps(float *g /* 6*16 */) { or_resamp_taps(OR_RS_L, 240000.0
  * summed in double from the float taps g.  (The rows repeat every 3 decimated samples: 12 or 6 resampler outputs, 10 or 5
  * discriminator samples.)  It is the same filter as "resample, then average" up to rounding -- 19 multiply-adds per decimated
  * sample instead of 64 -- and no 48 kS/s row exists. */
-int or_chan_composite_kt(int dec) { return dec == 4 ? 19 : 17; }
-void or_chan_composite_taps(const float *g /* 6*16 */, int dec, float *G /* 3 * OR_RS_KT_LD (20) */)
+int or_chan_composite_kt(int dec) { (void)dec; return 17; }
+/* round 4 (20 kS/s bins, 12/5 resampler): decimated sample n (12 kS/s) = the mean of the 48 kS/s outputs j = 4n .. 4n+3,
+ * output j = sum_t g[5j mod 12][t] d[floor(5j/12) - t]; newest input b(n) = floor(5 (4n + 3) / 12); the rows repeat every 3
+ * decimated samples (12 outputs, 5 inputs); 17 taps in use. */
+void or_chan_composite_taps(const float *g /* 12*16 */, int dec, float *G /* 3 * OR_RS_KT_LD (20) */)
 {
 	for (int phi = 0; phi < 3; phi++) {
-		const int j0 = dec * phi, b = (5 * (j0 + dec - 1)) / 6;
+		const int j0 = dec * phi, b = (OR_RS_M * (j0 + dec - 1)) / OR_RS_L;
 		for (int k = 0; k < OR_RS_KT_LD; k++) {
 			double sum = 0.0;
 			for (int i = 0; i < dec; i++) {
-				const int j = j0 + i, t = k - (b - (5 * j) / 6);
-				if (t >= 0 && t < OR_RS_T) sum += (double)g[((5 * j) % 6) * OR_RS_T + t];
+				const int j = j0 + i, t = k - (b - (OR_RS_M * j) / OR_RS_L);
+				if (t >= 0 && t < OR_RS_T) sum += (double)g[((OR_RS_M * j) % OR_RS_L) * OR_RS_T + t];
 			}
 			G[phi * OR_RS_KT_LD + k] = (float)(sum / (double)dec);
 		}
@@ -170,7 +176,7 @@ void or_fft512(float *re, float *im, const float *tw)
 struct OrChan {
 	float h[OR_CH_L], tw[OR_CH_M], g[OR_RS_L * OR_RS_T];
 	float *hist;                 /* last L-D wideband samples (I,Q) */
-	float iq_last[OR_CH_M][2];   /* per bin: previous 40 kS/s sample */
+	float phi_last[OR_CH_M];     /* per bin: the previous phase sample */
 	float dhist[OR_CH_M][OR_RS_T];   /* per bin: last 16 discriminator samples (oldest first) */
 };
 
@@ -185,15 +191,16 @@ OrChan *or_chan_new(void)
 }
 void or_chan_free(OrChan *c) { if (c) { free(c->hist); free(c); } }
 
-/* One block: n_steps*250 wideband samples in, per bin n_steps samples at 40 kS/s (bins: [512][n_steps][2]) and,
- * if out48 != NULL, n_steps*6/5 real samples at 48 kS/s ([512][n_steps*6/5]); n_steps % 5 == 0. */
+/* One block: n_steps*500 wideband samples in, per bin n_steps phase samples at 20 kS/s (bins: [512][n_steps]) and,
+ * if out48 != NULL, n_steps*12/5 real samples at 48 kS/s ([512][n_steps*12/5]); n_steps % 5 == 0. */
 void or_chan_block(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48)
 {
 	or_chan_block2(c, iq, n_steps, bins, out48, NULL, NULL);
 }
 
-/* The same, plus (decs != NULL) the decimated rows of SPEC 3.5b: bin k with decs[k] = 2 or 4 gets n_steps*6/5/decs[k] samples
- * at outdec[k * (n_steps*6/5/2)] (row stride: the 2:1 length); decs[k] = 0 skips the bin. */
+/* The same, plus (decs != NULL) the decimated rows of SPEC 3.5b: bin k with decs[k] = 4 gets n_steps*12/5/4 samples
+ * at outdec[k * (n_steps*12/5/2)] (row stride as in round 3); decs[k] = 0 skips the bin.
+ * bins: the per-bin PHASE samples, [512][n_steps] floats (quadrants). */
 void or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48, const uint8_t *decs, float *outdec)
 {
 	const size_t H = OR_CH_L - OR_CH_D, N = n_steps * OR_CH_D;
@@ -201,7 +208,7 @@ void or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, flo
 	memcpy(buf, c->hist, 2 * H * sizeof(float));
 	memcpy(buf + 2 * H, iq, 2 * N * sizeof(float));
 	float re[OR_CH_M], im[OR_CH_M];
-	float *bl = bins ? bins : malloc((size_t)OR_CH_M * n_steps * 2 * sizeof(float));
+	float *bl = bins ? bins : malloc((size_t)OR_CH_M * n_steps * sizeof(float));
 	for (size_t m = 0; m < n_steps; m++) {
 		const float *x = buf + 2 * m * OR_CH_D;
 		const int shift = (int)((m * OR_CH_D) % OR_CH_M);
@@ -216,22 +223,26 @@ void or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, flo
 			im[(r + shift) & (OR_CH_M - 1)] = ai;
 		}
 		or_fft512(re, im, c->tw);
-		for (int k = 0; k < OR_CH_M; k++) {
-			bl[((size_t)k * n_steps + m) * 2] = re[k];
-			bl[((size_t)k * n_steps + m) * 2 + 1] = im[k];
-		}
+		for (int k = 0; k < OR_CH_M; k++) bl[(size_t)k * n_steps + m] = or_atan2(im[k], re[k]);
 	}
 	memcpy(c->hist, buf + 2 * N, 2 * H * sizeof(float));   /* last L-D samples of [hist|block] */
 	free(buf);
 	if (out48 || (decs && outdec)) {
 		const size_t n_out = n_steps * OR_RS_L / OR_RS_M;
 		float *d = malloc((OR_RS_T + n_steps) * sizeof(float));
-		float G2[3 * OR_RS_KT_LD], G4[3 * OR_RS_KT_LD];
-		or_chan_composite_taps(c->g, 2, G2);
+		float G4[3 * OR_RS_KT_LD];
 		or_chan_composite_taps(c->g, 4, G4);
 		for (int k = 0; k < OR_CH_M; k++) {
 			memcpy(d, c->dhist[k], OR_RS_T * sizeof(float));
-			or_discriminate(bl + (size_t)k * n_steps * 2, n_steps, d + OR_RS_T, c->iq_last[k]);
+			/* discriminator: the wrapped difference of consecutive phases, quadrants in [-2, 2] */
+			float prev = c->phi_last[k];
+			for (size_t m = 0; m < n_steps; m++) {
+				const float ph = bl[(size_t)k * n_steps + m];
+				const float t = ph - prev;
+				d[OR_RS_T + m] = fmaf(-4.0f, rintf(0.25f * t), t);
+				prev = ph;
+			}
+			c->phi_last[k] = prev;
 			for (size_t j = 0; out48 && j < n_out; j++) {
 				const size_t i0 = (j * OR_RS_M) / OR_RS_L;
 				const int p = (int)((j * OR_RS_M) % OR_RS_L);
@@ -239,13 +250,12 @@ void or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, flo
 				for (int t = 0; t < OR_RS_T; t++) acc = fmaf(c->g[p * OR_RS_T + t], d[OR_RS_T + i0 - t], acc);
 				out48[(size_t)k * n_out + j] = acc;
 			}
-			if (decs && outdec && decs[k]) {
-				const size_t dec = decs[k];
-				const float *G = dec == 4 ? G4 : G2;
+			if (decs && outdec && decs[k] == 4) {
+				const size_t dec = 4;
 				const int kt = or_chan_composite_kt((int)dec);
 				for (size_t n = 0; n < n_out / dec; n++) {
-					const size_t b = (5 * (dec * n + dec - 1)) / 6;
-					const float *row = G + (n % 3) * OR_RS_KT_LD;
+					const size_t b = (OR_RS_M * (dec * n + dec - 1)) / OR_RS_L;
+					const float *row = G4 + (n % 3) * OR_RS_KT_LD;
 					float acc = 0.0f;
 					for (int t = 0; t < kt; t++) acc = fmaf(row[t], d[OR_RS_T + b - t], acc);      /* b - t >= -16: the carried history */
 					outdec[(size_t)k * (n_out / 2) + n] = acc;

@@ -149,13 +149,13 @@ size_t  or_yard_batch_run(int type, const float *iq, size_t nch, size_t n, int n
 /* ---- wideband front-end (config 4): 512-bin PFB channelizer + discriminator + 6/5 resampler ---- */
 #define OR_CH_FS   10000000.0   /* wideband sample rate */
 #define OR_CH_M    512          /* bins, spacing 19531.25 Hz */
-#define OR_CH_D    250          /* decimation: 40 kS/s per bin */
+#define OR_CH_D    500          /* decimation: 20 kS/s per bin (round 4; rounds 2-3: 250) */
 #define OR_CH_T    16           /* prototype taps per bin */
 #define OR_CH_L    (OR_CH_M * OR_CH_T)
-#define OR_RS_L    6            /* resampler: up 6 */
-#define OR_RS_M    5            /*            down 5 : 40 kS/s -> 48 kS/s */
+#define OR_RS_L    12           /* resampler: up 12 */
+#define OR_RS_M    5            /*            down 5 : 20 kS/s -> 48 kS/s */
 #define OR_RS_T    16           /* taps per resampler phase */
-#define OR_RS_KT_LD 20          /* row stride of the composite (resampler + boxcar) taps, SPEC 3.5b: 19 or 17 in use */
+#define OR_RS_KT_LD 20          /* row stride of the composite (resampler + boxcar) taps, SPEC 3.5b: 17 in use */
 typedef struct OrChan OrChan;
 void    or_chan_proto(float *h);
 void    or_chan_twiddles(float *tw);

@@ -177,8 +177,10 @@ def strided_rows(x, stride: int | None = None):
 
 
 class SondeChannelizer:
-    """Wideband front-end (BASELINE config 4): n_streams x 10 MS/s complex IQ -> 512 bins each -> per-bin decode; every stage
-    is one launch over all streams.  submit() takes [samples_per_submit, 2] (one stream) or [n_streams, samples_per_submit, 2]."""
+    """Wideband front-end (BASELINE config 4): n_streams x 10 MS/s complex IQ -> 512 bins each (20 kS/s, one phase sample per
+    step) -> per-bin decode; every stage is one launch over all streams.  submit() takes [samples_per_submit, 2] (one stream) or
+    [n_streams, samples_per_submit, 2].  Bins carry the 12 kS/s sondes (RS41, DFM, iMS-100, MRZ-N1) and, unfused, the AFSK
+    sondes; an M10 channel (50 kHz wide) does not fit a 19.5 kHz bin: use SondeVfo for those."""
 
     def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0, n_streams: int = 1, fused: bool | None = None, overlap: bool | None = None):
         self.L = _lib.load()
@@ -193,12 +195,13 @@ class SondeChannelizer:
         if self.L.sonde_chan_create_multi(tp, blocks_per_submit, self.n_streams, device, C.byref(h)) != 0:
             raise SondeError(_lib.last_error() or "sonde_chan_create_multi failed")
         self.h = h
-        # fused (default where possible): discriminator + resampler inside the decoder kernel; fused=False keeps the 48 kS/s rows (read())
-        self.fused = bool(self.L.sonde_chan_set_fused(self.h, 1 if fused is None or fused else 0))
+        # fused (default where possible): discriminator + resampler inside the decoder kernel; fused=False keeps the 48 kS/s rows
+        # (read()); fused=None leaves the library's choice (and its SONDE_CHAN_UNFUSED switch) alone
+        self.fused = bool(self.L.sonde_chan_set_fused(self.h, 1 if fused else 0)) if fused is not None else bool(self.L.sonde_chan_set_fused(self.h, -1))
         # overlap (an option, off by default): filter bank of submit k+1 beside the decoder of submit k, on internal streams
         self.overlap = bool(self.L.sonde_chan_set_overlap(self.h, 1)) if overlap else False
         self.samples_per_submit = int(self.L.sonde_chan_samples_per_submit(self.h))
-        self.n_steps = self.samples_per_submit // 250
+        self.n_steps = self.samples_per_submit // 500
         self.batch = SondeBatch.__new__(SondeBatch)          # borrowed view of the embedded 512-channel batch
         self.batch.L = self.L
         self.batch.h = C.c_void_p(self.L.sonde_chan_batch(self.h))
@@ -223,9 +226,10 @@ class SondeChannelizer:
         return tuple(x.value for x in v)
 
     def read(self):
-        bins = np.zeros((512 * self.n_streams, self.n_steps, 2), dtype=np.float32)
-        out48 = np.zeros((512 * self.n_streams, self.n_steps * 6 // 5), dtype=np.float32)
-        if self.L.sonde_chan_read(self.h, bins.ctypes.data_as(C.c_void_p), out48.ctypes.data_as(C.c_void_p)) != 0:
+        """(phases [bins, n_steps] in quadrants, 48 kS/s rows [bins, n_steps * 12 / 5] or None in fused mode) of the last submit."""
+        bins = np.zeros((512 * self.n_streams, self.n_steps), dtype=np.float32)
+        out48 = None if self.fused else np.zeros((512 * self.n_streams, self.n_steps * 12 // 5), dtype=np.float32)
+        if self.L.sonde_chan_read(self.h, bins.ctypes.data_as(C.c_void_p), out48.ctypes.data_as(C.c_void_p) if out48 is not None else None) != 0:
             raise SondeError("sonde_chan_read failed")
         return bins, out48
 

@@ -503,9 +503,11 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	return submit_impl(b, samples, n_samples, channel_stride, stream_, nullptr);
 }
 
-// The channelizer's decoder batch (created with SONDE_INPUT_REAL) takes its rows as 40 kS/s complex bins instead: n_steps bin
-// samples per channel (a multiple of 5120 = 3 tiles of 48 kS/s output), the per-bin discriminator and the 6/5 resampler run
-// in the demod kernel's load path (SPEC 3.5).  Internal to the library (channelizer.hip).
+// The channelizer's decoder batch (created with SONDE_INPUT_REAL) takes its rows as 20 kS/s PHASE samples instead: n_steps floats
+// per channel (a multiple of 2560 = 3 tiles of 48 kS/s output), the per-bin discriminator (wrapped phase difference) and the
+// composite 12/5 resampler - 4:1 decimator run in the demod kernel's load path (SPEC 3.5 / 3.5b).  The 12 kS/s sondes only (class
+// (4, 8)): a 19.5 kHz bin cannot carry an M10 channel (50 kHz in the reference, /root/reference/src/main.hpp:48), and the AFSK
+// sondes want 48 kS/s rows.  Internal to the library (channelizer.hip).
 int sd_batch_bins_capable(const SondeBatch *b)
 {
 	if (!b || b->input_kind != SONDE_INPUT_REAL) return 0;
@@ -513,16 +515,16 @@ int sd_batch_bins_capable(const SondeBatch *b)
 		if (b->chlist[t].empty()) continue;
 		if (t == SONDE_IMET4 || t == SONDE_C50) return 0;                     // the tone demodulator wants 48 kS/s rows
 		const int k = modem_class(b->md, t);
-		if (!(k_cls_nt[k] == 8 && (k_cls_decim[k] == 4 || k_cls_decim[k] == 2))) return 0;
+		if (!(k_cls_nt[k] == 8 && k_cls_decim[k] == 4)) return 0;
 	}
 	return 1;
 }
 int sd_batch_submit_bins(SondeBatch *b, const void *bins, size_t n_steps, size_t channel_stride, const SdBinsIn *d_bins_in, void *stream_)
 {
 	if (!b || !bins || !d_bins_in || !sd_batch_bins_capable(b)) return fail("sd_batch_submit_bins: bad argument");
-	const size_t n_out = n_steps / 5 * 6;
-	if (n_steps == 0 || n_steps % 5120 || n_out > b->max_samples || channel_stride < n_steps || ((uintptr_t)bins & 7u))
-		return fail("sd_batch_submit_bins: n_steps must be a multiple of 5120 within max_samples");
+	const size_t n_out = n_steps / 5 * 12;
+	if (n_steps == 0 || n_steps % 2560 || n_out > b->max_samples || channel_stride < n_steps || ((uintptr_t)bins & 3u))
+		return fail("sd_batch_submit_bins: n_steps must be a multiple of 2560 within max_samples");
 	return submit_impl(b, bins, n_out, channel_stride, stream_, d_bins_in);
 }
 
@@ -537,7 +539,6 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	b->n_submits++;
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	if (timed) HIPCHK(hipEventRecord(ev[0], stream));
-	const size_t n_afsk = b->chlist[SONDE_IMET4].size() + b->chlist[SONDE_C50].size();
 	const int iq = bins_in ? SD_IN_BINS : (b->input_kind == SONDE_INPUT_IQ ? SD_IN_IQ : SD_IN_REAL);      // what the rows hold
 	const int slot = (int)(b->tickets & 1);
 	SondeFrame *const d_frames = b->d_frames2[slot];
@@ -650,7 +651,13 @@ extern "C" size_t sonde_row_stride(size_t n_samples, int input_kind)
 	if (bytes < 64 * 1024) return n_samples;
 	size_t p = 64 * 1024;
 	while (p < bytes) p <<= 1;
-	return p / elem;
+	// the padding is never read but it is allocated (the library's own staging buffer, a host's resident blocks): a power of two
+	// only where it costs at most a third (1.5 MiB -> 2 MiB); rows just above a power of two would nearly double, and take an ODD
+	// number of 64 KiB units instead (consecutive rows then start on different HBM channel groups)
+	if (3 * p <= 4 * bytes) return p / elem;
+	size_t units = (bytes + 65535) / 65536;
+	units |= 1;
+	return units * 65536 / elem;
 }
 
 extern "C" int sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride)

@@ -51,14 +51,17 @@ __device__ __forceinline__ int wave_sum(int v)
 #define SD_WGT     512    // workgroup: waves 0-3 run the timing-loop rounds, waves 4-7 the discriminator
 // K4 (sync search) runs on round wave 3; on a discriminator wave it measured equal for RS41 and 40 % slower for DFM (profiles/r2_notes.md)
 
-// LDS: the discriminator samples of [tile_start - 64, tile_end) twice, so that every (d[x], d[x+1])
-// pair the FIR needs is one 8-byte-aligned ds_read_b64 with an immediate offset:
-//   A[x] = d[x],  B[x] = d[x+1]   (x = index relative to tile_start - 64)
-// and double-buffered over tiles: while the round waves read tile i from buffer i&1, the
-// discriminator waves fill buffer (i+1)&1 with tile i+1.  One barrier per tile.
+// LDS: A = the discriminator samples of [tile_start - 64, tile_end), double-buffered over tiles: while the round waves read tile i
+// from buffer i & 1, the discriminator waves fill buffer (i + 1) & 1 with tile i + 1.  One barrier per tile.  (Rounds 1-2 kept
+// a second copy of every tile shifted by one sample so that every FIR operand pair was one aligned 8-byte read; one copy and
+// two-dword reads measured faster, profiles/r3_notes.md.)
+// X = two more buffers of the same size that never hold a tile: X[1] keeps the GF(2^8) tables of the FEC epilogue for the whole
+// launch (from SD_EPI_TAB_OFF), X[0] and X[1] give the channelizer-input path its wave-private scratch, and A[0], A[1], X[0]
+// together are the eight per-wave work areas of the epilogue once the tiles are dead.  The workgroup's 39.7 KB are what four
+// workgroups per CU can have (160 KB): nothing to gain from a smaller struct, 8 waves per SIMD is the cap either way.
 struct DemodLds {
 	float A[2][SD_BUF];
-	float B[2][SD_BUF];
+	float X[2][SD_BUF];
 	float taps[SD_NPHASE * SD_TAPS_LD];     // rows padded to 36 floats: 16-byte aligned ds_read_b128
 	int4 red[2][4];                         // [round parity][wave]: (E, S1, S0, C1)
 	uint32_t chunk[2][18];                  // [round parity]: the round's bits, one ballot per wave (and half), zero-padded
@@ -79,10 +82,6 @@ struct DemodLds {
 __device__ __forceinline__ void store_pair(DemodLds &s, int b, uint32_t i, float d0, float d1)
 {
 	*reinterpret_cast<float2 *>(&s.A[b][SD_LH + i]) = make_float2(d0, d1);
-#ifdef SD_BCOPY
-	s.B[b][SD_LH + i - 1] = d0;
-	s.B[b][SD_LH + i] = d1;
-#endif
 }
 
 // v of the lane below, lane 0: `first` (DPP wave_shr:1, GFX9; lanes without a source keep the old value)
@@ -95,9 +94,6 @@ __device__ __forceinline__ float sd_wave_shr1(float v, float first)
 __device__ __forceinline__ void store_one(DemodLds &s, int b, uint32_t i, float d0)
 {
 	s.A[b][SD_LH + i] = d0;
-#ifdef SD_BCOPY
-	s.B[b][SD_LH + i - 1] = d0;
-#endif
 }
 
 // y(pos) = (sum_{j even} H[p][j] d[n+16-j]) + (sum_{j odd} H[p][j] d[n+16-j]), each an fmaf chain with j
@@ -105,30 +101,18 @@ __device__ __forceinline__ void store_one(DemodLds &s, int b, uint32_t i, float 
 // (T[2i] = H[2i+1], T[2i+1] = H[2i]) so that they line up with the (d[x], d[x+1]) pairs.
 // rel = pos relative to A[0], Q16.
 template <int NT>   // taps in use
-__device__ __forceinline__ float interp(const float *A, const float *B, const float *taps, uint32_t rel)
+__device__ __forceinline__ float interp(const float *A, const float *taps, uint32_t rel)
 {
 	const uint32_t top = (rel >> 16) + NT / 2;                          // buffer index of d for j = 0
 	const float *h = taps + ((rel >> 11) & (SD_NPHASE - 1)) * SD_TAPS_LD;
-	// pair i holds (d[top-1-2i], d[top-2i]); it is 8-byte aligned in A when top is odd, in B otherwise
-#ifndef SD_BCOPY
-	// pairs at any alignment, read as two dwords each (ds_read2_b32).  Rounds 1-2 kept a second copy B of every tile, shifted by
-	// one sample, so that a pair was one aligned 8-byte read in A or in B: two to three LDS stores per sample instead of one
-	// (mixed batch -2.5 %, 4096 x 96 tiles -1.7 %, headline unchanged without it: profiles/r3_notes.md)
+	// pair i holds (d[top-1-2i], d[top-2i]): pairs at any alignment, read as two dwords each (ds_read2_b32)
 	const float *lo = A + (top - (NT - 1));
-#else
-	const float *lo = (top & 1u) ? (A + (top - (NT - 1))) : (B + (top - NT));
-#endif
 	f32x2 acc = {0.0f, 0.0f};                                           // (odd chain, even chain)
 #pragma unroll
 	for (int q = 0; q < NT / 4; q++) {
 		const float4 hv = *reinterpret_cast<const float4 *>(h + 4 * q);
-#ifndef SD_BCOPY
 		const float2 v0 = make_float2(lo[(NT - 2) - 4 * q], lo[(NT - 1) - 4 * q]);
 		const float2 v1 = make_float2(lo[(NT - 4) - 4 * q], lo[(NT - 3) - 4 * q]);
-#else
-		const float2 v0 = *reinterpret_cast<const float2 *>(lo + (NT - 2) - 4 * q);
-		const float2 v1 = *reinterpret_cast<const float2 *>(lo + (NT - 4) - 4 * q);
-#endif
 		const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
 		const f32x2 d0 = {v0.x, v0.y}, d1 = {v1.x, v1.y};
 		acc = pk_fma(h0, d0, acc);
@@ -137,10 +121,10 @@ __device__ __forceinline__ float interp(const float *A, const float *B, const fl
 	return acc.y + acc.x;
 }
 
-// FEC epilogue (RS41 channels): the GF tables sit, for the whole launch, behind the part of B[1] that a decimated
+// FEC epilogue (RS41 channels): the GF tables sit, for the whole launch, in X[1] (placed as if behind the part of a buffer that a decimated
 // tile uses (decimation 4 or 2: <= 64 + 1024 + 4 floats of 2116), the per-wave work areas alias the tile buffers,
 // which are dead by then.
-#define SD_EPI_TAB_OFF 1100                 // floats into B[1]
+#define SD_EPI_TAB_OFF 1100                 // floats into X[1]
 struct EpiTabs { FramerTabs tabs; alignas(16) uint32_t swar[RS_R * 8]; };
 static_assert(SD_LH + SD_TILE / 2 + 4 <= SD_EPI_TAB_OFF, "the tables must stay clear of a 2:1 tile");
 static_assert(sizeof(EpiTabs) <= (SD_BUF - SD_EPI_TAB_OFF) * sizeof(float), "GF tables do not fit behind the tile");
@@ -156,8 +140,8 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 // discriminator and FIR variants do not share one register allocation.  Classes in use: (4, 8) RS41 / DFM / iMS-100 / MRZ-N1,
 // (2, 8) M10, (2, 16) and (1, 16) the same two groups under SONDE_FLAG_WIDE, (1, 16) also the 6 kS/s AFSK streams.
 // IN: what `in` holds per channel: SD_IN_REAL 48 kS/s discriminator samples, SD_IN_IQ 48 kS/s complex samples, SD_IN_BINS
-// 40 kS/s complex samples of a channelizer bin (the per-bin FM discriminator and the 6/5 resampler of SPEC 3.5 then run in
-// this kernel's load path: the 48 kS/s rows are never written to HBM).
+// 20 kS/s phase samples of a channelizer bin (the per-bin FM discriminator -- a wrapped phase difference -- and the composite
+// 12/5 resampler - decimator of SPEC 3.5b then run in this kernel's load path: the 48 kS/s rows are never written to HBM).
 template <int IN, bool LIST, int DEC, int NT>
 #ifndef SD_BINS_WAVES
 #define SD_BINS_WAVES 6      // waves per SIMD of the SD_IN_BINS instantiations (<= 80 VGPRs, three workgroups per CU): at 8 (64 VGPRs) the tile
@@ -172,10 +156,6 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 {
 	constexpr bool IS_IQ = IN == SD_IN_IQ, BINS = IN == SD_IN_BINS;
 	__shared__ __attribute__((aligned(16))) DemodLds s;
-#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: a workgroup's life: entry, first round, end of the tile loop
-	__shared__ unsigned long long s_life[3];
-	if (threadIdx.x == 0) s_life[0] = __builtin_amdgcn_s_memtime();
-#endif
 
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
@@ -203,16 +183,18 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			v[r] = make_float4(q.x, q.y, q.z, q.w);
 		}
 	};
-	// SD_IN_BINS: wave kw produces the outputs j in [J0, J0 + 512), J0 = 2048 tile + 512 kw (block-relative, SPEC 3.5:
-	// o[j] = sum_t g[5j mod 6][t] d[floor(5j/6) - t]); it needs d[ilo .. ilo + 442], ilo = floor(5 J0 / 6) - 15, i.e. the bin samples
-	// x[ilo - 1 ..]: 7 eight-byte loads per lane, element e = lane + 64 q <-> x[ilo - 1 + e]
-	constexpr int NB2 = 7;
-	float2 wa[NB2], wb[NB2];
-	const int bins_n = BINS ? (n_tiles / 3) * 5120 : 0;                       // samples per bin in this submit (3 tiles = 6144 outputs = 5120 inputs)
-	auto bins_ilo = [&](int tile) { return (int)((5u * (2048u * (uint32_t)tile + 512u * (uint32_t)kw)) / 6u) - 15; };
-	auto load_bins = [&](int tile, float2 (&w)[NB2]) {
-		const float2 *x = reinterpret_cast<const float2 *>(in) + (size_t)row * ch_stride;
-		const int base = bins_ilo(tile) - 1 + lane;
+	// SD_IN_BINS (SPEC 3.5 / 3.5b, round 4): the rows hold one PHASE sample (quadrants) per 20 kS/s step of a channelizer bin.  Wave kw
+	// produces the decimated samples n in [N0, N0 + 128), N0 = 512 tile + 128 kw, in groups u = a_grp + lane of three (the three
+	// that the five discriminator samples d[5u .. 5u + 4] complete), a_grp = floor((2048 tile + 512 kw) / 12); it needs
+	// d[5 a_grp - 15 .. 5 a_grp + 224], i.e. the phases from index 5 a_grp - 16 on: 4 four-byte loads per lane, element
+	// e = lane + 64 q <-> phi[5 a_grp - 16 + e] (block-relative)
+	constexpr int NB2 = 4;
+	float wa[NB2];
+	const int bins_n = BINS ? (n_tiles / 3) * 2560 : 0;                       // phase samples per bin in this submit (3 tiles = 6144 outputs = 2560 inputs)
+	auto bins_grp = [&](int tile) { return (2048u * (uint32_t)tile + 512u * (uint32_t)kw) / 12u; };
+	auto load_bins = [&](int tile, float (&w)[NB2]) {
+		const float *x = in + (size_t)row * ch_stride;
+		const int base = 5 * (int)bins_grp(tile) - 16 + lane;
 #pragma unroll
 		for (int q = 0; q < NB2; q++) {
 			int i = base + 64 * q;
@@ -223,9 +205,6 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	if (is_k) {
 		if (BINS) {
 			load_bins(0, wa);
-#ifdef BINS_AB_TWOSETS
-			if (n_tiles > 1) load_bins(1, wb);
-#endif
 		} else {
 			load_vec(0, va);
 			if (n_tiles > 1) load_vec(1, vb);
@@ -253,9 +232,6 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		if (tid < SD_LH) {
 			const float hv = hist[(size_t)ch * SD_HIST + tid];
 			s.A[0][tid] = hv;
-#ifdef SD_BCOPY
-			if (tid) s.B[0][tid - 1] = hv;
-#endif
 		}
 		if (tid == 0) {
 			s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
@@ -276,11 +252,7 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	           is_ims = cls_slow && stype == SONDE_IMS100, is_m10 = !cls_slow && stype == SONDE_M10,
 	           is_mrz = cls_slow && stype == SONDE_MRZN1;
 	const bool fuse = fo->fuse_fec != 0;
-#if defined(SD_NO_FRAMING) && !defined(SD_KEEP_K4)      // A/B builds (profiles/r2_notes.md): the demodulator alone / with K4 but no FEC epilogue
-	const bool framing = false;
-#else
 	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10 || is_mrz));   // workgroup-uniform
-#endif
 	if (framing && !is_k && tid >= SD_WG - SD_MIRROR_WORDS) {                               // round wave 3, the wave that runs K4
 		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WG - 1 - tid);       // the words up to and including wpos's
 		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
@@ -289,23 +261,15 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	// K5/K6 in this kernel's epilogue: RS41 only (few, heavy frames per submit).  The short frames of the fixed-length
 	// framers (a DFM frame every 2.7 tiles) decode faster as one wave per frame across the whole GPU (framer2_kernel.hip)
 	// than eight at a time at the end of each workgroup: measured 0.358 vs 0.324 ms per step for 4096 DFM channels.
-#ifdef SD_NO_FRAMING
-	const bool fec_here = false;
-#else
 	const bool fec_here = is_rs41 && fuse;     // workgroup-uniform
-#endif
-	EpiTabs &et = *reinterpret_cast<EpiTabs *>(&s.B[1][SD_EPI_TAB_OFF]);
+	EpiTabs &et = *reinterpret_cast<EpiTabs *>(&s.X[1][SD_EPI_TAB_OFF]);
 	// Round 3: clean frames can be decoded INSIDE the tile loop, by round wave 2, a step per round (sd_rs41_loop_step); its
 	// work area sits in the part of A[1] no decimated tile uses (the bins path keeps its scratch there).
 	// Only where it pays (interleaved A/B, tools/ab_repeat.sh, profiles/r3_notes.md): launches whose workgroups are ALL resident at
 	// once -- their epilogues coincide, nothing else streams meanwhile: 1024 x 96 tiles -1.6 % at 14 dB, -1.1 % at 9 dB -- and long
 	// enough (>= 48 tiles; at 24 the steps of the 1.6 frames a submit completes stall as much as they save).  In launches of several
 	// generations the epilogues overlap other workgroups' streaming for free and the steps only stall: 4096 x 96 tiles +7 %.
-#ifndef SD_NO_LOOP_FEC
 	const bool fec_loop = fec_here && !BINS && n_tiles >= 48 && gridDim.x <= fo->loop_fec_max_wg;
-#else
-	constexpr bool fec_loop = false;
-#endif
 	FramerLds &loop_wl = *reinterpret_cast<FramerLds *>(&s.A[1][1100]);
 	static_assert(sizeof(FramerLds) <= (SD_BUF - 1100) * sizeof(float), "in-loop FEC work area");
 	if (tid == 3 * 64 - 1) { s.fec.frame = 0; s.fec.phase = 0; s.fec.done_mask = 0; }      // (wave 2: the wave that uses it)
@@ -410,88 +374,79 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		if (IS_IQ) last_iq = make_float2(cx, cy);      // wave 7: the last (decimated) sample of the tile
 	};
 
-	// SD_IN_BINS: discriminator at 40 kS/s into a wave-private LDS scratch, then the composite resampler + decimator (SPEC 3.5b)
-	// straight into buffer b.  Scratch: the part of a tile buffer a decimated tile never uses (DEC 4: from 584, DEC 2: from 1096),
-	// one buffer per wave, 476 floats read (written: 457).  Wave 3 of a 4:1 instantiation shares B[1] with the FEC tables (at 1100):
-	// its scratch sits at B[1][600..1076).
-	float *const bscr = !BINS ? nullptr : (kw == 0 ? &s.A[0][1100] : kw == 1 ? &s.A[1][1100] : kw == 2 ? &s.B[0][1100] : &s.B[1][DEC == 4 ? 600 : 1100]);
-	static_assert(!BINS || DEC == 4 || DEC == 2, "the bins path needs the free part of a decimated tile buffer");
-	static_assert(SD_LH + SD_TILE / 2 + 4 <= 1100 && 1100 + 10 * 45 + 26 <= SD_BUF && 600 + 10 * 45 + 26 <= SD_EPI_TAB_OFF && 9 + 64 * NB2 <= 10 * 45 + 26 &&
-	              SD_LH + SD_TILE / 4 + 4 <= 600, "scratch regions");
-	float2 bins_last = make_float2(0.0f, 0.0f);
+	// SD_IN_BINS: discriminator (wrapped difference of consecutive phases) into a wave-private LDS scratch, then the composite
+	// resampler + decimator (SPEC 3.5b) straight into buffer b.  Scratch: the part of a tile buffer a 4:1 tile never uses (from 584),
+	// one buffer per wave, 256 floats.  Wave 3 shares X[1] with the FEC tables (at 1100): its scratch sits at X[1][600..856).
+	float *const bscr = !BINS ? nullptr : (kw == 0 ? &s.A[0][1100] : kw == 1 ? &s.A[1][1100] : kw == 2 ? &s.X[0][1100] : &s.X[1][600]);
+	static_assert(!BINS || DEC == 4, "the bins path serves the 12 kS/s sondes (4:1 class): a 19.5 kHz bin cannot carry an M10 channel");
+	static_assert(SD_LH + SD_TILE / 4 + 4 <= 600 && 600 + 64 * NB2 <= SD_EPI_TAB_OFF && 1100 + 64 * NB2 <= SD_BUF && 5 * 44 + 20 <= 64 * NB2, "scratch regions");
+	float bins_last = 0.0f;
 	if (BINS && is_k) {
-		// the composite taps of this decimation (3 rows of 20): every discriminator wave writes the same 60 values (identical
-		// stores may race), then reads them behind its own stores; the first wave of the block also needs the carried history
-		if (lane < 3 * SD_RS_KT_LD) s.rs_g[lane] = bins_in->g[(DEC == 4 ? 3 * SD_RS_KT_LD : 0) + lane];
+		// the composite taps (3 rows of 20): every discriminator wave writes the same 60 values (identical stores may race), then
+		// reads them behind its own stores; the first wave of the block also needs the carried history
+		if (lane < 3 * SD_RS_KT_LD) s.rs_g[lane] = bins_in->g[lane];
 		if (kw == 0) {
 			if (lane < 16) s.rs_dh[lane] = bins_in->dhist[(size_t)ch * 16 + lane];
-			bins_last = reinterpret_cast<const float2 *>(bins_in->iq_last)[ch];
+			bins_last = bins_in->phi_last[ch];
 		}
 	}
-	auto k1_bins = [&](int b, int tile, float2 (&w)[NB2]) {
-		const bool first = tile == 0 && kw == 0;                 // wave-uniform: the block's first wave (ilo = -15)
-		// the scratch holds d[10 a_grp - 16 ..]: load element e is d[ilo - 1 + e], ilo - 1 = 10 a_grp - 16 + shift, shift = floor(5 r / 6) <= 9
-		const uint32_t J0 = 2048u * (uint32_t)tile + 512u * (uint32_t)kw;
-		const uint32_t a_grp = J0 / 12u;
-		const int shift = (int)((5u * (J0 - 12u * a_grp)) / 6u);
-		float cx = 0.0f, cy = 0.0f;
+	auto k1_bins = [&](int b, int tile, float (&w)[NB2]) {
+		const bool first = tile == 0 && kw == 0;                 // wave-uniform: the block's first wave (elements 0..15 lie before the block)
+		const uint32_t a_grp = bins_grp(tile);
+		float cx = 0.0f;
 #pragma unroll
 		for (int q = 0; q < NB2; q++) {
-			// lane l takes lane l - 1's sample, lane 0 the carry: one DPP move each (wave_shr:1; __shfl_up is a ds_bpermute)
-			float px = sd_wave_shr1(w[q].x, cx), py = sd_wave_shr1(w[q].y, cy);
-			if (q == 0 && first && lane == 16) { px = bins_last.x; py = bins_last.y; }      // element 16 is x[0]: its predecessor is carried
-			float d = sd_disc(w[q].x, w[q].y, px, py);
+			// lane l takes lane l - 1's phase, lane 0 the carry: one DPP move (wave_shr:1)
+			float pv = sd_wave_shr1(w[q], cx);
+			if (q == 0 && first && lane == 16) pv = bins_last;                              // element 16 is phi[0]: its predecessor is carried
+			float d = sd_phase_diff(w[q], pv);
 			if (q == 0 && first && lane < 16) d = s.rs_dh[lane];                             // elements 1..15 are d[-15..-1]: carried
-			bscr[shift + lane + 64 * q] = d;
-			cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[q].x), 63));
-			cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[q].y), 63));
+			// element e = lane + 64 q is d[5 a_grp - 16 + e]; the scratch starts at d[5 a_grp - 15]: element 0 only carries a phase
+			if (q > 0 || lane > 0) bscr[lane + 64 * q - 1] = d;
+			cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[q]), 63));
 		}
-#ifndef BINS_AB_TWOSETS
-		// the bin samples are consumed: the next tile's go out into the same registers now (ONE register set: with two, tiles
-		// requested two phases ahead as in the HBM-bound instantiations, the 80-VGPR allocation spilled inside this loop)
+		const float w_last = w[NB2 - 1];
+		// the phases are consumed: the next tile's go out into the same registers now (ONE register set)
 		if (tile + 1 < n_tiles) load_bins(tile + 1, w);
-#endif
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// SPEC 3.5b: resampler and boxcar decimator as ONE polyphase filter, z[n] = sum_k fmaf(G[n mod 3][k], d[b(n) - k], acc),
-		// k < KT ascending, b(n) = floor(5 (DEC n + DEC - 1) / 6).  Lane <-> group u: the NC decimated samples n = NC u + c that
-		// the ten discriminator samples d[10 u .. 10 u + 9] complete (12 resampler outputs: 3 samples at 4:1, 6 at 2:1); it
-		// reads d[10 u - 16 .. 10 u + 9] from LDS once (13 eight-byte reads, lanes 40 bytes apart) and indexes them
-		// statically; the tap row of sample c is the same for every lane: broadcast reads.  19 (17) multiply-adds per
-		// decimated sample where "resample, then average" took 64 (32) plus a staging row: profiles/r3_notes.md.
-		constexpr int PER_WAVE = SD_TILE / DEC / 4;              // decimated samples a wave produces per tile: 128 (4:1) or 256 (2:1)
-		constexpr int NC = 12 / DEC, KT = DEC == 4 ? 19 : 17;
-		const uint32_t N0 = J0 / (uint32_t)DEC;
+		// k < 17 ascending, b(n) = floor(5 (4 n + 3) / 12).  Lane <-> group u: the 3 decimated samples n = 3 u + c that the five
+		// discriminator samples d[5 u .. 5 u + 4] complete (12 resampler outputs); it reads d[5 u - 15 .. 5 u + 4] from LDS once (20
+		// dwords, lanes 20 bytes apart: conflict-free) and indexes them statically; the tap row of sample c is the same for every lane:
+		// broadcast reads.  17 multiply-adds per decimated sample where "resample, then average" took 64.
+		constexpr int PER_WAVE = SD_TILE / DEC / 4;              // decimated samples a wave produces per tile: 128
+		const uint32_t N0 = (2048u * (uint32_t)tile + 512u * (uint32_t)kw) / (uint32_t)DEC;
 		{
 			const int ul = lane < 45 ? lane : 45;                                // 43-44 groups carry outputs of this wave
-			const float2 *dp = reinterpret_cast<const float2 *>(bscr + 10 * ul);
-			float dv[26];
+			const float *dp = bscr + 5 * ul;
+			float dv[20];
 #pragma unroll
-			for (int k = 0; k < 13; k++) { const float2 t2 = dp[k]; dv[2 * k] = t2.x; dv[2 * k + 1] = t2.y; }
+			for (int k = 0; k < 20; k++) dv[k] = dp[k];
 #pragma unroll
-			for (int c = 0; c < NC; c++) {
-				constexpr int BO4[3] = {2, 5, 9}, BO2[6] = {0, 2, 4, 5, 7, 9};
-				const int bo = (DEC == 4 ? BO4[c % 3] : BO2[c]) + 16;          // dv index of d[b(n)]
+			for (int c = 0; c < 3; c++) {
+				constexpr int BO[3] = {1, 2, 4};
+				const int bo = BO[c] + 15;                                         // dv index of d[b(n)]
 				float gt[20];
 #pragma unroll
 				for (int q = 0; q < 5; q++) {
-					const float4 g4 = *reinterpret_cast<const float4 *>(&s.rs_g[SD_RS_KT_LD * (c % 3) + 4 * q]);
+					const float4 g4 = *reinterpret_cast<const float4 *>(&s.rs_g[SD_RS_KT_LD * c + 4 * q]);
 					gt[4 * q] = g4.x; gt[4 * q + 1] = g4.y; gt[4 * q + 2] = g4.z; gt[4 * q + 3] = g4.w;
 				}
 				float acc = 0.0f;
 #pragma unroll
-				for (int t = 0; t < KT; t++) acc = __builtin_fmaf(gt[t], dv[bo - t], acc);
-				const uint32_t jr = (uint32_t)NC * (a_grp + (uint32_t)ul) + (uint32_t)c - N0;      // index inside the wave's span (wraps below N0)
+				for (int t = 0; t < SD_RS_KT; t++) acc = __builtin_fmaf(gt[t], dv[bo - t], acc);
+				const uint32_t jr = 3u * (a_grp + (uint32_t)ul) + (uint32_t)c - N0;      // index inside the wave's span (wraps below N0)
 				if (jr < (uint32_t)PER_WAVE && lane < 45) store_one(s, b, (uint32_t)PER_WAVE * (uint32_t)kw + jr, acc);
 			}
 		}
 		if (tile == n_tiles - 1 && kw == 3) {
-			// the block's last wave: carry the last 16 discriminator samples and the last bin sample to the next submit
-			// (read by the first wave at the top of the next launch; every barrier of this launch lies in between)
-			// for this wave J0 = n_out - 512, so ilo = bins_n - 442: x[bins_n - 1] is element 442 (lane 58 of load 6), d[bins_n - 16] element 427
-			constexpr int E_LAST = 442;
-			if (lane < 16) bins_in->dhist[(size_t)ch * 16 + lane] = bscr[shift + E_LAST - 15 + lane];
-			if (lane == (E_LAST & 63)) reinterpret_cast<float2 *>(bins_in->iq_last)[ch] = w[E_LAST >> 6];
+			// the block's last wave: carry the last 16 discriminator samples and the last phase to the next submit (read by the first
+			// wave at the top of the next launch).  For this wave 5 a_grp - 16 = bins_n - 231: phi[bins_n - 1] is element 230
+			// (lane 38 of load 3), d[bins_n - 16 ..] the scratch entries 214..229
+			constexpr int E_LAST = 230;
+			if (lane < 16) bins_in->dhist[(size_t)ch * 16 + lane] = bscr[E_LAST - 16 + lane];
+			if (lane == (E_LAST & 63)) bins_in->phi_last[ch] = w_last;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_wave_barrier();                         // the next k1 of this wave rewrites the scratch
@@ -519,10 +474,10 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			if (act) {
 				const int64_t base = (n0 - IT - SD_LH) << 16;
 				const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)k * (uint32_t)period;
-				y = interp<NT>(s.A[b], s.B[b], s.taps, rel);          // 3.2 symbols of taps (8 at 2.5 samples per symbol)
+				y = interp<NT>(s.A[b], s.taps, rel);          // 3.2 symbols of taps (8 at 2.5 samples per symbol)
 				// only the first 256 symbols of a round feed the timing detector (SPEC 3.2): the second symbol of a lane needs no
 				// mid-symbol FIR -- a quarter of the FIR work of the two-symbols-per-lane classes (M10: 117.7 M -> 108.5 M VALU instructions, 297 -> 277 us)
-				if (h == 0) m = interp<NT>(s.A[b], s.B[b], s.taps, rel - ((uint32_t)period >> 1));
+				if (h == 0) m = interp<NT>(s.A[b], s.taps, rel - ((uint32_t)period >> 1));
 			}
 			if (h == 0) {
 				const float yprev = sd_wave_shr1(y, 0.0f);            // (lane 0's term is not used)
@@ -648,17 +603,10 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	};
 	if (is_k) {
 		// register set A holds the even tiles, set B the odd ones (the arguments are literals at every call: static register sets)
-#ifdef BINS_AB_TWOSETS
-		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, tile, va, pa, qa); };
-		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wb); else k1_tile(b, tile, vb, pb, qb); };
-		auto ldA = [&](int tile) { if constexpr (BINS) load_bins(tile, wa); else load_tile(tile, va, pa, qa); };
-		auto ldB = [&](int tile) { if constexpr (BINS) load_bins(tile, wb); else load_tile(tile, vb, pb, qb); };
-#else
 		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, tile, va, pa, qa); };
 		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, tile, vb, pb, qb); };
 		auto ldA = [&](int tile) { if constexpr (!BINS) load_tile(tile, va, pa, qa); };
 		auto ldB = [&](int tile) { if constexpr (!BINS) load_tile(tile, vb, pb, qb); };
-#endif
 		if (!BINS) {
 			load_prev(0, pa, qa);          // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
 			if (n_tiles > 1) load_prev(1, pb, qb);
@@ -671,9 +619,6 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		for (int tile = 0; tile < n_tiles; tile += 2) {
 			if (tile + 1 < n_tiles) {
 				if (t < SD_LH) s.A[1][t] = s.A[0][IT + t];            // history roll into the other buffer
-#ifdef SD_BCOPY
-				else if (t < 2 * SD_LH - 1) s.B[1][t - SD_LH] = s.B[0][IT + t - SD_LH];
-#endif
 				k1B(1, tile + 1);
 				if (tile + 3 < n_tiles) ldB(tile + 3);
 			}
@@ -681,9 +626,6 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			if (tile + 1 >= n_tiles) break;
 			if (tile + 2 < n_tiles) {
 				if (t < SD_LH) s.A[0][t] = s.A[1][IT + t];
-#ifdef SD_BCOPY
-				else if (t < 2 * SD_LH - 1) s.B[0][t - SD_LH] = s.B[1][IT + t - SD_LH];
-#endif
 				k1A(0, tile + 2);
 				if (tile + 4 < n_tiles) ldA(tile + 4);
 			}
@@ -701,9 +643,6 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 		const bool k4 = framing && rwave == 3;
 		if (k4 && lane == 0) k4_load();
 		__syncthreads();
-#ifdef SD_EPI_TIMESTAMPS
-		if (threadIdx.x == 0) s_life[1] = __builtin_amdgcn_s_memtime();
-#endif
 		int K_total = 0;
 		for (int tile = 0; tile < n_tiles; tile++) {
 			const int b = tile & 1;
@@ -734,10 +673,8 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 					if (k4) k4_run(sd_uniform64(s.k4.wp_seen));
 					// the in-loop decoder of clean RS41 frames: one step per round on round wave 2, which would otherwise only wait
 					// for the lead wave's loop filter (a real call: sd_rsdec.h says why)
-#ifndef SD_NO_LOOP_FEC
 					if (fec_loop && rwave == 2) sd_rs41_loop_step(s.fec, s.k4, et.tabs, et.swar, loop_wl, ring_g, ring_mask,
 					                                              fo->frames + (size_t)ch * fo->max_frames, ch, fo->max_frames, lane);
-#endif
 					while (__hip_atomic_load(&s.pub.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1u)
 						__builtin_amdgcn_s_sleep(2);
 					t_next = s.pub.t_next; period = s.pub.period; bias = s.pub.bias; K = s.pub.K;
@@ -755,9 +692,6 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 			if (IS_IQ) afc_step(n_tiles - 1);
 		}
 		if (lead && lane == 0) s.pub.wpos = st.wpos;
-#ifdef SD_EPI_TIMESTAMPS
-		if (threadIdx.x == 0) s_life[2] = __builtin_amdgcn_s_memtime();
-#endif
 		__syncthreads();                                   // (E) matched by the discriminator role's last barrier
 		if (k4) k4_finish();      // ... and K4's catch-up over the last rounds' bits
 	}
@@ -802,13 +736,6 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 				d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);
 				d.inv = __builtin_amdgcn_readfirstlane((int)(d1 >> 32));
 				sd_rs41_decode_frame<true>(et.tabs, wl, swar, ring_g, ring_mask, d, fout + k, ch, lane);
-#ifdef SD_EPI_TIMESTAMPS
-				if (lane == 0) {       // words 128..131 (the corrector's stage times, sd_rsdec.h) give way to the workgroup's life
-					uint32_t *dbg = reinterpret_cast<uint32_t *>((fout + k)->data) + 128;
-					const unsigned long long now = __builtin_amdgcn_s_memtime();
-					dbg[0] = (uint32_t)(s_life[1] - s_life[0]); dbg[1] = (uint32_t)(s_life[2] - s_life[1]); dbg[2] = (uint32_t)(now - s_life[2]); dbg[3] = n_tiles;
-				}
-#endif
 			}
 		}
 	}
@@ -828,11 +755,9 @@ void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStr
 		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 2, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 1, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); } while (0)
 	if (in_kind == SD_IN_BINS) {
-		// channelizer bins: real-input classes only (the wide flag does not apply behind the discriminator): (4, 8) and (2, 8)
-		if (decim == 4 && !chlist) hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, false, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
-		else if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, true, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
-		else if (!chlist) hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, false, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
-		else hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, true, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
+		// channelizer bins (20 kS/s phases): the 12 kS/s sondes only, class (4, 8) (the host checks: sd_batch_bins_capable)
+		// (one class, no AFSK: always the plain launch over all bins)
+		hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, false, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
 	}
 	else if (in_kind == SD_IN_IQ && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ, false);
 	else if (in_kind == SD_IN_IQ) SD_DEMOD_LAUNCH(SD_IN_IQ, true);

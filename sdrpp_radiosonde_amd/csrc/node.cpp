@@ -1,0 +1,266 @@
+// node.cpp -- libsonde_rccl.so: the node-level host of include/sonde_node.h: ONE process, the GPUs of one node, one decoder
+// batch per GPU (north_star: "C++ host code ... sharded across the 8 GPUs of one node with an RCCL scatter of IQ blocks over
+// xGMI"; the reference's unit is one module instance per channel, any number of them, /root/reference/src/main.cpp:18-24).
+//
+// Channels shard in contiguous ranges (sonde_shard_range).  The only exchange is ingest: the IQ of all channels arrives on one
+// device and every other device receives its shard over xGMI STRAIGHT INTO THE ROWS ITS DECODER READS (rows on the recommended
+// channel stride, sonde_row_stride: no re-stride copy behind the collective) as one group of ncclSend (ingest device) /
+// ncclRecv (peers) per 256 rows of every peer -- RCCL has no scatter primitive, and point-to-point transfers let the ingest
+// device drive all its xGMI links at once.  The ingest device's own shard is a strided device copy, not a send to itself.
+// Frames come back per device straight to host memory (one process: nothing travels back over xGMI).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "../../include/sonde_node.h"
+#include "../../include/sonde_shard.h"
+
+static thread_local std::string g_nerr;
+static int nfail(const char *what, const char *detail = nullptr)
+{
+	g_nerr = what;
+	if (detail && *detail) { g_nerr += ": "; g_nerr += detail; }
+	return -1;
+}
+#define NCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return nfail(#x, ncclGetErrorString(r_)); } while (0)
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return nfail(#x, hipGetErrorString(e_)); } while (0)
+#define BCHK(x) do { if ((x) < 0) return nfail(#x, sonde_last_error()); } while (0)
+
+extern "C" const char *sonde_node_last_error(void) { return g_nerr.c_str(); }
+
+struct SondeNode {
+	uint32_t nd = 0, ingest = 0, n_channels = 0, max_samples = 0;
+	int kind = SONDE_INPUT_IQ;
+	size_t elem = 8;
+	std::vector<int> dev;
+	std::vector<uint32_t> first, count;
+	std::vector<SondeBatch *> batch;
+	std::vector<ncclComm_t> comm;
+	std::vector<hipStream_t> st;
+	std::vector<void *> rows;              // per device: its shard's rows, max stride apart
+	size_t rows_stride_max = 0;            // elements between rows at max_samples
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool have_scatter = false;
+	uint64_t last_bytes = 0;
+	uint32_t last_sends = 0;
+	std::vector<SondeFrame> tmp;
+};
+
+extern "C" void sonde_node_destroy(SondeNode *n)
+{
+	if (!n) return;
+	for (uint32_t d = 0; d < n->nd; d++) {
+		(void)hipSetDevice(n->dev[d]);
+		if (d < n->batch.size() && n->batch[d]) sonde_batch_destroy(n->batch[d]);
+		if (d < n->st.size() && n->st[d]) { (void)hipStreamSynchronize(n->st[d]); (void)hipStreamDestroy(n->st[d]); }
+		if (d < n->rows.size() && n->rows[d]) (void)hipFree(n->rows[d]);
+		if (d < n->comm.size() && n->comm[d]) (void)ncclCommDestroy(n->comm[d]);
+	}
+	if (n->nd) (void)hipSetDevice(n->dev[n->ingest]);
+	if (n->ev0) (void)hipEventDestroy(n->ev0);
+	if (n->ev1) (void)hipEventDestroy(n->ev1);
+	delete n;
+}
+
+extern "C" int sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out)
+{
+	if (!cfg || !out) return nfail("sonde_node_create: null argument");
+	*out = nullptr;
+	if (cfg->n_devices < 1 || cfg->n_devices > 16 || cfg->ingest >= cfg->n_devices) return nfail("sonde_node_create: n_devices must be 1..16 and ingest one of them");
+	if (cfg->n_channels < cfg->n_devices) return nfail("sonde_node_create: fewer channels than devices");
+	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL) return nfail("sonde_node_create: bad input_kind");
+	int ndev = 0;
+	HCHK(hipGetDeviceCount(&ndev));
+	SondeNode *n = new SondeNode;
+	n->nd = cfg->n_devices; n->ingest = cfg->ingest; n->n_channels = cfg->n_channels; n->max_samples = cfg->max_samples;
+	n->kind = cfg->input_kind;
+	n->elem = cfg->input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : sizeof(float);
+	n->dev.resize(n->nd); n->first.resize(n->nd); n->count.resize(n->nd);
+	n->batch.assign(n->nd, nullptr); n->st.assign(n->nd, nullptr); n->rows.assign(n->nd, nullptr); n->comm.assign(n->nd, nullptr);
+	for (uint32_t d = 0; d < n->nd; d++) {
+		n->dev[d] = cfg->devices ? cfg->devices[d] : (int)d;
+		if (n->dev[d] < 0 || n->dev[d] >= ndev) { delete n; return nfail("sonde_node_create: no such HIP device"); }
+		for (uint32_t e = 0; e < d; e++) if (n->dev[e] == n->dev[d]) { delete n; return nfail("sonde_node_create: a device is listed twice"); }
+		sonde_shard_range(cfg->n_channels, (int)n->nd, (int)d, &n->first[d], &n->count[d]);
+	}
+	n->rows_stride_max = sonde_row_stride(cfg->max_samples, cfg->input_kind);
+	for (uint32_t d = 0; d < n->nd; d++) {
+		hipError_t e = hipSetDevice(n->dev[d]);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&n->st[d], hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipMalloc(&n->rows[d], (size_t)n->count[d] * n->rows_stride_max * n->elem);
+		if (e != hipSuccess) { sonde_node_destroy(n); return nfail("sonde_node_create: stream / rows", hipGetErrorString(e)); }
+		SondeBatchConfig bc;
+		memset(&bc, 0, sizeof(bc));
+		bc.n_channels = n->count[d];
+		bc.types = cfg->types ? cfg->types + n->first[d] : nullptr;
+		bc.max_samples = cfg->max_samples;
+		bc.input_kind = cfg->input_kind;
+		bc.device = n->dev[d];
+		bc.flags = cfg->flags;
+		if (sonde_batch_create(&bc, &n->batch[d]) != 0) { sonde_node_destroy(n); return nfail("sonde_batch_create", sonde_last_error()); }
+	}
+	if (n->nd > 1) {
+		ncclResult_t r = ncclCommInitAll(n->comm.data(), (int)n->nd, n->dev.data());
+		if (r != ncclSuccess) { for (auto &c : n->comm) c = nullptr; sonde_node_destroy(n); return nfail("ncclCommInitAll", ncclGetErrorString(r)); }
+	}
+	hipError_t e = hipSetDevice(n->dev[n->ingest]);
+	if (e == hipSuccess) e = hipEventCreate(&n->ev0);
+	if (e == hipSuccess) e = hipEventCreate(&n->ev1);
+	if (e != hipSuccess) { sonde_node_destroy(n); return nfail("sonde_node_create: events", hipGetErrorString(e)); }
+	*out = n;
+	return 0;
+}
+
+extern "C" uint32_t sonde_node_devices(const SondeNode *n) { return n ? n->nd : 0; }
+extern "C" int sonde_node_range(const SondeNode *n, uint32_t d, uint32_t *first, uint32_t *count)
+{
+	if (!n || d >= n->nd) return nfail("sonde_node_range: bad argument");
+	if (first) *first = n->first[d];
+	if (count) *count = n->count[d];
+	return 0;
+}
+extern "C" SondeBatch *sonde_node_batch(SondeNode *n, uint32_t d) { return (n && d < n->nd) ? n->batch[d] : nullptr; }
+
+static int check_submit(const SondeNode *n, size_t n_samples, size_t channel_stride)
+{
+	if (n_samples == 0 || n_samples % SONDE_TILE || n_samples > n->max_samples) return nfail("sonde_node_submit: n_samples must be a multiple of SONDE_TILE and <= max_samples");
+	if (channel_stride < n_samples) return nfail("sonde_node_submit: channel_stride < n_samples");
+	return 0;
+}
+
+extern "C" int sonde_node_submit(SondeNode *n, const void *samples, size_t n_samples, size_t channel_stride)
+{
+	if (!n || !samples) return nfail("sonde_node_submit: null argument");
+	if (check_submit(n, n_samples, channel_stride)) return -1;
+	const size_t rs = sonde_row_stride(n_samples, n->kind);           // destination stride (elements)
+	const size_t row_bytes = n_samples * n->elem;
+	const char *src = (const char *)samples;
+	const uint32_t gi = n->ingest;
+	hipStream_t si = n->st[gi];
+	HCHK(hipSetDevice(n->dev[gi]));
+	HCHK(hipEventRecord(n->ev0, si));
+	n->last_bytes = 0; n->last_sends = 0;
+	if (n->nd > 1) {
+		const bool same_layout = channel_stride == rs;                  // a peer's shard is one contiguous run, padding included
+		uint32_t done_rows = 0, max_rows = 0;
+		for (uint32_t d = 0; d < n->nd; d++) if (d != gi) max_rows = std::max(max_rows, n->count[d]);
+		const uint32_t per_group = same_layout ? max_rows : 256u;      // rows of every peer per ncclGroup
+		while (done_rows < max_rows) {
+			NCHK(ncclGroupStart());
+			for (uint32_t d = 0; d < n->nd; d++) {
+				if (d == gi || done_rows >= n->count[d]) continue;
+				const uint32_t hi = std::min(n->count[d], done_rows + per_group);
+				if (same_layout) {
+					const size_t bytes = ((size_t)(n->count[d] - 1) * rs + n_samples) * n->elem;
+					ncclResult_t r = ncclSend(src + (size_t)n->first[d] * channel_stride * n->elem, bytes, ncclChar, (int)d, n->comm[gi], si);
+					if (r == ncclSuccess) r = ncclRecv(n->rows[d], bytes, ncclChar, (int)gi, n->comm[d], n->st[d]);
+					if (r != ncclSuccess) { (void)ncclGroupEnd(); return nfail("ncclSend/ncclRecv", ncclGetErrorString(r)); }
+					n->last_bytes += bytes; n->last_sends++;
+				} else {
+					for (uint32_t row = done_rows; row < hi; row++) {
+						ncclResult_t r = ncclSend(src + ((size_t)n->first[d] + row) * channel_stride * n->elem, row_bytes, ncclChar, (int)d, n->comm[gi], si);
+						if (r == ncclSuccess) r = ncclRecv((char *)n->rows[d] + (size_t)row * rs * n->elem, row_bytes, ncclChar, (int)gi, n->comm[d], n->st[d]);
+						if (r != ncclSuccess) { (void)ncclGroupEnd(); return nfail("ncclSend/ncclRecv", ncclGetErrorString(r)); }
+						n->last_bytes += row_bytes; n->last_sends++;
+					}
+				}
+			}
+			NCHK(ncclGroupEnd());
+			done_rows += per_group;
+		}
+		HCHK(hipSetDevice(n->dev[gi]));
+	}
+	// the ingest device's own shard: a strided device copy on its stream (not a send to itself)
+	HCHK(hipMemcpy2DAsync(n->rows[gi], rs * n->elem, src + (size_t)n->first[gi] * channel_stride * n->elem, channel_stride * n->elem,
+	                      row_bytes, n->count[gi], hipMemcpyDeviceToDevice, si));
+	HCHK(hipEventRecord(n->ev1, si));
+	n->have_scatter = true;
+	for (uint32_t d = 0; d < n->nd; d++) {
+		HCHK(hipSetDevice(n->dev[d]));
+		BCHK(sonde_batch_submit(n->batch[d], n->rows[d], n_samples, rs, (void *)n->st[d]));
+	}
+	return 0;
+}
+
+extern "C" int sonde_node_submit_local(SondeNode *n, const void *const *rows, size_t n_samples, size_t channel_stride)
+{
+	if (!n || !rows) return nfail("sonde_node_submit_local: null argument");
+	if (check_submit(n, n_samples, channel_stride)) return -1;
+	n->have_scatter = false;
+	n->last_bytes = 0; n->last_sends = 0;
+	for (uint32_t d = 0; d < n->nd; d++) {
+		if (!rows[d]) return nfail("sonde_node_submit_local: null rows pointer");
+		HCHK(hipSetDevice(n->dev[d]));
+		BCHK(sonde_batch_submit(n->batch[d], rows[d], n_samples, channel_stride, (void *)n->st[d]));
+	}
+	return 0;
+}
+
+extern "C" int sonde_node_scatter_done(SondeNode *n)
+{
+	if (!n) return nfail("sonde_node_scatter_done: null argument");
+	if (!n->have_scatter) return 0;
+	HCHK(hipSetDevice(n->dev[n->ingest]));
+	HCHK(hipEventSynchronize(n->ev1));
+	return 0;
+}
+
+extern "C" long sonde_node_sync(SondeNode *n)
+{
+	if (!n) return nfail("sonde_node_sync: null argument");
+	long total = 0;
+	for (uint32_t d = 0; d < n->nd; d++) {
+		const long k = sonde_batch_sync(n->batch[d]);
+		if (k < 0) return nfail("sonde_batch_sync", sonde_last_error());
+		total += k;
+	}
+	return total;
+}
+
+extern "C" long sonde_node_frames(SondeNode *n, SondeFrame *out, size_t cap)
+{
+	if (!n) return nfail("sonde_node_frames: null argument");
+	size_t k = 0;
+	for (uint32_t d = 0; d < n->nd; d++) {          // contiguous ascending ranges: device order is node-wide channel order
+		const long m = sonde_batch_sync(n->batch[d]);
+		if (m < 0) return nfail("sonde_batch_sync", sonde_last_error());
+		if (!out || cap == 0) { k += (size_t)m; continue; }        // count only
+		const size_t take = std::min((size_t)m, cap - k);
+		if (take == 0) continue;
+		const long got = sonde_batch_frames(n->batch[d], out + k, take);
+		if (got < 0) return nfail("sonde_batch_frames", sonde_last_error());
+		for (long i = 0; i < got; i++) out[k + (size_t)i].channel += n->first[d];
+		k += (size_t)got;
+	}
+	return (long)k;
+}
+
+extern "C" long sonde_node_poll(SondeNode *n, SondeData *out, uint32_t *channel, size_t cap)
+{
+	if (!n || !out || !channel) return nfail("sonde_node_poll: null argument");
+	size_t k = 0;
+	for (uint32_t d = 0; d < n->nd && k < cap; d++) {
+		const long got = sonde_batch_poll(n->batch[d], out + k, channel + k, cap - k);
+		if (got < 0) return nfail("sonde_batch_poll", sonde_last_error());
+		for (long i = 0; i < got; i++) channel[k + (size_t)i] += n->first[d];
+		k += (size_t)got;
+	}
+	return (long)k;
+}
+
+extern "C" int sonde_node_scatter_stats(SondeNode *n, float *ms, uint64_t *bytes_out, uint32_t *n_sends)
+{
+	if (!n) return nfail("sonde_node_scatter_stats: null argument");
+	float t = 0.0f;
+	if (n->have_scatter) {
+		HCHK(hipSetDevice(n->dev[n->ingest]));
+		HCHK(hipEventSynchronize(n->ev1));
+		HCHK(hipEventElapsedTime(&t, n->ev0, n->ev1));
+	}
+	if (ms) *ms = t;
+	if (bytes_out) *bytes_out = n->last_bytes;
+	if (n_sends) *n_sends = n->last_sends;
+	return 0;
+}

@@ -68,6 +68,13 @@ __device__ __forceinline__ float sd_atan2q(float y, float x)
 	return __builtin_copysignf(q2, y);
 }
 
+// discriminator behind the filter bank (SPEC 3.5, round 4): the wrapped difference of two phases given in quadrants, in [-2, 2]
+__device__ __forceinline__ float sd_phase_diff(float ph, float prev)
+{
+	const float t = ph - prev;
+	return __builtin_fmaf(-4.0f, __builtin_rintf(0.25f * t), t);
+}
+
 // AFC (SPEC 3.0b): the product x1 conj(x0) turned back by the phasor (c, sn) = (1 - u^2, 2u) before the arctangent; the phasor's
 // length does not matter to an arctangent
 __device__ __forceinline__ float sd_disc_rot(float x1, float y1, float x0, float y0, float c, float sn)

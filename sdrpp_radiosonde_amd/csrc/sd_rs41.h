@@ -102,7 +102,10 @@ __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t
 	}
 	if (lane == 0) {
 		lds_state.rpos = fs.rpos; lds_state.fstart = fs.fstart;
-		lds_state.collecting = fs.collecting; lds_state.inv = fs.inv; lds_state.flen = fs.flen; lds_state.nout = fs.nout;
+		lds_state.collecting = fs.collecting; lds_state.inv = fs.inv; lds_state.flen = fs.flen;
+		// nout is what ANOTHER wave (the in-loop clean-frame decoder, sd_rs41_loop_step on round wave 2) reads in the same round with
+		// no barrier in between: published behind the descriptors it announces (workgroup-scope release)
+		__hip_atomic_store(&lds_state.nout, fs.nout, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 	// the next step (same wave) reads the state back: DS operations of a wave execute in order
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

@@ -454,11 +454,15 @@ __device__ __attribute__((noinline)) void sd_rs41_loop_step(SdFecJob &job, const
 	FramerLds &wl, const uint32_t *__restrict__ ring, uint32_t mask, SondeFrame *__restrict__ fout, uint32_t ch, uint32_t max_frames, int lane)
 {
 	const int phase = __builtin_amdgcn_readfirstlane(job.phase), frame = __builtin_amdgcn_readfirstlane(job.frame);
-	const int listed = (int)min(min((uint32_t)__builtin_amdgcn_readfirstlane((int)k4.nout), max_frames), (uint32_t)SD_K4_LIST);
+	// K4 (round wave 3) may be appending to its list in this very round: the count is read with acquire semantics, behind K4's
+	// release store, so that every descriptor below `listed` is complete
+	const uint32_t nout_now = __hip_atomic_load(const_cast<uint32_t *>(&k4.nout), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	const int listed = (int)min(min((uint32_t)__builtin_amdgcn_readfirstlane((int)nout_now), max_frames), (uint32_t)SD_K4_LIST);
 	if (phase == 0 && frame >= listed) return;                   // nothing new (the usual step)
 	SdFrameDesc d;
 	d.fstart = sd_uniform64(reinterpret_cast<const unsigned long long *>(&k4.list[frame])[0]);
 	d.flen = __builtin_amdgcn_readfirstlane(k4.list[frame].flen);
+	d.flen = d.flen == 518 ? 518 : 320;                          // (a frame length is one of the two: the extract loop's bound never comes from anywhere else)
 	d.inv = __builtin_amdgcn_readfirstlane(k4.list[frame].inv);
 	const int W = (RS_R + (d.flen - 56) / 2 + 3) >> 2, Wh = W >> 1;
 	const int c = lane >= RS_R ? 1 : 0, j = lane - RS_R * c;

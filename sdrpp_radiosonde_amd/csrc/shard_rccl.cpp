@@ -110,3 +110,52 @@ extern "C" int sonde_shard_gather(SondeShard *s, const void *part_dev, size_t by
 	NCHK(ncclGroupEnd());
 	return 0;
 }
+
+// Scatter of ROWS into a strided destination (round 4): n_rows_total rows of row_bytes, root holds row k at
+// full_dev + k * src_stride_bytes; rank r owns the rows of sonde_shard_range(n_rows_total, world, r) -- unequal shards when the
+// count does not divide -- and receives them at shard_dev + row * dst_stride_bytes: straight into the rows its decoder reads
+// (sonde_row_stride), no re-stride copy behind the collective.  One ncclSend / ncclRecv pair per row, 256 rows of every peer
+// per group; with equal strides a peer's shard is one contiguous run (padding included): one pair per peer.  The root's own
+// shard is a strided device copy, not a send to itself.
+extern "C" int sonde_shard_scatter_rows(SondeShard *s, const void *full_dev, size_t src_stride_bytes, void *shard_dev, size_t dst_stride_bytes,
+                                        size_t row_bytes, uint32_t n_rows_total, int root, void *stream_)
+{
+	if (!s || !shard_dev || root < 0 || root >= s->world || (s->rank == root && !full_dev) || row_bytes == 0 ||
+	    src_stride_bytes < row_bytes || dst_stride_bytes < row_bytes || n_rows_total < (uint32_t)s->world)
+		return sfail("sonde_shard_scatter_rows: bad argument");
+	hipStream_t stream = (hipStream_t)stream_;
+	HCHK(hipSetDevice(s->device));
+	uint32_t my_first = 0, my_count = 0;
+	sonde_shard_range(n_rows_total, s->world, s->rank, &my_first, &my_count);
+	const bool same = src_stride_bytes == dst_stride_bytes;
+	const uint32_t max_rows = n_rows_total / (uint32_t)s->world + 1;
+	const uint32_t per_group = same ? max_rows : 256u;
+	for (uint32_t r0 = 0; r0 < max_rows; r0 += per_group) {
+		NCHK(ncclGroupStart());
+		ncclResult_t r = ncclSuccess;
+		if (s->rank == root) {
+			for (int p = 0; p < s->world && r == ncclSuccess; p++) {
+				if (p == root) continue;
+				uint32_t f = 0, c = 0;
+				sonde_shard_range(n_rows_total, s->world, p, &f, &c);
+				if (same) {
+					if (r0 == 0) r = ncclSend((const char *)full_dev + (size_t)f * src_stride_bytes, (size_t)(c - 1) * src_stride_bytes + row_bytes, ncclChar, p, s->comm, stream);
+				} else {
+					for (uint32_t row = r0; row < c && row < r0 + per_group && r == ncclSuccess; row++)
+						r = ncclSend((const char *)full_dev + ((size_t)f + row) * src_stride_bytes, row_bytes, ncclChar, p, s->comm, stream);
+				}
+			}
+		} else if (same) {
+			if (r0 == 0) r = ncclRecv(shard_dev, (size_t)(my_count - 1) * dst_stride_bytes + row_bytes, ncclChar, root, s->comm, stream);
+		} else {
+			for (uint32_t row = r0; row < my_count && row < r0 + per_group && r == ncclSuccess; row++)
+				r = ncclRecv((char *)shard_dev + (size_t)row * dst_stride_bytes, row_bytes, ncclChar, root, s->comm, stream);
+		}
+		if (r != ncclSuccess) { (void)ncclGroupEnd(); return sfail("ncclSend/ncclRecv", ncclGetErrorString(r)); }
+		NCHK(ncclGroupEnd());
+	}
+	if (s->rank == root)
+		HCHK(hipMemcpy2DAsync(shard_dev, dst_stride_bytes, (const char *)full_dev + (size_t)my_first * src_stride_bytes, src_stride_bytes,
+		                      row_bytes, my_count, hipMemcpyDeviceToDevice, stream));
+	return 0;
+}

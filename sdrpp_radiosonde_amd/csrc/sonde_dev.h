@@ -24,11 +24,13 @@
 // what the demod kernel's input rows hold
 #define SD_IN_REAL 0        // 48 kS/s FM-discriminator samples (float)
 #define SD_IN_IQ   1        // 48 kS/s complex samples
-#define SD_IN_BINS 2        // 40 kS/s complex samples of a channelizer bin: discriminator + composite 6/5 resampler-decimator in the kernel (SPEC 3.5b)
-#define SD_RS_KT_LD 20      // row stride of the composite taps (19 in use at 4:1, 17 at 2:1)
+#define SD_IN_BINS 2        // 20 kS/s PHASE samples of a channelizer bin (one float each): discriminator (wrapped difference) + composite
+                            // 12/5 resampler - 4:1 decimator in the kernel (SPEC 3.5b)
+#define SD_RS_KT_LD 20      // row stride of the composite taps (17 in use)
+#define SD_RS_KT    17
 struct SdBinsIn {           // SD_IN_BINS: composite taps and the state carried from block to block (device pointers)
-	const float *g;         // [2][3][SD_RS_KT_LD]: the rows for 2:1, then for 4:1
-	float       *iq_last;   // per channel [2]: the last bin sample (re, im) of the previous block
+	const float *g;         // [3][SD_RS_KT_LD]
+	float       *phi_last;  // per channel: the last phase sample of the previous block
 	float       *dhist;     // per channel: the last 16 discriminator samples of the previous block, oldest first
 };
 

@@ -73,6 +73,7 @@ class NativeShard:
             L.sonde_shard_range.restype = None
             L.sonde_shard_scatter.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
             L.sonde_shard_gather.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
+            L.sonde_shard_scatter_rows.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int, vp]
             L.sonde_shard_last_error.restype = C.c_char_p
             cls._lib = L
         return cls._lib
@@ -114,6 +115,25 @@ class NativeShard:
                                           nbytes, root, C.c_void_p(st)) != 0:
             raise RuntimeError(self.lib().sonde_shard_last_error().decode())
         return out
+
+    def scatter_rows(self, full: torch.Tensor | None, n_rows_total: int, n_samples: int, root: int = 0) -> torch.Tensor:
+        """root holds `full` = [n_rows_total, n, 2] float32 (rows may be strided); every rank gets the rows of its channel range
+        (sonde_shard_range: unequal when the count does not divide) STRAIGHT into rows on the decoder's recommended channel
+        stride: a [count, n, 2] view of a padded allocation, what SondeBatch.submit takes.  No re-stride copy."""
+        import ctypes as C
+        from .batch import row_stride
+        lo, hi = self.channel_range(n_rows_total, self.rank, self.world)
+        st_ = row_stride(n_samples, iq=True)
+        buf = torch.empty((hi - lo, st_, 2), dtype=torch.float32, device=f"cuda:{self.device}")
+        src_stride = 0
+        if self.rank == root:
+            assert full is not None and full.shape[0] == n_rows_total and full.shape[1] == n_samples and full.stride(1) == 2
+            src_stride = full.stride(0) * 4
+        st = torch.cuda.current_stream(buf.device).cuda_stream
+        if self.lib().sonde_shard_scatter_rows(self.h, C.c_void_p(full.data_ptr() if self.rank == root else 0), src_stride or n_samples * 8,
+                                               C.c_void_p(buf.data_ptr()), st_ * 8, n_samples * 8, n_rows_total, root, C.c_void_p(st)) != 0:
+            raise RuntimeError(self.lib().sonde_shard_last_error().decode())
+        return buf[:, :n_samples]
 
     def gather_bytes(self, part: torch.Tensor, root: int = 0) -> torch.Tensor | None:
         """Every rank contributes the same number of bytes (a padded frame block); root gets [world, nbytes] uint8."""

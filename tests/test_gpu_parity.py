@@ -266,7 +266,8 @@ def test_random_finite_garbage_matches_oracle(oracle):
 
 def test_rs41_wide_mode(oracle):
     """SONDE_FLAG_WIDE: RS41 at 2:1 instead of 4:1 (24 kS/s internally) -- bit-exact against the oracle set the same
-    way, and it decodes a carrier 4 kHz off centre, which the default (12 kS/s, like the reference's 10 kHz VFO) cannot."""
+    way, and it decodes every frame of a carrier 4 kHz off centre, where the default (12 kS/s, like the reference's 10 kHz VFO;
+    its AFC, SPEC 3.0b, pulls in +-2.6 kHz) loses most of them."""
     from sdrpp_radiosonde_amd._lib import FLAG_WIDE as FLAG_RS41_WIDE
     C_, n = 6, TILE * 60
     nbits = int(n * 4800 / 48000) + 16
@@ -277,7 +278,8 @@ def test_rs41_wide_mode(oracle):
     x = np.ascontiguousarray(np.stack([z.real, z.imag], axis=-1).astype(np.float32))
     narrow = SondeBatch(C_, n)
     narrow.submit(_dev(torch.from_numpy(x)))
-    assert len(narrow.frames()) == 0                                 # 4 kHz off: outside the default path's +-1 kHz
+    fn = narrow.frames()
+    n_narrow = int((fn["nerr"] >= 0).all(axis=1).sum())              # 4 kHz off: beyond the default path's AFC range
     wide = SondeBatch(C_, n, flags=FLAG_RS41_WIDE)
     wide.submit(_dev(torch.from_numpy(x)))
     got = wide.frames()
@@ -290,7 +292,7 @@ def test_rs41_wide_mode(oracle):
     assert got.tobytes() == ref.tobytes()
     sent = sum(len(f) for f in frames)
     good = [f for f in got if (f["nerr"] >= 0).all()]
-    assert len(good) >= sent - 2 * C_
+    assert len(good) >= sent - 2 * C_ and n_narrow < 0.75 * len(good)
     for f in good:
         assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in frames[f["channel"]])
 
@@ -298,7 +300,8 @@ def test_rs41_wide_mode(oracle):
 @pytest.mark.parametrize("stype,wide_decim,cfo", [(1, 2, 3700.0), (3, 1, 8000.0)])
 def test_wide_mode_other_types(oracle, stype, wide_decim, cfo):
     """SONDE_FLAG_WIDE for DFM (2:1 instead of 4:1) and M10 (48 kS/s instead of 2:1): the kernel classes (2, 16) and
-    (1, 16) -- bit-exact against the oracle set the same way; they decode a carrier offset the default classes cannot."""
+    (1, 16) -- bit-exact against the oracle set the same way; they decode every frame at a carrier offset where the default
+    classes (AFC range +-2.6 / +-5.2 kHz) lose frames."""
     from sdrpp_radiosonde_amd._lib import FLAG_WIDE
     C_, n = 6, TILE * 40
     sb = synth.make_batch(stype, C_, n, seed=63 + stype, ebn0_db=22.0, cfo_max_hz=0.0)
@@ -309,7 +312,7 @@ def test_wide_mode_other_types(oracle, stype, wide_decim, cfo):
     ok = lambda fr: int(((fr["nerr"][:, 1] == 0) if stype == 1 else (fr["nerr"][:, 0] == 0)).sum())
     narrow = SondeBatch(C_, n, types=types)
     narrow.submit(_dev(torch.from_numpy(x)))
-    assert ok(narrow.frames()) == 0
+    n_narrow = ok(narrow.frames())
     wide = SondeBatch(C_, n, types=types, flags=FLAG_WIDE)
     wide.submit(_dev(torch.from_numpy(x)))
     got = wide.frames()
@@ -321,7 +324,7 @@ def test_wide_mode_other_types(oracle, stype, wide_decim, cfo):
         L.or_modem_set_decim(stype, 2 * wide_decim)
     assert got.tobytes() == ref.tobytes()
     sent = sum(len(f) for f in sb.frames)
-    assert ok(got) >= sent - 2 * C_
+    assert ok(got) >= sent - 2 * C_ and n_narrow < 0.8 * ok(got)
 
 
 def test_split_fec_kernel_equals_fused_epilogue(oracle):
@@ -385,8 +388,10 @@ def test_rows_on_the_recommended_stride_and_host_staging(oracle):
     power of two in bytes -- what bench.py keeps resident and what sonde_batch_submit_host stages into) decode to the frames,
     bits and loop state of the back-to-back layout, which the tests above tie to the oracle."""
     from sdrpp_radiosonde_amd.batch import row_stride, strided_rows
-    C, n = 5, TILE * 36
-    assert row_stride(n) == 131072 and row_stride(TILE * 96) == 262144 and row_stride(TILE) == TILE and row_stride(TILE * 96, iq=False) == 262144
+    C, n = 5, TILE * 24
+    assert row_stride(n) == 65536 and row_stride(TILE * 96) == 262144 and row_stride(TILE) == TILE and row_stride(TILE * 96, iq=False) == 262144
+    # the padding is capped at a third (ADVICE r3): 576 KiB rows would need 1 MiB, they take an odd number of 64 KiB units instead
+    assert row_stride(TILE * 36) == TILE * 36 and row_stride(TILE * 33) == TILE * 36 and row_stride(TILE * 34) == TILE * 36 and row_stride(TILE * 65) == TILE * 68
     sb = synth.make_rs41_batch(C, n, seed=77, ebn0_db=16.0)
     outs = []
     for mode in ("contiguous", "strided", "host"):

@@ -18,7 +18,7 @@ def test_exports_and_range_arithmetic():
     L = shard.NativeShard.lib()
     hdr = open(os.path.join(ROOT, "include", "sonde_shard.h")).read()
     declared = set(re.findall(r"\b(sonde_shard_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) == 9
+    assert len(declared) == 10
     for s in declared:
         assert hasattr(L, s), s
     for n in (0, 1, 7, 1024, 65536, 65537):
@@ -41,4 +41,18 @@ def test_single_rank_scatter_gather_on_device():
     back = ns.gather_bytes(got, root=0)
     torch.cuda.synchronize()
     assert back.shape == (1, x.numel() * 4) and torch.equal(back.view(-1).view(torch.float32).reshape(x.shape), x)
+    ns.close()
+
+
+@pytest.mark.gpu
+def test_single_rank_scatter_rows_into_strided_rows():
+    """sonde_shard_scatter_rows: the rows land on the decoder's recommended channel stride (a view of a padded allocation)."""
+    import torch
+    from sdrpp_radiosonde_amd.batch import row_stride
+    ns = shard.NativeShard(0, rank=0, world=1)
+    n = 8 * 2048 + 2048                                   # 144 KiB rows -> 256 KiB stride
+    x = torch.randn((5, n, 2), device="cuda:0")
+    got = ns.scatter_rows(x, 5, n, root=0)
+    torch.cuda.synchronize()
+    assert got.shape == x.shape and got.stride(0) == 2 * row_stride(n) and torch.equal(got, x)
     ns.close()

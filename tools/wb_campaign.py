@@ -21,9 +21,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(77)
 t0 = time.time()
 for it in range(n):
-    streams = int(rng.choice([1, 1, 2, 3]))
-    bps = int(rng.choice([1, 2, 5]))
-    nblk = 10
+    streams = int(rng.choice([1, 1, 2, 3, 8]))
+    bps = int(rng.choice([1, 2, 5, 4]))
+    nblk = 12 if bps == 4 else 10
     ebn0 = float(rng.uniform(9.0, 30.0))
     seed = int(rng.integers(10, 10_000))
     active = sorted(int(x) for x in rng.choice(np.arange(2, 510), size=4, replace=False))
@@ -31,7 +31,7 @@ for it in range(n):
     scenes = [synth.make_wideband_rs41(active, nblk * tc.BLOCK, seed=seed + s, ebn0_db=ebn0, device="cuda:0")[0] for s in range(streams)]
     types = np.zeros(512 * streams, dtype=np.uint8)
     for s_ in range(streams):
-        types[[512 * s_ + k for k in m10]] = 3
+        types[[512 * s_ + k for k in m10]] = 1          # silent bins of another sonde type (DFM)
     chz = SondeChannelizer(types=types, blocks_per_submit=bps, n_streams=streams)
     assert chz.fused
     got = []
@@ -59,6 +59,6 @@ for it in range(n):
     ref = np.concatenate(refs)
     assert key(got).tobytes() == key(ref).tobytes(), it
     chz.close()
-    print(f"[{it + 1}/{n}] seed {seed} Eb/N0 {ebn0:5.1f} dB streams {streams} blocks/submit {bps} bins {active} + 2:1 {m10}: "
+    print(f"[{it + 1}/{n}] seed {seed} Eb/N0 {ebn0:5.1f} dB streams {streams} blocks/submit {bps} bins {active} + DFM {m10}: "
           f"{len(ref)} frames, {nbits} ring bits, loop state of {len(active + m10) * streams} bins identical to the oracle", flush=True)
 print(f"wideband campaign done in {time.time() - t0:.0f} s")
