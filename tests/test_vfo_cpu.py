@@ -33,11 +33,12 @@ def test_ratio_and_taps(rate):
     assert np.all(20 * np.log10(H[f > 0.75 * lo] + 1e-12) < -50.0)
 
 
-def test_six_fifths_is_the_channelizer_stage():
+def test_twelve_fifths_is_the_channelizer_stage():
+    """(round 4: the channelizer's bins run at 20 kS/s; its resampler is the VFO front-end's 20 kS/s stage, 12/5)"""
     L = oracle_lib.lib()
-    g = np.zeros((6, 16), dtype=np.float32)
+    g = np.zeros((12, 16), dtype=np.float32)
     L.or_chan_resamp_taps(oracle_lib.fptr(g))
-    assert np.array_equal(g, oracle_lib.Vfo(40000).taps())
+    assert np.array_equal(g, oracle_lib.Vfo(20000).taps())
 
 
 @pytest.mark.parametrize("rate", sorted(RATES))
