@@ -143,11 +143,9 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 // 20 kS/s phase samples of a channelizer bin (the per-bin FM discriminator -- a wrapped phase difference -- and the composite
 // 12/5 resampler - decimator of SPEC 3.5b then run in this kernel's load path: the 48 kS/s rows are never written to HBM).
 template <int IN, bool LIST, int DEC, int NT>
-#ifndef SD_BINS_WAVES
-#define SD_BINS_WAVES 6      // waves per SIMD of the SD_IN_BINS instantiations (<= 80 VGPRs, three workgroups per CU): at 8 (64 VGPRs) the tile
-                             // prefetch spills to scratch; 4096 bins x 3 tiles: 113 us at 4, 93 at 6 (profiles/r3_notes.md)
-#endif
-__global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void sd_demod_kernel(
+// (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU.  Round 3's SD_IN_BINS form -- complex 40 kS/s bins, the
+// discriminator in here -- needed 80 VGPRs; the round-4 form, phases in, fits: 4096 bins x 3 tiles 57.7 -> 50.3 us, r4_notes.md)
+__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
@@ -220,7 +218,7 @@ __global__ __launch_bounds__(SD_WGT, IN == SD_IN_BINS ? SD_BINS_WAVES : 8) void 
 	// waves issue the first two tiles' loads right away instead (below): a wave's vector loads retire in order (vmcnt), so a
 	// wave that has to wait for its share of the taps cannot have tile loads in flight behind them; with the state -> taps
 	// chain (two dependent global loads) and the first tile's HBM round trip in parallel a workgroup reaches its first round
-	// in ~4 us instead of ~7 (tools/life_probe.py).
+	// in ~4 us instead of ~7 (profiles/r3_notes.md).
 	uint32_t *ring_g = bitring + (size_t)ch * ring_words;
 	const uint32_t ring_mask = ring_words - 1;
 	if (!is_k) {

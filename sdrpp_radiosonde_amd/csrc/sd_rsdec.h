@@ -105,12 +105,7 @@ __device__ __forceinline__ uint32_t syndrome_swar(const FramerTabs &tb, const ui
 	return syndrome_swar_finish(tb, syndrome_swar_part(cw, W, 0, 0u, t), j);
 }
 
-#ifdef SD_EPI_TIMESTAMPS       // stage k of the corrector reached: time stamp into the unused tail of the second codeword buffer
-#define SD_TSI(k) do { __builtin_amdgcn_s_waitcnt(0); const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); \
-		if (lane == 0) for (int q_ = (k); q_ < 5; q_++) reinterpret_cast<uint32_t *>(s.cw[1] + 224)[q_] = now_; } while (0)
-#else
 #define SD_TSI(k)
-#endif
 
 // Decode both codewords held in s.cw[c][0..n) (zero-padded to 256).  Wave-synchronous; 64 lanes.
 __device__ void rs255_decode_pair(const FramerTabs &tb, FramerLds &s, int n, int lane, const GfSwar &swar)
@@ -506,13 +501,7 @@ __device__ __forceinline__ void sd_rs41_decode_frame(const FramerTabs &tabs, Fra
 	const uint32_t *__restrict__ ring, uint32_t mask, const SdFrameDesc d, SondeFrame *__restrict__ fr, uint32_t ch, int lane)
 {
 	const int flen = d.flen;
-#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
-	const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-	unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
-#define SD_TS(x) do { __builtin_amdgcn_s_waitcnt(0); x = __builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define SD_TS(x)
-#endif
 	sd_rs41_extract<COHERENT>(s, ring, mask, d, lane);
 	WAVE_SYNC();
 	SD_TS(ts1);
@@ -531,17 +520,5 @@ __device__ __forceinline__ void sd_rs41_decode_frame(const FramerTabs &tabs, Fra
 	}
 	WAVE_SYNC();
 	sd_rs41_write_record(s, d, fr, ch, lane);
-#ifdef SD_EPI_TIMESTAMPS       // tools/ts_probe.py: stage times of the FEC epilogue, stored behind the frame bytes
-	{
-		unsigned long long ts4;
-		SD_TS(ts4);
-		if (lane == 0) {
-			uint32_t *dbg = reinterpret_cast<uint32_t *>(fr->data) + 124;      // bytes 496..527: behind any frame but the extended one
-			dbg[0] = (uint32_t)(ts1 - ts0); dbg[1] = (uint32_t)(ts2 - ts1); dbg[2] = (uint32_t)(ts3 - ts2); dbg[3] = (uint32_t)(ts4 - ts3);
-			const uint32_t *ti = reinterpret_cast<const uint32_t *>(s.cw[1] + 224);          // syndromes, fast paths, locator, roots + values
-			dbg[4] = ti[1] - ti[0]; dbg[5] = ti[2] - ti[1]; dbg[6] = ti[3] - ti[2]; dbg[7] = ti[4] - ti[3];
-		}
-	}
-#endif
 	WAVE_SYNC();       // the next frame of this wave reuses s
 }
