@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--sonde-type", type=int, default=0, help="all channels of this SONDE_* type (1 DFM09, 2 iMS-100, 3 M10; not the headline workload)")
     ap.add_argument("--wideband", action="store_true", help="BASELINE configs[3]: 10 MS/s IQ -> 512-bin channelizer -> per-bin demod+FEC")
     ap.add_argument("--wb-streams", type=int, default=1, help="--wideband: independent 10 MS/s streams processed per step")
+    ap.add_argument("--wb-dual", action="store_true", help="--wideband: both stackings of every stream (even + odd-stacked bank: 1024 channels per stream, "
+                    "every carrier within 4.9 kHz of a bin centre)")
     ap.add_argument("--wb-overlap", action="store_true", help="--wideband: filter bank and decoder on two internal streams (consecutive submits may overlap)")
     ap.add_argument("--wb-blocks", type=int, default=1, choices=(1, 2, 4, 8), help="--wideband: blocks of 1 280 000 samples (0.128 s) per submit")
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
@@ -393,6 +395,57 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     return rec
 
 
+def host_e2e_run(C, tiles, NB, args, local_rank, dev, steps=20):
+    """The boundary's whole host path at the north_star's per-GPU shape: C channels, one second (24 tiles) at a time, from HOST memory
+    (pinned) through sonde_batch_submit_host (PCIe + staging into strided rows), the kernels, and sonde_batch_poll down to
+    SondeData fragments with their channel numbers (the reference's callback input, decoder.hpp:59-117, main.cpp:320-331).
+    PCIe-inclusive by construction: reported as a real-time factor, never as `value`."""
+    import ctypes
+    from sdrpp_radiosonde_amd import _lib
+    from sdrpp_radiosonde_amd.batch import SondeBatch
+    n = tiles * 2048
+    blocks, _ = make_blocks("rs41", C, tiles, NB, args.ebn0, dev, seed=1000)
+    host = [b.cpu().pin_memory().numpy() for b in blocks]
+    del blocks
+    torch.cuda.empty_cache()
+    batch = SondeBatch(C, n, device=local_rank)
+    L = batch.L
+    cap = 65536
+    out = (_lib.SondeData * cap)()
+    chan = (ctypes.c_uint32 * cap)()
+
+    def step(k):
+        batch.submit_host(host[k % NB])
+        nfr = batch.sync()
+        nfrag = 0
+        while True:
+            got = L.sonde_batch_poll(batch.h, out, chan, cap)
+            if got <= 0:
+                break
+            nfrag += got
+        return nfr, nfrag
+    for k in range(NB):                       # warm: staging buffer, parsers, clocks
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fr = fg = 0
+    for k in range(steps):
+        a, b_ = step(NB + k)
+        fr += a
+        fg += b_
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    batch.close()
+    sig_s = n / 48000.0
+    return {"channels": C, "samples_per_channel": n, "steps": steps, "ms_per_step": round(dt * 1e3, 3),
+            "value": round(C * n / dt / 1e6, 3), "unit": "Msamples/s (PCIe-inclusive, host to SondeData)",
+            "realtime_factor": round(sig_s / dt, 1), "realtime_channels": round(C * sig_s / dt, 0),
+            "frames_per_step": round(fr / steps, 1), "fragments_per_step": round(fg / steps, 1),
+            "note": "pinned host IQ -> sonde_batch_submit_host (PCIe, strided staging) -> kernels -> sonde_batch_poll -> SondeData fragments, synchronously, "
+                    "one step = one second of signal of every channel; realtime_channels = how many 48 kS/s channels this one GPU keeps up with through "
+                    "the whole host path"}
+
+
 def measured_traffic(args):
     """HBM bytes per launch of the demod kernel from rocprofv3 PMC counters, measured NOW: two separate --pmc passes
     (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md) over a 10-step sub-run of this script with the
@@ -619,10 +672,17 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                                         "(1.22 residencies of 4 workgroups x 256 CUs); SONDE_FLAG_PIPELINE: two launch units on their own streams, the tail of one overlaps the next submit of the other")
         others["ch1280x96"] = small_run("rs41", 1280, 96, 5, FLAG_PIPELINE, args, local_rank, dev, barrier, stream)
         others["ch1280x96"]["workload"] = "1280 RS41 channels x 196608 samples per step: the headline's rows, 1.25 residencies; SONDE_FLAG_PIPELINE (two launch units)"
-        for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8x4", 8, 4)):
+        try:
+            others["rt1250_host_e2e"] = host_e2e_run(1250, 24, 5, args, local_rank, dev)
+            others["rt1250_host_e2e"]["workload"] = ("the north_star's per-GPU share, end to end through the boundary: 1250 RS41 channels, one second at a time, host "
+                                                     "memory in, SondeData fragments out")
+        except Exception as e:                    # (never lets the line fail: the headline above does not depend on it)
+            others["rt1250_host_e2e"] = {"error": f"{type(e).__name__}: {e}"}
+        for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8x4", 8, 4), ("wideband4_dual", 4, 1)):
             import copy
             a = copy.copy(args)
             a.wb_streams, a.wb_blocks = S, B
+            a.wb_dual = name.endswith("_dual")
             a.steps, a.warmup, a.ramp_ms = max(40, min(args.steps, 50)), max(8, min(args.warmup, 10)), min(args.ramp_ms, 100.0)
             w = run_wideband(a, rank, local_rank, world, dev, barrier, reduce_max_sum)
             others[name] = {
@@ -709,7 +769,8 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
 
     S = args.wb_streams
-    chan = SondeChannelizer(blocks_per_submit=args.wb_blocks, device=local_rank, n_streams=S, overlap=getattr(args, "wb_overlap", False))      # ONE object: every stage is one launch over all S streams
+    dual = bool(getattr(args, "wb_dual", False))
+    chan = SondeChannelizer(blocks_per_submit=args.wb_blocks, device=local_rank, n_streams=S, overlap=getattr(args, "wb_overlap", False), dual=dual)      # ONE object: every stage is one launch over all S streams
     nwb = chan.samples_per_submit
     bins_active = list(range(8, 504, 8))
     # a 1.024 s scene (8 blocks of 0.128 s) with 16 RS41 transmitters, cycled block by block so that the per-bin streams
@@ -749,7 +810,8 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
         "ramp_ms": args.ramp_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{S} x 10 MS/s complex IQ -> 512-bin polyphase channelizer (20 kS/s/bin, one phase sample per step) -> FM discriminator (wrapped phase difference) -> 12/5 resampler "
-                               f"-> {S} x 512 x 48 kS/s RS41 demod+FEC, one launch per stage over all streams; {nwb} wideband samples per stream per step", "streams_per_gpu": S,
+                               f"-> {S} x {1024 if dual else 512} x 48 kS/s RS41 demod+FEC" + (" (both stackings: bins every 9.77 kHz)" if dual else "") +
+                               f", one launch per stage over all streams; {nwb} wideband samples per stream per step", "streams_per_gpu": S,
                    "wideband_samples_per_step": nwb},
         "realtime_factor": round(msps * 1e6 / (S * world * 10e6) , 2),
         "realtime_streams": round(msps / 10.0, 1),

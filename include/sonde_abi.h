@@ -244,7 +244,15 @@ int         sonde_chan_create(const uint8_t *types /* 512 entries or NULL = RS41
  * n_streams * 512 entries (stream-major) or is NULL; sonde_chan_submit then takes n_streams blocks laid out back to back,
  * [n_streams][n_samples] complex64; channel s * 512 + k of sonde_chan_batch() is bin k of stream s. */
 int         sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out);
-uint32_t    sonde_chan_streams(const SondeChannelizer *c);
+/* Both stackings of every stream (DESIGN SPEC 3.5c): besides the 512 bins centred at k x 19531.25 Hz a second, ODD-STACKED bank with
+ * bins centred at (k + 1/2) x 19531.25 Hz runs over the same samples, so that every carrier on the reference's 1 kHz VFO raster
+ * (/root/reference/src/main.cpp:14,55-56) lies within 4.9 kHz of a bin centre (a bin passes about +-5 kHz; the slicer follows the
+ * offset).  1024 decoder channels per stream: channel 1024 p + k = even bin k of stream p, 1024 p + 512 + k = odd bin k; types has
+ * n_streams * 1024 entries in that order (or is NULL).  Costs about twice the single bank (the same filter-bank kernel runs twice
+ * over the input, the decoder over twice the channels). */
+int         sonde_chan_create_dual(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out);
+uint32_t    sonde_chan_streams(const SondeChannelizer *c);       /* input streams per submit */
+uint32_t    sonde_chan_channels(const SondeChannelizer *c);      /* decoder channels: 512 per stream, 1024 with both stackings */
 /* By default (where every bin's sonde type allows it: no AFSK sonde) the per-bin discriminator and the 12/5 resampler run in
  * the decoder kernel's load path: a submit is two launches and the 48 kS/s rows never exist in HBM.  on = 0 keeps them as a
  * kernel of their own (then sonde_chan_read can return the rows: parity tests).  Call before the first submit; returns the mode

@@ -174,11 +174,43 @@ void or_fft512(float *re, float *im, const float *tw)
 }
 
 struct OrChan {
+	int odd;                     /* the odd-stacked bank (round 4): bin k centred at (k + 1/2) x 19531.25 Hz */
+	float wtw[2 * OR_CH_M];      /* its twist W[r] = exp(-j pi r / 512) */
 	float h[OR_CH_L], tw[OR_CH_M], g[OR_RS_L * OR_RS_T];
 	float *hist;                 /* last L-D wideband samples (I,Q) */
 	float phi_last[OR_CH_M];     /* per bin: the previous phase sample */
 	float dhist[OR_CH_M][OR_RS_T];   /* per bin: last 16 discriminator samples (oldest first) */
 };
+
+/* The ODD-STACKED bank (SPEC 3.5c, round 4): the same bank applied to the stream shifted down by half a bin,
+ * x'[n] = x[n] exp(-j pi n / 512), so that bin k is centred at (k + 1/2) bin spacings: together with the even bank every carrier
+ * on the reference's 1 kHz VFO raster (/root/reference/src/main.cpp:14,55-56) lies within 4.9 kHz of a bin centre.  Without touching
+ * the samples: window sample i = r + 512 t of step m is stream sample n0 + i, n0 = 500 m - 7692, so
+ * x'[n0 + i] = x[n0 + i] (-1)^t W[r] exp(-j pi n0 / 512): the taps of odd t change sign (exact), the folded value is multiplied by
+ * the twist W[r] = exp(-j pi r / 512) (t.re = fmaf(-v.im, W.im, v.re W.re), t.im = fmaf(v.re, W.im, v.im W.re)), and the step's
+ * common phase -pi 500 m / 512 = -(125 / 64) m quadrants (the constant part is dropped: a discriminator does not see it) is taken
+ * off the phase samples: phi = wrap(atan2q(...) - ramp(m)), ramp(m) = (125 (m mod 256)) / 64 wrapped into [-2, 2] (exact in
+ * float; 256 steps are a whole number of turns, and a block is a multiple of 256 steps: no state). */
+void or_chan_twist(float *w /* 2*512: (re, im) of exp(-j pi r / 512) */)
+{
+	for (int r = 0; r < OR_CH_M; r++) {
+		w[2 * r] = (float)cos(CH_PI * (double)r / (double)OR_CH_M);
+		w[2 * r + 1] = (float)(-sin(CH_PI * (double)r / (double)OR_CH_M));
+	}
+}
+float or_chan_ramp(size_t m)
+{
+	const float t = (float)(125u * (unsigned)(m & 255u)) * (1.0f / 64.0f);      /* < 499: exact */
+	return fmaf(-4.0f, rintf(0.25f * t), t);
+}
+OrChan *or_chan_new_odd(void)
+{
+	OrChan *c = or_chan_new();
+	c->odd = 1;
+	or_chan_twist(c->wtw);
+	for (int i = 0; i < OR_CH_L; i++) if ((i / OR_CH_M) & 1) c->h[i] = -c->h[i];
+	return c;
+}
 
 OrChan *or_chan_new(void)
 {
@@ -219,10 +251,22 @@ void or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, flo
 				ar = fmaf(c->h[i], x[2 * i], ar);
 				ai = fmaf(c->h[i], x[2 * i + 1], ai);
 			}
+			if (c->odd) {
+				const float wr = c->wtw[2 * r], wi = c->wtw[2 * r + 1];
+				const float tr = fmaf(-ai, wi, ar * wr), ti = fmaf(ar, wi, ai * wr);
+				ar = tr; ai = ti;
+			}
 			re[(r + shift) & (OR_CH_M - 1)] = ar;
 			im[(r + shift) & (OR_CH_M - 1)] = ai;
 		}
 		or_fft512(re, im, c->tw);
+		if (c->odd) {
+			const float ramp = or_chan_ramp(m);
+			for (int k = 0; k < OR_CH_M; k++) {
+				const float t = or_atan2(im[k], re[k]) - ramp;
+				bl[(size_t)k * n_steps + m] = fmaf(-4.0f, rintf(0.25f * t), t);
+			}
+		} else
 		for (int k = 0; k < OR_CH_M; k++) bl[(size_t)k * n_steps + m] = or_atan2(im[k], re[k]);
 	}
 	memcpy(c->hist, buf + 2 * N, 2 * H * sizeof(float));   /* last L-D samples of [hist|block] */

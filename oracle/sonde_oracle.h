@@ -169,6 +169,9 @@ void    or_vfo_free(OrVfo *v);
 size_t  or_vfo_process(OrVfo *v, const float *iq, size_t n_in, float *out48);
 void    or_fft512(float *re, float *im, const float *tw);
 OrChan *or_chan_new(void);
+OrChan *or_chan_new_odd(void);        /* the odd-stacked bank: bin k centred at (k + 1/2) bin spacings (SPEC 3.5c) */
+void    or_chan_twist(float *w);
+float   or_chan_ramp(size_t m);
 void    or_chan_free(OrChan *c);
 void    or_chan_block(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48);
 void    or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, float *out48, const uint8_t *decs, float *outdec);

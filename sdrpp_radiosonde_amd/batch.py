@@ -182,18 +182,24 @@ class SondeChannelizer:
     [n_streams, samples_per_submit, 2].  Bins carry the 12 kS/s sondes (RS41, DFM, iMS-100, MRZ-N1) and, unfused, the AFSK
     sondes; an M10 channel (50 kHz wide) does not fit a 19.5 kHz bin: use SondeVfo for those."""
 
-    def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0, n_streams: int = 1, fused: bool | None = None, overlap: bool | None = None):
+    def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0, n_streams: int = 1, fused: bool | None = None, overlap: bool | None = None,
+                 dual: bool = False):
+        """dual: both stackings of every stream (SPEC 3.5c): 1024 channels per stream, 1024 p + k = even bin k (centre k x 19531.25 Hz),
+        1024 p + 512 + k = odd bin k (centre (k + 1/2) x 19531.25 Hz): every carrier lies within 4.9 kHz of a bin centre."""
         self.L = _lib.load()
         self._types = None
         self.n_streams = int(n_streams)
+        self.dual = bool(dual)
+        self.n_channels = (1024 if dual else 512) * self.n_streams
         tp = None
         if types is not None:
             self._types = np.ascontiguousarray(types, dtype=np.uint8)
-            assert self._types.shape == (512 * self.n_streams,)
+            assert self._types.shape == (self.n_channels,)
             tp = self._types.ctypes.data_as(C.c_void_p)
         h = C.c_void_p()
-        if self.L.sonde_chan_create_multi(tp, blocks_per_submit, self.n_streams, device, C.byref(h)) != 0:
-            raise SondeError(_lib.last_error() or "sonde_chan_create_multi failed")
+        create = self.L.sonde_chan_create_dual if dual else self.L.sonde_chan_create_multi
+        if create(tp, blocks_per_submit, self.n_streams, device, C.byref(h)) != 0:
+            raise SondeError(_lib.last_error() or "sonde_chan_create failed")
         self.h = h
         # fused (default where possible): discriminator + resampler inside the decoder kernel; fused=False keeps the 48 kS/s rows
         # (read()); fused=None leaves the library's choice (and its SONDE_CHAN_UNFUSED switch) alone
@@ -205,7 +211,7 @@ class SondeChannelizer:
         self.batch = SondeBatch.__new__(SondeBatch)          # borrowed view of the embedded 512-channel batch
         self.batch.L = self.L
         self.batch.h = C.c_void_p(self.L.sonde_chan_batch(self.h))
-        self.batch.n_channels = 512 * self.n_streams
+        self.batch.n_channels = self.n_channels
         self.batch.close = lambda: None
 
     def submit(self, iq, stream: int | None = None):
@@ -227,8 +233,8 @@ class SondeChannelizer:
 
     def read(self):
         """(phases [bins, n_steps] in quadrants, 48 kS/s rows [bins, n_steps * 12 / 5] or None in fused mode) of the last submit."""
-        bins = np.zeros((512 * self.n_streams, self.n_steps), dtype=np.float32)
-        out48 = None if self.fused else np.zeros((512 * self.n_streams, self.n_steps * 12 // 5), dtype=np.float32)
+        bins = np.zeros((self.n_channels, self.n_steps), dtype=np.float32)
+        out48 = None if self.fused else np.zeros((self.n_channels, self.n_steps * 12 // 5), dtype=np.float32)
         if self.L.sonde_chan_read(self.h, bins.ctypes.data_as(C.c_void_p), out48.ctypes.data_as(C.c_void_p) if out48 is not None else None) != 0:
             raise SondeError("sonde_chan_read failed")
         return bins, out48

@@ -109,8 +109,9 @@ __device__ __forceinline__ void pfb_fft512(float2 *fb, const float2 *s_tw, int l
 
 __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const float2 *__restrict__ iq_all, size_t stream_stride,
                                                            const float2 *__restrict__ hist_in_all, float2 *__restrict__ hist_out_all,
-                                                           const float *__restrict__ h, const float2 *__restrict__ tw,
-                                                           float *__restrict__ phi_all, uint32_t n_steps, uint32_t xcd_map)
+                                                           const float *__restrict__ h_even, const float2 *__restrict__ tw,
+                                                           float *__restrict__ phi_all, uint32_t n_steps, uint32_t xcd_map,
+                                                           uint32_t dual, const float *__restrict__ h_odd, const float2 *__restrict__ twist)
 {
 	__shared__ __attribute__((aligned(16))) float2 s_x[P_CHW];
 	float2 *const s_tw = s_x + P_S * PFB_FB;                 // written once the window is dead
@@ -120,9 +121,15 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const float2 *__restric
 	// served by that XCD's L2 (round 3: 8 streams 104 -> 97 us; one stream x one block loses: the host asks for it from two
 	// generations of workgroups on, xcd_map)
 	const uint32_t grp = xcd_map ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+	// blockIdx.y = LOGICAL stream.  dual (SPEC 3.5c): logical streams 2p and 2p + 1 are the even and the odd-stacked bank (bins centred
+	// at k and k + 1/2 bin spacings) of physical stream p: the same samples, taps of odd t negated, a twist behind the fold, the
+	// step's common phase taken off the phase samples
 	const uint32_t m0 = grp * P_S, sidx = blockIdx.y;
-	const float2 *iq = iq_all + (size_t)sidx * stream_stride;
-	const float2 *hist_in = hist_in_all + (size_t)sidx * CH_H;
+	const bool odd = dual && (sidx & 1u);
+	const uint32_t phys = dual ? sidx >> 1 : sidx;
+	const float *h = odd ? h_odd : h_even;
+	const float2 *iq = iq_all + (size_t)phys * stream_stride;
+	const float2 *hist_in = hist_in_all + (size_t)phys * CH_H;
 	float *phi = phi_all + (size_t)sidx * CH_M * n_steps;
 	const long p0 = (long)m0 * CH_D - CH_H;                   // stream position of window sample 0 (even)
 	constexpr int NQ = (P_CHW / 2 + P_NT - 1) / P_NT;
@@ -152,9 +159,9 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const float2 *__restric
 	float hr[CH_T];
 #pragma unroll
 	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
-	if (grp == gridDim.x - 1) {     // the last CH_H samples of the block are the next submit's history (n_steps * 500 >= CH_H)
+	if (grp == gridDim.x - 1 && !odd) {     // the last CH_H samples of the block are the next submit's history (n_steps * 500 >= CH_H)
 		const float4 *tail = reinterpret_cast<const float4 *>(iq + (size_t)n_steps * CH_D - CH_H);
-		float4 *ho = reinterpret_cast<float4 *>(hist_out_all + (size_t)sidx * CH_H);
+		float4 *ho = reinterpret_cast<float4 *>(hist_out_all + (size_t)phys * CH_H);
 		for (int i = tid; i < CH_H / 2; i += P_NT) ho[i] = tail[i];
 	}
 	store_round(ta);
@@ -182,6 +189,14 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const float2 *__restric
 	__syncthreads();
 	fold_round(1);
 	__syncthreads();                       // the window is dead from here on
+	if (odd) {                              // the twist W[r] = exp(-j pi r / 512) (wave-uniform branch)
+		const float2 w = twist[r];
+#pragma unroll
+		for (int q = 0; q < P_S; q++) {
+			const float tr = __builtin_fmaf(-v[q].y, w.y, v[q].x * w.x), ti = __builtin_fmaf(v[q].x, w.y, v[q].y * w.x);
+			v[q] = make_float2(tr, ti);
+		}
+	}
 	// 3. rotate + bit-reverse into the buffer of the step; twiddles next to the buffers
 #pragma unroll
 	for (int q = 0; q < P_S; q++) {
@@ -197,6 +212,12 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const float2 *__restric
 	float ph[8];
 #pragma unroll
 	for (int j = 0; j < 8; j++) ph[j] = sd_atan2q(e0[j].y, e0[j].x);
+	if (odd) {                              // the step's common phase -(125 / 64) m quadrants (256 steps = whole turns; a block is a multiple of 256 steps)
+		const float t = (float)(125u * ((m0 + (uint32_t)wave) & 255u)) * (1.0f / 64.0f);
+		const float ramp = __builtin_fmaf(-4.0f, __builtin_rintf(0.25f * t), t);
+#pragma unroll
+		for (int j = 0; j < 8; j++) ph[j] = sd_phase_diff(ph[j], ramp);
+	}
 	__syncthreads();                       // every wave has left its FFT buffer: the phase tile aliases them
 	float *const s_t = reinterpret_cast<float *>(s_x);
 #pragma unroll
@@ -245,7 +266,9 @@ extern "C" const char *sonde_last_error(void);
 
 struct SondeChannelizer {
 	int device = 0;
-	uint32_t n_steps = 0, n_streams = 1;
+	uint32_t n_steps = 0, n_streams = 1;     // n_streams: LOGICAL streams (grid.y, 512 decoder channels each)
+	uint32_t n_phys = 1, dual = 0;            // physical input streams; dual: every physical stream feeds an even and an odd-stacked bank (SPEC 3.5c)
+	float *d_h_odd = nullptr; float2 *d_twist = nullptr;
 	bool fused = false;                    // the decoder kernel takes the bins themselves (discriminator + resampler in its load path): two launches per submit
 	SdBinsIn *d_bins_in = nullptr;
 	hipStream_t last_stream = nullptr;     // a submit on another stream waits for the previous one (the state is carried)
@@ -345,12 +368,24 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 	if (c->s_dec) (void)hipStreamDestroy(c->s_dec);
 	(void)hipFree(c->d_bins_b);
 	(void)hipFree(c->d_hist[0]); (void)hipFree(c->d_hist[1]); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_philast);
-	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48); (void)hipFree(c->d_bins_in); (void)hipFree(c->d_gc);
+	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48); (void)hipFree(c->d_bins_in); (void)hipFree(c->d_gc); (void)hipFree(c->d_h_odd); (void)hipFree(c->d_twist);
 	delete c;
 }
 
+static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_phys, uint32_t dual, int device, SondeChannelizer **out);
 extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out)
 {
+	return chan_create(types, blocks_per_submit, n_streams, 0, device, out);
+}
+// Both stackings of every stream (SPEC 3.5c): 1024 decoder channels per stream, channel 1024 p + k = even bin k (centre k x 19531.25 Hz),
+// 1024 p + 512 + k = odd bin k (centre (k + 1/2) x 19531.25 Hz): every carrier lies within 4.9 kHz of a bin centre.
+extern "C" int sonde_chan_create_dual(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_streams, int device, SondeChannelizer **out)
+{
+	return chan_create(types, blocks_per_submit, n_streams, 1, device, out);
+}
+static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_t n_phys, uint32_t dual, int device, SondeChannelizer **out)
+{
+	const uint32_t n_streams = n_phys * (dual ? 2u : 1u);
 	// up to 8 blocks per submit when the decoder takes the phases itself; the stand-alone discriminator + resampler kernel stages
 	// (16 + 2560 q) floats per bin in LDS: 1-2 blocks
 	if (!out || blocks_per_submit == 0 || blocks_per_submit > 8 || n_streams == 0 || n_streams > 64) return -1;
@@ -361,6 +396,8 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 	SondeChannelizer *c = new SondeChannelizer;
 	c->device = device;
 	c->n_streams = n_streams;
+	c->n_phys = n_phys;
+	c->dual = dual;
 	c->n_steps = 2560u * blocks_per_submit;                  // 2560 steps = 1.28 M wideband samples = 6144 samples at 48 kS/s
 	c->xcd_map = (c->n_steps / P_S) % 8 == 0 && (size_t)(c->n_steps / P_S) * n_streams > 1024 && !getenv("SONDE_PFB_NOXCD");
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
@@ -375,7 +412,7 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 	if (sonde_batch_create(&cfg, &c->batch) != 0) { delete c; return -1; }
 	std::vector<float> h, tw, g;
 	make_tables(h, tw, g);
-	const size_t hist_bytes = (size_t)n_streams * CH_H * sizeof(float2);
+	const size_t hist_bytes = (size_t)n_phys * CH_H * sizeof(float2);
 	bool ok = hipMalloc((void **)&c->d_hist[0], hist_bytes) == hipSuccess && hipMalloc((void **)&c->d_hist[1], hist_bytes) == hipSuccess &&
 	          hipMalloc((void **)&c->d_bins, nb * c->n_steps * sizeof(float)) == hipSuccess &&
 	          (blocks_per_submit > 2 || hipMalloc((void **)&c->d_out48, nb * n_out * sizeof(float)) == hipSuccess) &&
@@ -395,6 +432,15 @@ extern "C" int sonde_chan_create_multi(const uint8_t *types, uint32_t blocks_per
 		float gc[3 * SD_RS_KT_LD];
 		composite_rows(g, 4, gc);
 		ok = hipMalloc((void **)&c->d_gc, sizeof(gc)) == hipSuccess && hipMemcpy(c->d_gc, gc, sizeof(gc), hipMemcpyHostToDevice) == hipSuccess;
+		if (ok && dual) {                     // the odd-stacked bank's tables: taps of odd t negated, twist exp(-j pi r / 512)
+			const double PI = 3.14159265358979323846;
+			std::vector<float> ho(h), wt(2 * CH_M);
+			for (int i = 0; i < CH_L; i++) if ((i / CH_M) & 1) ho[i] = -ho[i];
+			for (int r = 0; r < CH_M; r++) { wt[2 * r] = (float)cos(PI * (double)r / (double)CH_M); wt[2 * r + 1] = (float)(-sin(PI * (double)r / (double)CH_M)); }
+			ok = hipMalloc((void **)&c->d_h_odd, CH_L * sizeof(float)) == hipSuccess && hipMalloc((void **)&c->d_twist, CH_M * sizeof(float2)) == hipSuccess &&
+			     hipMemcpy(c->d_h_odd, ho.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+			     hipMemcpy(c->d_twist, wt.data(), CH_M * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
+		}
 		const SdBinsIn bi = { c->d_gc, c->d_philast, c->d_dhist };
 		ok = ok && hipMalloc((void **)&c->d_bins_in, sizeof(bi)) == hipSuccess && hipMemcpy(c->d_bins_in, &bi, sizeof(bi), hipMemcpyHostToDevice) == hipSuccess;
 		// fused unless a bin's sonde type needs 48 kS/s rows (AFSK) or the host asks for the rows (sonde_chan_set_fused, SONDE_CHAN_UNFUSED)
@@ -411,7 +457,8 @@ extern "C" int sonde_chan_create(const uint8_t *types, uint32_t blocks_per_submi
 {
 	return sonde_chan_create_multi(types, blocks_per_submit, 1, device, out);
 }
-extern "C" uint32_t sonde_chan_streams(const SondeChannelizer *c) { return c ? c->n_streams : 0; }
+extern "C" uint32_t sonde_chan_streams(const SondeChannelizer *c) { return c ? c->n_phys : 0; }          // physical input streams
+extern "C" uint32_t sonde_chan_channels(const SondeChannelizer *c) { return c ? c->n_streams * CH_M : 0; }  // decoder channels: 512 (dual: 1024) per stream
 // on = 0: keep the per-bin discriminator + resampler as a kernel of its own, so that the 48 kS/s rows exist (sonde_chan_read;
 // parity tests); on = 1 (the default where every bin's sonde type allows it): they run inside the decoder kernel.  Before the
 // first submit only.  Returns the mode in force.
@@ -475,7 +522,7 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		if (c->n_blocks >= 2 && hipStreamWaitEvent(c->s_pfb, c->ev_dec[b], 0) != hipSuccess) return -1;
 		if (timed) (void)hipEventRecord(c->ev[0], c->s_pfb);
 		hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / P_S, c->n_streams), dim3(P_NT), 0, c->s_pfb, (const float2 *)iq_dev, n_samples,
-		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map);
+		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
 		c->n_blocks++;
 		c->d_bins_last = bins;
 		if (timed) { (void)hipEventRecord(c->ev[1], c->s_pfb); (void)hipEventRecord(c->ev[2], c->s_pfb); c->ev_pending = true; }
@@ -496,7 +543,7 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 	c->last_stream = stream;
 	if (timed) (void)hipEventRecord(c->ev[0], stream);
 	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / P_S, c->n_streams), dim3(P_NT), 0, stream, (const float2 *)iq_dev, n_samples,
-	                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps, c->xcd_map);
+	                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
 	c->n_blocks++;
 	c->d_bins_last = c->d_bins;
 	if (timed) (void)hipEventRecord(c->ev[1], stream);

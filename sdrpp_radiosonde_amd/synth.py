@@ -1074,9 +1074,10 @@ WB_BINS = 512
 
 
 def make_wideband_rs41(bins_active, n_samples: int, *, seed: int = 1, ebn0_db: float = 30.0,
-                       device: str | torch.device = "cpu"):
-    """RS41 transmitters at the centres of the given channelizer bins (spacing 19531.25 Hz), summed into one
-    10 MS/s complex stream [n_samples, 2].  Returns (iq, {bin: [(bit offset, frame bytes), ...]})."""
+                       device: str | torch.device = "cpu", offset_hz: float = 0.0):
+    """RS41 transmitters at the centres of the given channelizer bins (spacing 19531.25 Hz; each within +-300 Hz of it, plus
+    offset_hz for all of them), summed into one 10 MS/s complex stream [n_samples, 2].
+    Returns (iq, {bin: [(bit offset, frame bytes), ...]})."""
     bins_active = list(bins_active)
     baud = 4800.0
     nbits = int(n_samples * baud / WB_FS) + 16
@@ -1088,7 +1089,7 @@ def make_wideband_rs41(bins_active, n_samples: int, *, seed: int = 1, ebn0_db: f
         # noise is added once per transmitter at its own Eb/N0 (white over the full 10 MHz)
         iq, _, _, _ = gfsk_modulate(bits[i: i + 1], n_samples, baud, seed=seed + 31 * i, ebn0_db=ebn0_db, device=device,
                                     cfo_max_hz=300.0, amp_range=(0.5, 0.9), fs=WB_FS)
-        ph = (2.0 * math.pi * k / WB_BINS) * n
+        ph = (2.0 * math.pi * (k / WB_BINS + offset_hz / WB_FS)) * n
         c, s_ = torch.cos(ph).to(torch.float32), torch.sin(ph).to(torch.float32)
         total[:, 0] += iq[0, :, 0] * c - iq[0, :, 1] * s_
         total[:, 1] += iq[0, :, 0] * s_ + iq[0, :, 1] * c

@@ -71,6 +71,10 @@ def lib():
     L.or_batch_run.restype = C.c_size_t
     L.or_batch_run.argtypes = [C.c_int, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
     L.or_chan_new.restype = C.c_void_p
+    L.or_chan_new_odd.restype = C.c_void_p
+    L.or_chan_twist.argtypes = [f32p]
+    L.or_chan_ramp.restype = C.c_float
+    L.or_chan_ramp.argtypes = [C.c_size_t]
     L.or_chan_free.argtypes = [C.c_void_p]
     L.or_chan_block.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, f32p]
     L.or_chan_block2.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, f32p, C.c_void_p, f32p]

@@ -52,12 +52,12 @@ def test_channelizer_isolates_a_tone(oracle):
     assert np.allclose(out48[k, 500:], 4 * df / 20000, atol=2e-3)
 
 
-def _oracle_decode_wideband(oracle, iq_np, bins_active, types=None, composite=False):
+def _oracle_decode_wideband(oracle, iq_np, bins_active, types=None, composite=False, odd=False):
     """composite=False: 48 kS/s rows (SPEC 3.5) fed to the channels' real-input path (what the product's unfused mode does);
     composite=True: the decimated rows of SPEC 3.5b (resampler + boxcar as one filter: the product's default, fused mode)."""
     L = oracle.lib()
     nblk = iq_np.shape[0] // BLOCK
-    ch = L.or_chan_new()
+    ch = L.or_chan_new_odd() if odd else L.or_chan_new()      # odd: the half-bin-shifted bank (SPEC 3.5c)
     dec = {k: oracle.Channel(int(types[k]) if types is not None else 0, k) for k in bins_active}
     n_out = STEPS * 12 // 5
     out48 = np.zeros((512, n_out), dtype=np.float32)
@@ -106,6 +106,30 @@ def test_composite_rows_are_resample_then_average(oracle):
     assert (G.reshape(3, 20)[:, 17:] == 0).all() and (G.reshape(3, 20)[:, 16] != 0).any()
     fa, fc = a[100].frames(), c[100].frames()
     assert len(fa) >= 1 and np.array_equal(fa["data"], fc["data"]) and np.array_equal(fa["bitpos"], fc["bitpos"])
+
+
+def test_odd_stacked_bank_covers_the_gaps_between_bins(oracle):
+    """SPEC 3.5c: a transmitter half a bin (9.77 kHz) above the centre of bin 100 is out of every even bin's reach and in the middle of
+    odd bin 100; one 4 kHz above an even centre decodes in the even bank (the reaches overlap: at 30 dB the odd bank may have it too,
+    5.8 kHz off): the two banks together cover the whole band
+    (the reference's VFO sits anywhere on a 1 kHz raster, /root/reference/src/main.cpp:14,55-56)."""
+    half = 10e6 / 512 / 2
+    iq, truth = synth.make_wideband_rs41([100, 333], 10 * BLOCK, seed=6, ebn0_db=30.0, offset_hz=half)
+    even, _ = _oracle_decode_wideband(oracle, iq.numpy(), [100, 101, 333, 334], composite=True)
+    odd, _ = _oracle_decode_wideband(oracle, iq.numpy(), [100, 333], composite=True, odd=True)
+    for k in (100, 333):
+        assert len(even[k].frames()) == 0 and len(even[k + 1].frames()) == 0
+        fr = odd[k].frames()
+        assert len(fr) >= 1 and (fr["nerr"] >= 0).all()
+        for f in fr:
+            assert any(np.array_equal(tx[8:], f["data"][8:320]) for _, tx in truth[k])
+    iq, truth = synth.make_wideband_rs41([100, 333], 10 * BLOCK, seed=6, ebn0_db=30.0, offset_hz=4000.0)
+    even, _ = _oracle_decode_wideband(oracle, iq.numpy(), [100, 333], composite=True)
+    assert all(len(even[k].frames()) >= 1 for k in (100, 333))
+    # the ramp: 256 steps are a whole number of turns, every value lies in [-2, 2]
+    L = oracle.lib()
+    r = np.array([L.or_chan_ramp(m) for m in range(512)])
+    assert np.array_equal(r[:256], r[256:]) and np.abs(r).max() <= 2.0 and r[0] == 0.0 and abs(r[1] - 1.953125) < 1e-7
 
 
 def test_oracle_decodes_rs41_out_of_a_wideband_scene(oracle):
@@ -278,6 +302,55 @@ def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
     assert chz.batch.nbits(c7) == len(rb) > 3000 and np.array_equal(chz.batch.read_bits(c7, len(rb) - 3000, 3000), rb[-3000:])
     st, rs = chz.batch.state(c7), dec[7].state()
     assert (st["t_next"], st["period"]) == (rs["t_next"], rs["period"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused,streams", [(True, 4), (False, 2)])
+def test_dual_stacking_equals_oracle_and_covers_the_band(oracle, fused, streams):
+    """sonde_chan_create_dual (SPEC 3.5c): the even and the odd-stacked bank over the same samples, two streams.  Stream 0 carries
+    transmitters half a bin above bins 100 / 333 (decoded by odd bins 100 / 333 only), stream 1 transmitters 3 kHz above bins 40 / 200
+    (even bins); (True, 4) = the shape of bench.py's other_configs.wideband4_dual (streams 2 and 3: two more scenes).  Phases of every
+    bin of both banks, frames, bits and loop state equal the oracle's two banks."""
+    import torch
+    from sdrpp_radiosonde_amd.batch import SondeChannelizer
+    half = 10e6 / 512 / 2
+    NBLK = 10
+    sc = [synth.make_wideband_rs41([100, 333], NBLK * BLOCK, seed=6, ebn0_db=30.0, offset_hz=half, device="cuda:0")[0],
+          synth.make_wideband_rs41([40, 200], NBLK * BLOCK, seed=9, ebn0_db=30.0, offset_hz=3000.0, device="cuda:0")[0]]
+    watch = {0: [100, 333, 101], 1: [40, 200]}
+    for extra in range(2, streams):
+        sc.append(synth.make_wideband_rs41([7 + extra, 450], NBLK * BLOCK, seed=20 + extra, ebn0_db=30.0, offset_hz=-half if extra & 1 else 0.0, device="cuda:0")[0])
+        watch[extra] = [7 + extra, 450, 6 + extra, 449]
+    chz = SondeChannelizer(n_streams=streams, dual=True, fused=fused)
+    assert chz.n_channels == 1024 * streams and chz.fused == fused
+    got, first = [], None
+    for b in range(NBLK):
+        chz.submit(torch.stack([s[b * BLOCK: (b + 1) * BLOCK] for s in sc]).contiguous())
+        if b == 0:
+            first = chz.read()
+        got.append(chz.frames())
+    got = np.concatenate(got)
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    refs = []
+    for p in range(streams):
+        host = sc[p].cpu().numpy()
+        for odd in (False, True):
+            dec, ofirst = _oracle_decode_wideband(oracle, host, watch[p], composite=fused, odd=odd)
+            base = 1024 * p + (512 if odd else 0)
+            assert first[0][base: base + 512].tobytes() == ofirst[0].tobytes(), (p, odd)      # phases of all 512 bins, first block
+            for k in watch[p]:
+                r = dec[k].frames().copy()
+                r["channel"] = base + k
+                refs.append(r)
+                st, rs = chz.batch.state(base + k), dec[k].state()
+                assert (st["t_next"], st["period"]) == (rs["t_next"], rs["period"]) and chz.batch.nbits(base + k) == len(dec[k].bits())
+    ref = np.concatenate(refs)
+    want_ch = {1024 * 0 + 512 + 100, 1024 * 0 + 512 + 333, 1024 * 1 + 40, 1024 * 1 + 200}
+    assert want_ch <= set(ref["channel"].tolist())
+    watched = {1024 * p + 512 * o + k for p in range(streams) for o in (0, 1) for k in watch[p]}
+    sel = got[np.isin(got["channel"], sorted(watched))]
+    assert key(sel).tobytes() == key(ref).tobytes()
+    assert not (set(got["channel"].tolist()) & {100, 333})          # the even bank of stream 0 hears nothing of the half-bin transmitters
 
 
 @pytest.mark.gpu

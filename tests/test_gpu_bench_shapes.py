@@ -5,6 +5,7 @@ other_configs.mix4096               test_mix4096_pipelined_five_blocks_back_to_b
 low_snr                             test_headline_shape_at_9_db                        (1024 x 96 tiles, Eb/N0 9 dB)
 other_configs.rt1250, ch1280x96     test_part_filled_last_generation[1250-24-4 / 1280-96-4]  (not a multiple of one residency; pipelined, two units)
 other_configs.wideband8x4           tests/test_channelizer.py::test_fused_channelizer_frames_equal_oracle[4-8]
+other_configs.rt1250_host_e2e       test_host_path_at_the_target_shape                 (1250 channels x 1 s from host memory to SondeData fragments)
 
 What a frame stream must equal: /root/reference/src/decode/decoder.hpp:61 (one X_decode call sequence per channel); the oracle
 (oracle/, the CPU restatement) stands for it."""
@@ -139,3 +140,32 @@ def test_part_filled_last_generation(oracle, C, tiles, flags):
         rs, gs = ch.state(), b.state(c)
         assert (gs["t_next"], gs["period"], gs["bias"], gs["amp"]) == (rs["t_next"], rs["period"], rs["bias"], rs["amp"]), c
         assert b.nbits(c) == len(ch.bits())
+
+
+def test_host_path_at_the_target_shape(oracle):
+    """bench.py's rt1250_host_e2e: 1250 RS41 channels, one second at a time, HOST memory in (sonde_batch_submit_host: PCIe + staging
+    into strided rows), SondeData fragments out (sonde_batch_poll).  Frames of every submit equal the oracle's; every FEC-clean frame
+    yields its sequence fragment with the right channel and serial; nothing is lost between submits."""
+    from sdrpp_radiosonde_amd import _lib
+    C, n, NS = 1250, 24 * TILE, 3
+    sb = synth.make_rs41_batch(C, NS * n, seed=4242, ebn0_db=15.0, device="cuda:0")
+    host = sb.iq.cpu().numpy()
+    b = SondeBatch(C, n)
+    frames, frags = [], []
+    for k in range(NS):
+        b.submit_host(np.ascontiguousarray(host[:, k * n: (k + 1) * n]))
+        frames.append(b.frames())
+        frags += b.poll(cap=4096)
+    got = _key(np.concatenate(frames))
+    ref = oracle.batch_run(0, host, nthreads=CORES)
+    assert len(ref) >= C and got.tobytes() == ref.tobytes()
+    seqs = {}
+    for c, d in frags:
+        if d.fields & _lib.DATA_SEQ:
+            assert d.serial == ("S%07d" % c).encode()
+            seqs.setdefault(c, []).append(d.seq)
+    clean = got[(got["nerr"] >= 0).all(axis=1)]
+    for c in range(0, C, 53):
+        want = [int(f["data"][59]) | (int(f["data"][60]) << 8) for f in clean if f["channel"] == c]
+        assert seqs.get(c, []) == want, c
+    assert sum(len(v) for v in seqs.values()) == len(clean)
