@@ -24,15 +24,20 @@ for it in range(n):
     streams = int(rng.choice([1, 1, 2, 3, 8]))
     bps = int(rng.choice([1, 2, 5, 4]))
     nblk = 12 if bps == 4 else 10
+    dual = bool(rng.integers(0, 4) == 0) and streams <= 3           # a quarter of the scenes: both stackings (SPEC 3.5c)
+    offset = float(rng.choice([0.0, 9765.625, -3000.0])) if dual else 0.0
     ebn0 = float(rng.uniform(9.0, 30.0))
     seed = int(rng.integers(10, 10_000))
     active = sorted(int(x) for x in rng.choice(np.arange(2, 510), size=4, replace=False))
     m10 = [int(x) for x in rng.choice([b for b in range(2, 510) if b not in active], size=2, replace=False)]
-    scenes = [synth.make_wideband_rs41(active, nblk * tc.BLOCK, seed=seed + s, ebn0_db=ebn0, device="cuda:0")[0] for s in range(streams)]
-    types = np.zeros(512 * streams, dtype=np.uint8)
+    scenes = [synth.make_wideband_rs41(active, nblk * tc.BLOCK, seed=seed + s, ebn0_db=ebn0, device="cuda:0", offset_hz=offset)[0] for s in range(streams)]
+    per = 1024 if dual else 512
+    types = np.zeros(per * streams, dtype=np.uint8)
     for s_ in range(streams):
-        types[[512 * s_ + k for k in m10]] = 1          # silent bins of another sonde type (DFM)
-    chz = SondeChannelizer(types=types, blocks_per_submit=bps, n_streams=streams)
+        types[[per * s_ + k for k in m10]] = 1          # silent bins of another sonde type (DFM)
+        if dual:
+            types[[per * s_ + 512 + k for k in m10]] = 1
+    chz = SondeChannelizer(types=types, blocks_per_submit=bps, n_streams=streams, dual=dual)
     assert chz.fused
     got = []
     for b in range(nblk // bps):
@@ -43,13 +48,14 @@ for it in range(n):
     key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
     refs, nbits = [], 0
     for s_, sc in enumerate(scenes):
-        dec, _ = tc._oracle_decode_wideband(oracle, sc.cpu().numpy(), active + m10, types=types[:512], composite=True)
+      for odd in ((False, True) if dual else (False,)):
+        dec, _ = tc._oracle_decode_wideband(oracle, sc.cpu().numpy(), active + m10, types=types[:512], composite=True, odd=odd)
         for k in active + m10:
             r = dec[k].frames().copy()
-            r["channel"] = 512 * s_ + k
+            r["channel"] = per * s_ + (512 if odd else 0) + k
             refs.append(r)
             rb = dec[k].bits()
-            c = 512 * s_ + k
+            c = per * s_ + (512 if odd else 0) + k
             assert chz.batch.nbits(c) == len(rb), (it, s_, k)
             tail = min(len(rb), 4000)
             assert np.array_equal(chz.batch.read_bits(c, len(rb) - tail, tail), rb[-tail:]), (it, s_, k)
@@ -57,8 +63,10 @@ for it in range(n):
             assert (st["t_next"], st["period"]) == (rs["t_next"], rs["period"]), (it, s_, k)
             nbits += tail
     ref = np.concatenate(refs)
-    assert key(got).tobytes() == key(ref).tobytes(), it
+    watched = sorted(set(ref["channel"].tolist())) if len(ref) else []
+    sel = got[np.isin(got["channel"], [per * s_ + o + k for s_ in range(streams) for o in ((0, 512) if dual else (0,)) for k in active + m10])]
+    assert key(sel).tobytes() == key(ref).tobytes(), it
     chz.close()
-    print(f"[{it + 1}/{n}] seed {seed} Eb/N0 {ebn0:5.1f} dB streams {streams} blocks/submit {bps} bins {active} + DFM {m10}: "
+    print(f"[{it + 1}/{n}] seed {seed} Eb/N0 {ebn0:5.1f} dB streams {streams} blocks/submit {bps} dual {int(dual)} offset {offset:.0f} Hz bins {active} + DFM {m10}: "
           f"{len(ref)} frames, {nbits} ring bits, loop state of {len(active + m10) * streams} bins identical to the oracle", flush=True)
 print(f"wideband campaign done in {time.time() - t0:.0f} s")
