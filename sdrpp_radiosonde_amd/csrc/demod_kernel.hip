@@ -471,7 +471,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			float y = 0.0f, m = 0.0f;
 			if (act) {
 				const int64_t base = (n0 - IT - SD_LH) << 16;
-				const uint32_t rel = (uint32_t)(t_next - base) + (uint32_t)k * (uint32_t)period;
+				const uint32_t rel = (uint32_t)(t_next - base) + __umul24((unsigned)k, (unsigned)period);      // (k < 2^10, period < 2^20: one full-rate v_mad_u32_u24, not a quarter-rate v_mul_lo_u32)
 				y = interp<NT>(s.A[b], s.taps, rel);          // 3.2 symbols of taps (8 at 2.5 samples per symbol)
 				// only the first 256 symbols of a round feed the timing detector (SPEC 3.2): the second symbol of a lane needs no
 				// mid-symbol FIR -- a quarter of the FIR work of the two-symbols-per-lane classes (M10: 117.7 M -> 108.5 M VALU instructions, 297 -> 277 us)
