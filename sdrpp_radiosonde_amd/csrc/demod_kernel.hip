@@ -145,7 +145,11 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 template <int IN, bool LIST, int DEC, int NT>
 // (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU.  Round 3's SD_IN_BINS form -- complex 40 kS/s bins, the
 // discriminator in here -- needed 80 VGPRs; the round-4 form, phases in, fits: 4096 bins x 3 tiles 57.7 -> 50.3 us, r4_notes.md)
+#ifdef SD_SETS3
+__global__ __launch_bounds__(SD_WGT, 6) void sd_demod_kernel(
+#else
 __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
+#endif
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
@@ -169,6 +173,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
 	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)row * ch_stride);
 	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
+#ifdef SD_SETS3                            // experiment (tools/ab): a third set, 80 VGPRs, three workgroups per CU
+	float4 vc[NLD];
+#endif
 	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
 	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
 	// of the same wave at r - 1 (no extra load); only each wave's very first sample needs the float4 before it.
@@ -499,35 +506,45 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		S0i = wave_sum(S0i);
 		if (lane == 0) s.red[par][rwave] = make_int4(Ei, S1i, S0i, C1);
 	};
-	// lead wave, after the barrier: append the round's bits, update slicer levels and the PI loop filter
-	auto round_back = [&](int K, int par) {
+	// round wave 1, after the barrier: append the previous round's bits to the bit ring (HBM) and its LDS mirror, beside the lead wave's
+	// loop filter (round 4: it was the first quarter of the lead wave's chain) and tell K4 how far the mirror is valid
+	uint64_t wpos_w = st.wpos;
+	auto ring_append = [&](int K, int par) {
 		if (K <= 0) {                      // nothing appended: carry the partial word to the next slot
-			if (t == 0) s.partial[par ^ 1] = s.partial[par];
+			if (lane == 0) s.partial[par ^ 1] = s.partial[par];
 			return;
 		}
+		if (lane < 8 * SPL + 1) {
+			const uint32_t sh = (uint32_t)wpos_w & 31u;
+			const uint32_t w0 = (uint32_t)(wpos_w >> 5);
+			uint32_t vv = 0;
+			const bool touched = (uint32_t)(32 * lane) < sh + (uint32_t)K;
+			if (touched) {
+				const uint32_t lo = s.chunk[par][lane + 1];
+				const uint32_t pvw = s.chunk[par][lane];
+				vv = sh ? ((lo << sh) | (pvw >> (32u - sh))) : lo;
+				const uint32_t idx = (w0 + lane) & ring_mask;
+				if (lane == 0 && sh) vv |= s.partial[par] & ((1u << sh) - 1u);
+				ring_g[idx] = vv;
+				s.mirror[idx & (SD_MIRROR_WORDS - 1)] = vv;
+			}
+			// whoever owns the word the next round starts in publishes it (read after a barrier)
+			if ((uint32_t)lane == ((sh + (uint32_t)K) >> 5)) s.partial[par ^ 1] = vv;
+		}
+		wpos_w += (uint64_t)K;
+		// every bit below it is in the ring and in the mirror (this wave's LDS stores execute in order; K4 reads it whenever it looks:
+		// how far the search has come by a given round may vary, what it finds does not)
+		if (lane == 0) __hip_atomic_store(&s.pub.wpos, (unsigned long long)wpos_w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+	// lead wave, after the barrier: update slicer levels and the PI loop filter
+	auto round_back = [&](int K, int par) {
+		if (K <= 0) return;
 		const int4 r0 = s.red[par][0], r1 = s.red[par][1], r2 = s.red[par][2], r3 = s.red[par][3];
 		const int E = r0.x + r1.x + r2.x + r3.x;
 		const int S1 = r0.y + r1.y + r2.y + r3.y;
 		const int S0 = r0.z + r1.z + r2.z + r3.z;
 		const int C1 = r0.w + r1.w + r2.w + r3.w;
 		const int C0 = K - C1;
-		if (t < 8 * SPL + 1) {
-			const uint32_t sh = (uint32_t)st.wpos & 31u;
-			const uint32_t w0 = (uint32_t)(st.wpos >> 5);
-			uint32_t vv = 0;
-			const bool touched = (uint32_t)(32 * t) < sh + (uint32_t)K;
-			if (touched) {
-				const uint32_t lo = s.chunk[par][t + 1];
-				const uint32_t pvw = s.chunk[par][t];
-				vv = sh ? ((lo << sh) | (pvw >> (32u - sh))) : lo;
-				const uint32_t idx = (w0 + t) & ring_mask;
-				if (t == 0 && sh) vv |= s.partial[par] & ((1u << sh) - 1u);
-				ring_g[idx] = vv;
-				s.mirror[idx & (SD_MIRROR_WORDS - 1)] = vv;
-			}
-			// whoever owns the word the next round starts in publishes it (read after a barrier)
-			if ((uint32_t)t == ((sh + (uint32_t)K) >> 5)) s.partial[par ^ 1] = vv;
-		}
 		if (C1 > 0 && C0 > 0) {
 			const f32x2 cnt = {(float)C1, (float)C0};
 			const f32x2 rc = sd_recip2(cnt);
@@ -609,6 +626,30 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			load_prev(0, pa, qa);          // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
 			if (n_tiles > 1) load_prev(1, pb, qb);
 		}
+#ifdef SD_SETS3
+		if constexpr (!BINS) {
+			float4 pc, qc;
+			qc = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
+			auto k1C = [&](int b, int tile) { k1_tile(b, tile, vc, pc, qc); };
+			auto ldC = [&](int tile) { load_tile(tile, vc, pc, qc); };
+			if (n_tiles > 2) ldC(2);
+			k1A(0, 0);
+			if (n_tiles > 3) ldA(3);
+			__syncthreads();
+			auto roll = [&](int b) { if (t < SD_LH) s.A[b][t] = s.A[b ^ 1][IT + t]; };
+			for (int q = 0; q < n_tiles; q += 3) {
+				if (q + 1 < n_tiles) { roll((q + 1) & 1); k1B((q + 1) & 1, q + 1); if (q + 4 < n_tiles) ldB(q + 4); }
+				for (int r = 0; r < rounds; r++) __syncthreads();
+				if (q + 1 >= n_tiles) break;
+				if (q + 2 < n_tiles) { roll((q + 2) & 1); k1C((q + 2) & 1, q + 2); if (q + 5 < n_tiles) ldC(q + 5); }
+				for (int r = 0; r < rounds; r++) __syncthreads();
+				if (q + 2 >= n_tiles) break;
+				if (q + 3 < n_tiles) { roll((q + 3) & 1); k1A((q + 3) & 1, q + 3); if (q + 6 < n_tiles) ldA(q + 6); }
+				for (int r = 0; r < rounds; r++) __syncthreads();
+			}
+		} else
+#endif
+		{
 		k1A(0, 0);
 		if (n_tiles > 2) ldA(2);
 		__syncthreads();
@@ -628,6 +669,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				if (tile + 4 < n_tiles) ldA(tile + 4);
 			}
 			for (int r = 0; r < rounds; r++) __syncthreads();
+		}
 		}
 		if (IS_IQ && t == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
 		__syncthreads();                                   // (E)
@@ -662,12 +704,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 					t_next = st.t_next; period = st.period; bias = st.bias;
 					if (lane == 0) {
 						s.pub.t_next = t_next; s.pub.period = period; s.pub.bias = bias; s.pub.K = K;
-						s.pub.wpos = st.wpos;                             // every bit below it is in the ring and in the mirror
 						__hip_atomic_store(&s.pub.flag, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				} else {
 					// K4 instead of spinning while the lead wave runs the loop filter: the search works on the bits the
 					// PREVIOUS publish announced (one round behind; the epilogue catches up)
+					if (rwave == 1 && pendK >= 0) ring_append(pendK, par ^ 1);      // the previous round's bits
 					if (k4) k4_run(sd_uniform64(s.k4.wp_seen));
 					// the in-loop decoder of clean RS41 frames: one step per round on round wave 2, which would otherwise only wait
 					// for the lead wave's loop filter (a real call: sd_rsdec.h says why)
@@ -676,7 +718,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 					while (__hip_atomic_load(&s.pub.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1u)
 						__builtin_amdgcn_s_sleep(2);
 					t_next = s.pub.t_next; period = s.pub.period; bias = s.pub.bias; K = s.pub.K;
-					if (k4 && lane == 0) s.k4.wp_seen = s.pub.wpos;
+					if (k4 && lane == 0) s.k4.wp_seen = __hip_atomic_load(&s.pub.wpos, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 				round_front(K, b, par);
 				pendK = K;
@@ -689,7 +731,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			round_back(pendK, (int)((seq & 1u) ^ 1u));
 			if (IS_IQ) afc_step(n_tiles - 1);
 		}
-		if (lead && lane == 0) s.pub.wpos = st.wpos;
+		if (rwave == 1 && pendK >= 0) ring_append(pendK, (int)((seq & 1u) ^ 1u));
 		__syncthreads();                                   // (E) matched by the discriminator role's last barrier
 		if (k4) k4_finish();      // ... and K4's catch-up over the last rounds' bits
 	}
