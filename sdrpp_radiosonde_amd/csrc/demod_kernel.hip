@@ -145,11 +145,7 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 template <int IN, bool LIST, int DEC, int NT>
 // (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU.  Round 3's SD_IN_BINS form -- complex 40 kS/s bins, the
 // discriminator in here -- needed 80 VGPRs; the round-4 form, phases in, fits: 4096 bins x 3 tiles 57.7 -> 50.3 us, r4_notes.md)
-#ifdef SD_SETS3
-__global__ __launch_bounds__(SD_WGT, 6) void sd_demod_kernel(
-#else
 __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
-#endif
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
@@ -173,9 +169,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
 	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)row * ch_stride);
 	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
-#ifdef SD_SETS3                            // experiment (tools/ab): a third set, 80 VGPRs, three workgroups per CU
-	float4 vc[NLD];
-#endif
 	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
 	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
 	// of the same wave at r - 1 (no extra load); only each wave's very first sample needs the float4 before it.
@@ -626,30 +619,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			load_prev(0, pa, qa);          // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
 			if (n_tiles > 1) load_prev(1, pb, qb);
 		}
-#ifdef SD_SETS3
-		if constexpr (!BINS) {
-			float4 pc, qc;
-			qc = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
-			auto k1C = [&](int b, int tile) { k1_tile(b, tile, vc, pc, qc); };
-			auto ldC = [&](int tile) { load_tile(tile, vc, pc, qc); };
-			if (n_tiles > 2) ldC(2);
-			k1A(0, 0);
-			if (n_tiles > 3) ldA(3);
-			__syncthreads();
-			auto roll = [&](int b) { if (t < SD_LH) s.A[b][t] = s.A[b ^ 1][IT + t]; };
-			for (int q = 0; q < n_tiles; q += 3) {
-				if (q + 1 < n_tiles) { roll((q + 1) & 1); k1B((q + 1) & 1, q + 1); if (q + 4 < n_tiles) ldB(q + 4); }
-				for (int r = 0; r < rounds; r++) __syncthreads();
-				if (q + 1 >= n_tiles) break;
-				if (q + 2 < n_tiles) { roll((q + 2) & 1); k1C((q + 2) & 1, q + 2); if (q + 5 < n_tiles) ldC(q + 5); }
-				for (int r = 0; r < rounds; r++) __syncthreads();
-				if (q + 2 >= n_tiles) break;
-				if (q + 3 < n_tiles) { roll((q + 3) & 1); k1A((q + 3) & 1, q + 3); if (q + 6 < n_tiles) ldA(q + 6); }
-				for (int r = 0; r < rounds; r++) __syncthreads();
-			}
-		} else
-#endif
-		{
 		k1A(0, 0);
 		if (n_tiles > 2) ldA(2);
 		__syncthreads();
@@ -669,7 +638,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				if (tile + 4 < n_tiles) ldA(tile + 4);
 			}
 			for (int r = 0; r < rounds; r++) __syncthreads();
-		}
 		}
 		if (IS_IQ && t == SD_WG - 1) { s.iq_last[0] = last_iq.x; s.iq_last[1] = last_iq.y; }
 		__syncthreads();                                   // (E)
