@@ -373,8 +373,8 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     a = copy.copy(args)
     # (their own step counts, stated in the record: the pipelined class streams need a few steps to fill and one to drain,
     # which a 20-step region would charge at 3-5 %)
-    a.steps = steps or max(60, min(args.steps, 100))
-    a.warmup = warmup or max(10, min(args.warmup, 20))
+    a.steps = steps or (100 if flags & FLAG_PIPELINE else max(60, min(args.steps, 100)))
+    a.warmup = warmup or (20 if flags & FLAG_PIPELINE else max(10, min(args.warmup, 20)))
     a.ramp_ms = min(args.ramp_ms, 100.0)
     blocks, types = make_blocks(kind, C, tiles, NB, args.ebn0 if ebn0 is None else ebn0, dev, seed=1000)
     blocks = restride(blocks, args)
