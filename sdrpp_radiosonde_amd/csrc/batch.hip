@@ -156,6 +156,7 @@ struct SondeBatch {
 	// workgroups end with the FEC epilogue): with n_chunks > 1 every compute unit holds a mix of heavy (M10: VALU / LDS bound)
 	// and light (HBM bound) workgroups at any time instead of a generation of M10 followed by generations of the others.
 	uint32_t n_cls[4] = {};
+	int cls_type[4] = { -1, -1, -1, -1 };  // the sonde type of a class whose channels are all of one type, else -1 (sd_launch_demod's utype)
 	int n_classes = 0, only_class = 0;
 	// Joined batches (the default: every submit ends in the caller's stream) launch per CLASS instead (type = -1: the types
 	// of a class share one launch over the class's channel list, their frame decoders follow): measured 0.319 ms per step
@@ -295,6 +296,10 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	for (int k = 0; k < 4; k++) {
 		b->n_cls[k] = (uint32_t)cls[k].size();
 		if (b->n_cls[k]) { b->n_classes++; b->only_class = k; }
+		for (uint32_t c : cls[k]) {
+			if (c == cls[k][0]) b->cls_type[k] = b->types[c];
+			else if (b->types[c] != b->cls_type[k]) { b->cls_type[k] = -1; break; }
+		}
 	}
 	// Round 4: a ONE-class batch created with SONDE_FLAG_PIPELINE is cut into TWO launch units (halves of the channel list, each
 	// with its own stream from submit to submit).  A workgroup lives for its channel's whole submit, so a launch whose
@@ -579,7 +584,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	const bool one_launch = b->units.empty();
 	if (one_launch) {
 		sd_launch_demod(iq, k_cls_decim[b->only_class], k_cls_nt[b->only_class], b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
-			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, bins_in);
+			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, bins_in, b->cls_type[b->only_class]);
 		HIPCHK(hipGetLastError());
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
 		for (int t = 0; t < SONDE_NTYPES; t++) if (launch_framers(t, stream)) return -1;
@@ -601,11 +606,11 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 				sd_launch_afsk(u.type, iq == SD_IN_IQ, u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_chlist[u.type], b->d_astates, u.type == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
 				sd_launch_demod(SD_IN_REAL, 1, 16, u.n, u.st, rows, nq, (int)(nq / SONDE_TILE),
-					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo);
+					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo, nullptr, u.type);
 			} else {
 				sd_launch_demod(iq, k_cls_decim[u.cls], k_cls_nt[u.cls], u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems,
-					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo, bins_in);
+					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo, bins_in, u.type < 0 ? b->cls_type[u.cls] : u.type);
 			}
 			HIPCHK(hipGetLastError());
 			if (timed) HIPCHK(hipEventRecord(ec[1], u.st));

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
-	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, const SdBinsIn *__restrict__ bins_in)
+	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, const SdBinsIn *__restrict__ bins_in, int utype)
 {
 	constexpr bool IS_IQ = IN == SD_IN_IQ, BINS = IN == SD_IN_BINS;
 	__shared__ __attribute__((aligned(16))) DemodLds s;
@@ -210,7 +210,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	}
 
 	SdChanState st = states[ch];
-	const SdModem md = modems[st.type];
+	// utype >= 0: every channel of this launch is of that sonde type (the host knows: one-type batches, per-type launch units), so
+	// the taps and modem parameters do not have to wait for the state
+	int stype;
+	if (utype >= 0) stype = utype;
+	else stype = __builtin_amdgcn_readfirstlane(st.type);
+	const SdModem md = modems[stype];
 	const int rounds = md.rounds;          // sub-phases (= barriers) per tile: 1, or 2 for the SRS-C50 6 kS/s stream
 	constexpr int IT = SD_TILE / DEC;      // internal samples per input tile (= md.itile)
 	constexpr bool dec2 = DEC == 2, dec4 = DEC == 4;
@@ -221,22 +226,49 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// in ~4 us instead of ~7 (profiles/r3_notes.md).
 	uint32_t *ring_g = bitring + (size_t)ch * ring_words;
 	const uint32_t ring_mask = ring_words - 1;
+	// Round 4, the (4:1, 8 taps) class: the history and the ring words are requested TOGETHER with the taps (one HBM round trip less at
+	// the head of every workgroup; the loads the history / open ring word / mirror used to wait for one after the other).  The other
+	// classes have no registers to spare while the tile loads are in flight (their first tile's loads spill) and keep the old order.
+	constexpr bool JOIN = DEC == 4 && NT == 8;
 	if (!is_k) {
-		const float4 *taps_g = reinterpret_cast<const float4 *>(taps_all + (size_t)st.type * SD_NPHASE * SD_NTAPS);
+		const float4 *taps_g = reinterpret_cast<const float4 *>(taps_all + (size_t)stype * SD_NPHASE * SD_NTAPS);
 		const float4 tv = taps_g[tid];                                   // 32 rows x 8 float4: one 16-byte load per lane
-		// pair-swapped rows (T[2i] = H[2i+1], T[2i+1] = H[2i]), see interp()
-		*reinterpret_cast<float4 *>(&s.taps[(tid >> 3) * SD_TAPS_LD + 4 * (tid & 7)]) = make_float4(tv.y, tv.x, tv.w, tv.z);
-		// restore the carried history in front of the first tile (both copies)
-		if (tid < SD_LH) {
-			const float hv = hist[(size_t)ch * SD_HIST + tid];
-			s.A[0][tid] = hv;
-		}
-		if (tid == 0) {
-			s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
-			s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
-			s.pub.flag = 0;
-			s.pub.wpos = st.wpos;
-			s.afc_u[0] = st.afc[0]; s.afc_u[1] = st.afc[1]; s.afc_u[2] = st.afc[2];
+		if constexpr (JOIN) {
+			// the carried history (stored by wave 0) and the bit ring's newest words, the ones up to and including wpos's (lane 63's), for
+			// K4's mirror and the open word (stored by wave 3) -- requested together with the taps, not after the taps have arrived, and
+			// by every round wave: unconditional loads (256 bytes each, L2 hits for three of the four waves) keep the three requests of a
+			// wave back to back; predicated ones made the compiler wait for the taps before the next request (register reuse)
+			const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(63 - lane);
+			const float hv = hist[(size_t)ch * SD_HIST + lane];
+			const uint32_t xw = ring_g[w & ring_mask];
+			asm volatile("" :: "v"(hv), "v"(xw));      // (a use right here: without it the compiler sinks each load into the branch that stores it)
+			// pair-swapped rows (T[2i] = H[2i+1], T[2i+1] = H[2i]), see interp()
+			*reinterpret_cast<float4 *>(&s.taps[(tid >> 3) * SD_TAPS_LD + 4 * (tid & 7)]) = make_float4(tv.y, tv.x, tv.w, tv.z);
+			if (rwave == 0) s.A[0][lane] = hv;                               // in front of the first tile
+			if (rwave == 3) {
+				s.mirror[w & (SD_MIRROR_WORDS - 1)] = xw;
+				if (lane == 63) {
+					s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
+					s.partial[0] = ((uint32_t)st.wpos & 31u) ? xw : 0u;
+					s.pub.flag = 0;
+					s.pub.wpos = st.wpos;
+					s.afc_u[0] = st.afc[0]; s.afc_u[1] = st.afc[1]; s.afc_u[2] = st.afc[2];
+				}
+			}
+		} else {
+			*reinterpret_cast<float4 *>(&s.taps[(tid >> 3) * SD_TAPS_LD + 4 * (tid & 7)]) = make_float4(tv.y, tv.x, tv.w, tv.z);
+			// restore the carried history in front of the first tile
+			if (tid < SD_LH) {
+				const float hv = hist[(size_t)ch * SD_HIST + tid];
+				s.A[0][tid] = hv;
+			}
+			if (tid == 0) {
+				s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
+				s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
+				s.pub.flag = 0;
+				s.pub.wpos = st.wpos;
+				s.afc_u[0] = st.afc[0]; s.afc_u[1] = st.afc[1]; s.afc_u[2] = st.afc[2];
+			}
 		}
 	}
 	// K4: the sync search of the framed sondes runs in here, on round wave 3, over an LDS mirror of the newest ring words
@@ -245,13 +277,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// RS41, DFM, iMS-100, MRZ-N1; (2, 8) and, wide, (1, 16) -> M10 (and the AFSK 6 kS/s streams, which are framed elsewhere).
 	// Testing the class first lets the compiler drop the other types' code from each instantiation.
 	constexpr bool cls_slow = DEC == 4 || (DEC == 2 && NT == 16);     // the ~5000 chips/s sondes
-	const int stype = __builtin_amdgcn_readfirstlane(st.type);
 	const bool is_rs41 = cls_slow && stype == SONDE_RS41, is_dfm = cls_slow && stype == SONDE_DFM09,
 	           is_ims = cls_slow && stype == SONDE_IMS100, is_m10 = !cls_slow && stype == SONDE_M10,
 	           is_mrz = cls_slow && stype == SONDE_MRZN1;
 	const bool fuse = fo->fuse_fec != 0;
 	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10 || is_mrz));   // workgroup-uniform
-	if (framing && !is_k && tid >= SD_WG - SD_MIRROR_WORDS) {                               // round wave 3, the wave that runs K4
+	if (!JOIN && framing && !is_k && tid >= SD_WG - SD_MIRROR_WORDS) {                      // round wave 3, the wave that runs K4
 		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WG - 1 - tid);       // the words up to and including wpos's
 		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
 	}
@@ -752,11 +783,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */, const SdBinsIn *bins_in /* device memory; SD_IN_BINS only */)
+	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */, const SdBinsIn *bins_in /* device memory; SD_IN_BINS only */,
+	int utype)
 {
 	const dim3 g(n_channels), blk(SD_WGT);
 	const int ci = compact_in ? 1 : 0;
-#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo, bins_in
+#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo, bins_in, utype
 #define SD_DEMOD_LAUNCH(KIND, LS) do { \
 		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else if (decim == 2 && nt == 8) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \

@@ -24,7 +24,8 @@ void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStr
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */,
-	const SdBinsIn *bins_in = nullptr);
+	const SdBinsIn *bins_in /* SD_IN_BINS only, else null */,
+	int utype /* >= 0: every channel of the launch is of this sonde type (taps / modem loads need not wait for the state); -1: per channel */);
 // the batch object behind a channelizer takes its input as bins (channelizer.hip): 3 tiles per 5120 bin samples
 int sd_batch_submit_bins(SondeBatch *b, const void *bins, size_t n_steps, size_t channel_stride, const SdBinsIn *d_bins_in, void *stream);
 int sd_batch_bins_capable(const SondeBatch *b);      // 1: every channel's class has a bins instantiation (no AFSK sonde, no class without one)
