@@ -88,7 +88,12 @@ SONDE_B1_DECL(MRZN1Decoder,  mrzn1)   /* main.hpp:42 */
 enum { SONDE_RS41 = 0, SONDE_DFM09 = 1, SONDE_IMS100 = 2, SONDE_M10 = 3, SONDE_IMET4 = 4, SONDE_C50 = 5, SONDE_MRZN1 = 6, SONDE_NTYPES = 7 };
 
 enum { SONDE_INPUT_IQ = 0,      /* complex64 interleaved I,Q at 48 kS/s (vfo->output level, main.cpp:57) */
-       SONDE_INPUT_REAL = 1 };  /* float FM-discriminator output at 48 kS/s (decoder.hpp:35 level) */
+       SONDE_INPUT_REAL = 1,    /* float FM-discriminator output at 48 kS/s (decoder.hpp:35 level) */
+       SONDE_INPUT_IQ16 = 2 };  /* the vfo->output level as 16-bit integers: int16 I, int16 Q interleaved at 48 kS/s, 4 bytes per sample --
+                                 * what SDR hardware and WAV recordings hold before SDR++'s sources convert to float.  Converted in the
+                                 * kernel's load path (exactly; no scaling: the discriminator does not depend on the amplitude), so the
+                                 * frames are those of SONDE_INPUT_IQ fed with the same integers as floats, for half the bytes over PCIe,
+                                 * xGMI and HBM.  Batch / node API only; not for the tone-demodulated sondes (iMet-4, SRS-C50). */
 
 #define SONDE_TILE       2048   /* samples; submit lengths are multiples of this */
 #define SONDE_FRAME_MAX  528
@@ -107,7 +112,7 @@ typedef struct {
 	uint32_t       n_channels;
 	const uint8_t *types;            /* n_channels entries of SONDE_*; NULL = all SONDE_RS41 */
 	uint32_t       max_samples;      /* largest samples-per-channel of one submit (multiple of SONDE_TILE) */
-	int32_t        input_kind;       /* SONDE_INPUT_IQ or SONDE_INPUT_REAL */
+	int32_t        input_kind;       /* SONDE_INPUT_IQ, SONDE_INPUT_REAL or SONDE_INPUT_IQ16 */
 	int32_t        device;           /* HIP device ordinal */
 	uint32_t       flags;            /* SONDE_FLAG_*; 0 = defaults */
 } SondeBatchConfig;
@@ -150,6 +155,8 @@ void sonde_batch_destroy(SondeBatch *b);
  * its own staging buffer: the next power of two in bytes where that costs at most a third more memory (1.5 MiB rows -> 2 MiB),
  * else the next odd multiple of 64 KiB (rows of 1.01 MiB -> 1.0625 MiB, not 2 MiB); rows below 64 KiB stay back to back. */
 size_t sonde_row_stride(size_t n_samples, int input_kind);
+/* bytes per sample (element) of an input kind: 8 (IQ), 4 (REAL, IQ16) */
+size_t sonde_sample_bytes(int input_kind);
 int  sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream);
 /* Same, from HOST memory (staged through an internal pinned/device buffer; PCIe-inclusive). */
 int  sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SONDE_MI355_LIB") or os.path.join(PKG_DIR, "libsonde_
 TILE = 2048
 FRAME_MAX = 528
 (RS41, DFM09, IMS100, M10, IMET4, C50, MRZN1) = range(7)
-INPUT_IQ, INPUT_REAL = 0, 1
+INPUT_IQ, INPUT_REAL, INPUT_IQ16 = 0, 1, 2
 PROCEED, PARSED = 0, 1
 DATA_SEQ, DATA_POS, DATA_SPEED, DATA_TIME, DATA_PTU, DATA_SERIAL, DATA_SHUTDOWN, DATA_OZONE = (1 << i for i in range(8))
 
@@ -53,7 +53,7 @@ FLAG_PIPELINE = 4        # mixed batches: class streams are not joined into the 
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them
 ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
-    "sonde_row_stride", "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_class_ms", "sonde_batch_read_bits",
+    "sonde_row_stride", "sonde_sample_bytes", "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_class_ms", "sonde_batch_read_bits",
     "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_test_rs255", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
     "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp", "sonde_rs41_pressure", "sonde_ozone_mpa",
     "sonde_m10_temp", "sonde_m10_rh", "sonde_m20_temp", "sonde_ims100_temp",
@@ -153,6 +153,8 @@ def load() -> C.CDLL:
     L.sonde_chan_set_overlap.argtypes = [vp, C.c_int]
     L.sonde_row_stride.argtypes = [C.c_size_t, C.c_int]
     L.sonde_row_stride.restype = C.c_size_t
+    L.sonde_sample_bytes.argtypes = [C.c_int]
+    L.sonde_sample_bytes.restype = C.c_size_t
     L.sonde_chan_streams.argtypes = [vp]
     L.sonde_chan_streams.restype = C.c_uint32
     L.sonde_chan_destroy.argtypes = [vp]

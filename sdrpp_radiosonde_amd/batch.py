@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FRAME_DTYPE, INPUT_IQ, INPUT_REAL, TILE
+from ._lib import FRAME_DTYPE, INPUT_IQ, INPUT_IQ16, INPUT_REAL, TILE
 
 
 class SondeError(RuntimeError):
@@ -60,28 +60,30 @@ class SondeBatch:
         n = shape[1]
         if shape[0] != self.n_channels:
             raise SondeError("first dimension must be n_channels")
-        if self.input_kind == INPUT_IQ and (len(shape) != 3 or shape[2] != 2):
-            raise SondeError("IQ input must be [C, n, 2] float32")
-        if self.input_kind != INPUT_IQ and len(shape) != 2:
+        is_iq = self.input_kind in (INPUT_IQ, INPUT_IQ16)
+        if is_iq and (len(shape) != 3 or shape[2] != 2):
+            raise SondeError("IQ input must be [C, n, 2] (float32, or int16 for INPUT_IQ16)")
+        if not is_iq and len(shape) != 2:
             raise SondeError("real input must be [C, n] float32")
         # the C side sees only a pointer: check what it cannot (dtype, device, inner layout)
         dt = str(getattr(samples, "dtype", ""))
-        if not dt.endswith("float32"):
-            raise SondeError(f"samples must be float32, got {dt}")
+        want = "int16" if self.input_kind == INPUT_IQ16 else "float32"
+        if not dt.endswith(want):
+            raise SondeError(f"samples must be {want}, got {dt}")
         dev = getattr(samples, "device", None)
         if dev is None or getattr(dev, "type", "") != "cuda":
             raise SondeError("samples must be a device (HIP) tensor; use submit_host() for host memory")
         if dev.index is not None and dev.index != self.device:
             raise SondeError(f"samples live on device {dev.index}, the batch on device {self.device}")
         st = tuple(samples.stride())
-        if (self.input_kind == INPUT_IQ and st[1:] != (2, 1)) or (self.input_kind != INPUT_IQ and st[1] != 1):
+        if (is_iq and st[1:] != (2, 1)) or (not is_iq and st[1] != 1):
             raise SondeError("samples must be contiguous inside a channel (only the channel stride may be padded)")
-        stride = samples.stride(0) // (2 if self.input_kind == INPUT_IQ else 1)
+        stride = samples.stride(0) // (2 if is_iq else 1)
         self._keep = samples   # keep the device buffer alive until sync
         self._chk(self.L.sonde_batch_submit(self.h, C.c_void_p(samples.data_ptr()), n, stride, C.c_void_p(stream or 0)))
 
     def submit_host(self, samples: np.ndarray):
-        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        samples = np.ascontiguousarray(samples, dtype=np.int16 if self.input_kind == INPUT_IQ16 else np.float32)
         n = samples.shape[1]
         self._chk(self.L.sonde_batch_submit_host(self.h, samples.ctypes.data_as(C.c_void_p), n, n))
 
@@ -157,10 +159,12 @@ class SondeBatch:
         return dict(t_next=t.value, period=p.value, bias=b.value, amp=a.value, yprev=y.value)
 
 
-def row_stride(n_samples: int, iq: bool = True) -> int:
+def row_stride(n_samples: int, iq: bool = True, kind: int | None = None) -> int:
     """Channel stride (in samples) the library recommends for rows of n_samples: the next power of two in bytes (HBM channel
-    spread of rows streamed side by side; include/sonde_abi.h sonde_row_stride)."""
-    return int(_lib.load().sonde_row_stride(int(n_samples), INPUT_IQ if iq else _lib.INPUT_REAL))
+    spread of rows streamed side by side; include/sonde_abi.h sonde_row_stride).  kind: an INPUT_* value (overrides iq)."""
+    if kind is None:
+        kind = INPUT_IQ if iq else INPUT_REAL
+    return int(_lib.load().sonde_row_stride(int(n_samples), kind))
 
 
 def strided_rows(x, stride: int | None = None):
@@ -168,7 +172,7 @@ def strided_rows(x, stride: int | None = None):
     view of the padded allocation: what submit() takes."""
     import torch
     n = x.shape[1]
-    st = stride or row_stride(n, iq=x.dim() == 3)
+    st = stride or row_stride(n, kind=(INPUT_IQ16 if x.dtype == torch.int16 else INPUT_IQ) if x.dim() == 3 else INPUT_REAL)
     if st == n:
         return x
     buf = torch.empty((x.shape[0], st) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)

@@ -224,7 +224,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	*out = nullptr;
 	if (cfg->n_channels == 0) return fail("sonde_batch_create: n_channels == 0");
 	if (cfg->max_samples == 0 || cfg->max_samples % SONDE_TILE) return fail("sonde_batch_create: max_samples must be a positive multiple of SONDE_TILE");
-	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL) return fail("sonde_batch_create: bad input_kind");
+	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL && cfg->input_kind != SONDE_INPUT_IQ16) return fail("sonde_batch_create: bad input_kind");
 	int ndev = 0;
 	HIPCHK(hipGetDeviceCount(&ndev));
 	if (cfg->device < 0 || cfg->device >= ndev) return fail("sonde_batch_create: no such HIP device");
@@ -236,7 +236,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	b->input_kind = cfg->input_kind;
 	b->device = cfg->device;
 	for (int t = 0; t < SONDE_NTYPES; t++) b->md[t] = k_modems[t];
-	if ((cfg->flags & SONDE_FLAG_WIDE) && cfg->input_kind == SONDE_INPUT_IQ)
+	if ((cfg->flags & SONDE_FLAG_WIDE) && cfg->input_kind != SONDE_INPUT_REAL)
 		for (int t = 0; t < SONDE_NTYPES; t++) if (b->md[t].pre == 1) b->md[t].decim /= 2;       // one decimation step less (SPEC 3.0)
 	const ModemDef *md = b->md;
 	b->types.assign(cfg->n_channels, SONDE_RS41);
@@ -286,6 +286,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size() + b->chlist[SONDE_C50].size();      // tone-demodulated sondes
+	if (n_afsk && cfg->input_kind == SONDE_INPUT_IQ16) { sonde_batch_destroy(b); return fail("sonde_batch_create: 16-bit IQ input does not serve the tone-demodulated sondes (iMet-4, SRS-C50)"); }
 	std::vector<uint32_t> cls[4];               // index: demod-kernel class (k_cls_decim, k_cls_nt)
 	for (uint32_t c = 0; c < b->n_channels; c++) {
 		if (b->types[c] == SONDE_IMET4 || b->types[c] == SONDE_C50) continue;
@@ -504,7 +505,7 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	if (channel_stride < n_samples) return fail("sonde_batch_submit: channel_stride < n_samples");
 	// the kernels read 16 bytes per lane: every channel row must start on a 16-byte boundary
 	if (((uintptr_t)samples & 15u) || channel_stride % (b->input_kind == SONDE_INPUT_IQ ? 2 : 4))
-		return fail("sonde_batch_submit: samples must be 16-byte aligned and channel_stride a multiple of 2 (IQ) / 4 (real) samples");
+		return fail("sonde_batch_submit: samples must be 16-byte aligned and channel_stride a multiple of 2 (IQ) / 4 (real, 16-bit IQ) samples");
 	return submit_impl(b, samples, n_samples, channel_stride, stream_, nullptr);
 }
 
@@ -544,7 +545,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	b->n_submits++;
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	if (timed) HIPCHK(hipEventRecord(ev[0], stream));
-	const int iq = bins_in ? SD_IN_BINS : (b->input_kind == SONDE_INPUT_IQ ? SD_IN_IQ : SD_IN_REAL);      // what the rows hold
+	const int iq = bins_in ? SD_IN_BINS : (b->input_kind == SONDE_INPUT_IQ ? SD_IN_IQ : (b->input_kind == SONDE_INPUT_IQ16 ? SD_IN_IQ16 : SD_IN_REAL));      // what the rows hold
 	const int slot = (int)(b->tickets & 1);
 	SondeFrame *const d_frames = b->d_frames2[slot];
 	uint32_t *const d_counts = b->d_counts2[slot];
@@ -649,9 +650,14 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 // Measured (profiles/r3_stride_sweep.txt, three boxes): 1024 rows of 1.5 MiB streamed side by side run 2.3-5.5 % faster 2 MiB
 // apart than back to back (rows 384 KiB -> 512 KiB: +0.8 %); strides a little off a power of two (2064 KiB) can be 7 % SLOWER
 // than the contiguous layout: how the rows that are in flight together spread over the HBM channels.
+extern "C" size_t sonde_sample_bytes(int input_kind)
+{
+	return input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : (input_kind == SONDE_INPUT_IQ16 ? 2 * sizeof(int16_t) : sizeof(float));
+}
+
 extern "C" size_t sonde_row_stride(size_t n_samples, int input_kind)
 {
-	const size_t elem = input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : sizeof(float);
+	const size_t elem = sonde_sample_bytes(input_kind);
 	const size_t bytes = n_samples * elem;
 	if (bytes < 64 * 1024) return n_samples;
 	size_t p = 64 * 1024;
@@ -670,7 +676,7 @@ extern "C" int sonde_batch_submit_host(SondeBatch *b, const void *samples, size_
 	if (!b || !samples) return fail("sonde_batch_submit_host: null argument");
 	if (n_samples == 0 || n_samples % b->granule || n_samples > b->max_samples) return fail("sonde_batch_submit_host: bad n_samples");
 	HIPCHK(hipSetDevice(b->device));
-	const size_t elem = b->input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : sizeof(float);
+	const size_t elem = sonde_sample_bytes(b->input_kind);
 	const size_t dstride = sonde_row_stride(n_samples, b->input_kind);            // rows on the recommended stride
 	const size_t need = (size_t)b->n_channels * sonde_row_stride(b->max_samples, b->input_kind) * elem;
 	if (b->stage_bytes < need) {

@@ -17,6 +17,7 @@
 // explicit __builtin_fmaf; each lane's FIR is a fixed-order fmaf chain; every cross-lane
 // reduction (timing error, slicer level statistics) is an integer sum, so lane order is irrelevant.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "sonde_dev.h"
 
 #include "sd_math.h"
@@ -26,6 +27,27 @@
 #include "launch.h"
 
 typedef float sd_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sd_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned sd_u32x4 __attribute__((ext_vector_type(4)));
+typedef short sd_i16x2 __attribute__((ext_vector_type(2)));
+// SD_IN_IQ16, 4:1 class: one 16-byte load = four complex samples = ONE decimated sample: I and Q sums in integers (exact, as the
+// float sums of the float path are: |sum| < 2^17), v_dot2c_i32_i16 against (1, 0) / (0, 1) extracts and adds in one instruction
+static __device__ __forceinline__ float2 sd_cs16_sum4(uint4 q)
+{
+	const sd_i16x2 lo = {1, 0}, hi = {0, 1};
+	int i = 0, j = 0;
+	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.x), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.x), hi, j, false);
+	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.y), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.y), hi, j, false);
+	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.z), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.z), hi, j, false);
+	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.w), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.w), hi, j, false);
+	return make_float2((float)i, (float)j);
+}
+// SD_IN_IQ16: two complex samples of 16-bit integers (I0 Q0 I1 Q1, little endian) -> the float4 the float path would have loaded
+// (int16 -> float is exact; no scaling: the discriminator's output does not depend on the amplitude)
+static __device__ __forceinline__ float4 sd_cs16_f4(uint2 q)
+{
+	return make_float4((float)(int16_t)(q.x & 0xffffu), (float)((int32_t)q.x >> 16), (float)(int16_t)(q.y & 0xffffu), (float)((int32_t)q.y >> 16));
+}
 
 // min(max(v, lo), hi) as ONE v_med3_f32 (equal for every non-NaN v; the fminf / fmaxf pair costs a canonicalising v_max_f32 more)
 __device__ __forceinline__ float sd_clamp(float v, float lo, float hi)
@@ -152,7 +174,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
 	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, const SdBinsIn *__restrict__ bins_in, int utype)
 {
-	constexpr bool IS_IQ = IN == SD_IN_IQ, BINS = IN == SD_IN_BINS;
+	constexpr bool IQ16 = IN == SD_IN_IQ16, IS_IQ = IN == SD_IN_IQ || IQ16, BINS = IN == SD_IN_BINS;
+	constexpr bool IQ16D4 = IQ16 && DEC == 4;                                 // 16-byte loads of four samples = one decimated sample each
+	// what one lane holds per load: two input samples (IQ; four in the 16-bit 4:1 class), four (real)
+	using LoadT = typename std::conditional<IQ16, typename std::conditional<IQ16D4, uint4, uint2>::type, float4>::type;
 	__shared__ __attribute__((aligned(16))) DemodLds s;
 
 	const int tid = threadIdx.x;
@@ -165,20 +190,29 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const uint32_t row = (LIST && compact_in) ? blockIdx.x : ch;       // row of `in`
 
 	// ---- discriminator waves: the first two tiles' loads go out before anything else (see the prologue note below)
-	constexpr int NLD = IS_IQ ? 4 : 2;     // float4 loads per thread per tile
-	constexpr int TILE_F4 = (IS_IQ ? 2 : 1) * SD_TILE / 4;
-	const float4 *src = reinterpret_cast<const float4 *>(in + (IS_IQ ? 2 : 1) * (size_t)row * ch_stride);
-	float4 va[NLD], vb[NLD];               // two register sets: tiles are prefetched two phases ahead
+	constexpr int NLD = (IS_IQ && !IQ16D4) ? 4 : 2;     // loads per thread per tile (float4; SD_IN_IQ16: 8 bytes, the same two samples, or 16 bytes, four)
+	constexpr int TILE_F4 = ((IS_IQ && !IQ16D4) ? 2 : 1) * SD_TILE / 4;      // load units (LoadT) per tile
+	// (ch_stride counts samples: 8 bytes each for complex64, 4 for real input and for 16-bit IQ)
+	const LoadT *src = reinterpret_cast<const LoadT *>(in + ((IS_IQ && !IQ16) ? 2 : 1) * (size_t)row * ch_stride);
+	LoadT va[NLD], vb[NLD];                // two register sets: tiles are prefetched two phases ahead
 	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
 	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
 	// of the same wave at r - 1 (no extra load); only each wave's very first sample needs the float4 before it.
 	const int kw = wave & 3;
 	auto f4_index = [&](int r) { return SD_WG / 4 * (NLD * kw + r) + lane; };      // float4 index inside the tile
-	auto load_vec = [&](int tile, float4 (&v)[NLD]) {
+	auto load_vec = [&](int tile, LoadT (&v)[NLD]) {
 #pragma unroll
 		for (int r = 0; r < NLD; r++) {                    // read-once data: streaming (nontemporal) loads
-			const sd_f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const sd_f32x4 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
-			v[r] = make_float4(q.x, q.y, q.z, q.w);
+			if constexpr (IQ16D4) {
+				const sd_u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const sd_u32x4 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
+				v[r] = make_uint4(q.x, q.y, q.z, q.w);
+			} else if constexpr (IQ16) {
+				const sd_u32x2 q = __builtin_nontemporal_load(reinterpret_cast<const sd_u32x2 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
+				v[r] = make_uint2(q.x, q.y);
+			} else {
+				const sd_f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const sd_f32x4 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
+				v[r] = make_float4(q.x, q.y, q.z, q.w);
+			}
 		}
 	};
 	// SD_IN_BINS (SPEC 3.5 / 3.5b, round 4): the rows hold one PHASE sample (quadrants) per 20 kS/s step of a channelizer bin.  Wave kw
@@ -312,11 +346,20 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	}
 
 	// ================================================================ discriminator role (waves 4-7)
-	float4 pa, pb, qa, qb;                 // the float4s (two input samples each) just before the wave's first one: -1 (pa, pb), -2 (qa, qb)
-	qa = qb = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
+	LoadT pa, pb, qa, qb;                  // the float4s (two input samples each) just before the wave's first one: -1 (pa, pb), -2 (qa, qb)
+	if constexpr (IQ16D4) { pa = pb = qa = qb = make_uint4(0u, 0u, 0u, 0u); }
+	else if constexpr (IQ16) { pa = pb = qa = qb = make_uint2(0u, 0u); }
+	else { qa = qb = make_float4(-0.0f, -0.0f, -0.0f, -0.0f); }
 	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);
-	auto load_prev = [&](int tile, float4 &pv, float4 &pw) {
-		if (IS_IQ) {
+	auto load_prev = [&](int tile, LoadT &pv, LoadT &pw) {
+		if constexpr (IQ16) {
+			// (16-bit input: the raw pairs; at the very start of the stream k1_tile takes the carried sample from the state itself)
+			const long f4 = (long)tile * TILE_F4 + SD_WG / 4 * NLD * kw;
+			if (f4 > 0) {
+				pv = src[f4 - 1];
+				if (dec4 && !IQ16D4) pw = src[f4 - 2];
+			}
+		} else if constexpr (IS_IQ) {
 			// the two float4s just before this wave's first one: wave-uniform addresses, so scalar loads (no VGPRs,
 			// not counted by vmcnt); at the very start of the stream they stand for the carried (decimated) sample.
 			// -0.0f is the additive identity for every float (+0 and -0 included), so k1_tile needs no case split
@@ -331,7 +374,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			}
 		}
 	};
-	auto load_tile = [&](int tile, float4 (&v)[NLD], float4 &pv, float4 &pw) { load_vec(tile, v); load_prev(tile, pv, pw); };
+	auto load_tile = [&](int tile, LoadT (&v)[NLD], LoadT &pv, LoadT &pw) { load_vec(tile, v); load_prev(tile, pv, pw); };
 	// K0+K1: (2:1 boxcar decimation,) d[n] = atan2q(z[n] * conj(z[n-1])), straight into buffer b
 	// AFC (SPEC 3.0b, IQ input): tile T's products are turned back by the phasor (1 - u^2, 2u), u = the state the lead wave published
 	// three tiles earlier (LDS, written two barriers ago) or, for the first three tiles of a submit, carried in the channel state
@@ -339,12 +382,40 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		const float u = tile == 0 ? st.afc[0] : (tile == 1 ? st.afc[1] : (tile == 2 ? st.afc[2] : s.afc_u[tile & 3]));
 		return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u)));
 	};
-	auto k1_tile = [&](int b, int tile, const float4 (&v)[NLD], const float4 &pv, const float4 &pw) {
+	auto k1_tile = [&](int b, int tile, const LoadT (&vraw)[NLD], const LoadT &pvraw, const LoadT &pwraw) {
 		const float afc_u = IS_IQ ? afc_of(tile) : 0.0f;
 		const float rc = __builtin_fmaf(-afc_u, afc_u, 1.0f), rs = afc_u + afc_u;
+		if constexpr (IQ16D4) {
+			// 16-bit input, 4:1: load g of lane l IS decimated sample 128 kw + 64 g + l (no exchange between lanes as in the float path)
+			float2 c = sd_cs16_sum4(pvraw);
+			float cx = c.x, cy = c.y;
+			if (tile == 0 && kw == 0) { cx = st.iq_last[0]; cy = st.iq_last[1]; }       // the carried (decimated) sample
+#pragma unroll
+			for (int g = 0; g < NLD; g++) {
+				const float2 z = sd_cs16_sum4(vraw[g]);
+				const float px = sd_wave_shr1(z.x, cx), py = sd_wave_shr1(z.y, cy);
+				store_one(s, b, (uint32_t)(128 * kw + 64 * g + lane), sd_disc_rot(z.x, z.y, px, py, rc, rs));
+				cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z.x), 63));
+				cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z.y), 63));
+			}
+			last_iq = make_float2(cx, cy);
+			return;
+		}
+		float4 v[NLD], pv, pw;
+		if constexpr (IQ16D4) {
+		} else if constexpr (IQ16) {
+#pragma unroll
+			for (int r = 0; r < NLD; r++) v[r] = sd_cs16_f4(vraw[r]);
+			pv = sd_cs16_f4(pvraw); pw = sd_cs16_f4(pwraw);
+		} else {
+#pragma unroll
+			for (int r = 0; r < NLD; r++) v[r] = vraw[r];
+			pv = pvraw; pw = pwraw;
+		}
 		// lane 0's predecessor (decimated) sample; after each load: lane 63's last sample
 		float cx = dec4 ? (pw.x + pw.z) + (pv.x + pv.z) : (dec2 ? pv.x + pv.z : pv.z);
 		float cy = dec4 ? (pw.y + pw.w) + (pv.y + pv.w) : (dec2 ? pv.y + pv.w : pv.w);
+		if (IQ16 && tile == 0 && kw == 0) { cx = st.iq_last[0]; cy = st.iq_last[1]; }       // the carried (decimated) sample
 		if (IS_IQ && dec4) {
 			// 4:1: a decimated sample spans two adjacent float4s, which the coalesced loads put into adjacent LANES.
 			// The per-float4 partial sums of two loads go through a wave-private LDS scratch (128 float2) and come back
@@ -799,6 +870,8 @@ void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStr
 		// (one class, no AFSK: always the plain launch over all bins)
 		hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, false, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
 	}
+	else if (in_kind == SD_IN_IQ16 && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ16, false);
+	else if (in_kind == SD_IN_IQ16) SD_DEMOD_LAUNCH(SD_IN_IQ16, true);
 	else if (in_kind == SD_IN_IQ && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ, false);
 	else if (in_kind == SD_IN_IQ) SD_DEMOD_LAUNCH(SD_IN_IQ, true);
 	else if (!chlist) SD_DEMOD_LAUNCH(SD_IN_REAL, false);

@@ -70,13 +70,13 @@ extern "C" int sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out)
 	*out = nullptr;
 	if (cfg->n_devices < 1 || cfg->n_devices > 16 || cfg->ingest >= cfg->n_devices) return nfail("sonde_node_create: n_devices must be 1..16 and ingest one of them");
 	if (cfg->n_channels < cfg->n_devices) return nfail("sonde_node_create: fewer channels than devices");
-	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL) return nfail("sonde_node_create: bad input_kind");
+	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL && cfg->input_kind != SONDE_INPUT_IQ16) return nfail("sonde_node_create: bad input_kind");
 	int ndev = 0;
 	HCHK(hipGetDeviceCount(&ndev));
 	SondeNode *n = new SondeNode;
 	n->nd = cfg->n_devices; n->ingest = cfg->ingest; n->n_channels = cfg->n_channels; n->max_samples = cfg->max_samples;
 	n->kind = cfg->input_kind;
-	n->elem = cfg->input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : sizeof(float);
+	n->elem = sonde_sample_bytes(cfg->input_kind);
 	n->dev.resize(n->nd); n->first.resize(n->nd); n->count.resize(n->nd);
 	n->batch.assign(n->nd, nullptr); n->st.assign(n->nd, nullptr); n->rows.assign(n->nd, nullptr); n->comm.assign(n->nd, nullptr);
 	for (uint32_t d = 0; d < n->nd; d++) {

@@ -26,6 +26,8 @@
 #define SD_IN_IQ   1        // 48 kS/s complex samples
 #define SD_IN_BINS 2        // 20 kS/s PHASE samples of a channelizer bin (one float each): discriminator (wrapped difference) + composite
                             // 12/5 resampler - 4:1 decimator in the kernel (SPEC 3.5b)
+#define SD_IN_IQ16 3        // 48 kS/s complex samples as 16-bit integers (I, Q interleaved: what SDR hardware and WAV recordings hold): half the
+                            // bytes of SD_IN_IQ per sample; converted exactly (int16 -> float, no scaling) in the load path, then SD_IN_IQ's arithmetic
 #define SD_RS_KT_LD 20      // row stride of the composite taps (17 in use)
 #define SD_RS_KT    17
 struct SdBinsIn {           // SD_IN_BINS: composite taps and the state carried from block to block (device pointers)

@@ -64,6 +64,18 @@ def test_argument_validation(lib):
     cfg.n_channels, cfg.max_samples = 4, 1000
     assert lib.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0 and b"multiple" in lib.sonde_last_error()
     assert lib.rs41_decoder_init(44100) is None        # reference always passes 48000 (main.cpp:16,62-68)
+    cfg.n_channels, cfg.max_samples, cfg.input_kind = 4, 2048, 7
+    assert lib.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0 and b"input_kind" in lib.sonde_last_error()
+
+
+def test_input_kinds_sample_bytes_and_row_stride(lib):
+    """complex64, float discriminator samples, 16-bit integer IQ: element sizes, and the recommended row stride in elements
+    (the same BYTES for the same row: 1.5 MiB rows go 2 MiB apart whatever they hold)"""
+    assert [lib.sonde_sample_bytes(k) for k in (_lib.INPUT_IQ, _lib.INPUT_REAL, _lib.INPUT_IQ16)] == [8, 4, 4]
+    n = 2048 * 96
+    assert lib.sonde_row_stride(n, _lib.INPUT_IQ) == 262144            # 1.5 MiB -> 2 MiB
+    assert lib.sonde_row_stride(n, _lib.INPUT_IQ16) == 262144          # 0.75 MiB -> 1 MiB
+    assert lib.sonde_row_stride(2 * n, _lib.INPUT_IQ16) == 524288      # 1.5 MiB -> 2 MiB
 
 
 def test_parse_frame_fields(lib):

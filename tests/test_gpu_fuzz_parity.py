@@ -19,10 +19,17 @@ def test_mixed_batch_low_snr_bit_exact(ebn0, seed, flags, cfo):
     run_mixed(ebn0, seed, check_coverage=True, flags=flags, cfo_max_hz=cfo)
 
 
-def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0):
+@pytest.mark.parametrize("ebn0,seed,flags", [(7.5, 5, 0), (11.0, 6, 4)])
+def test_mixed_batch_as_16_bit_iq_bit_exact(ebn0, seed, flags):
+    run_mixed(ebn0, seed, check_coverage=False, flags=flags, cfo_max_hz=1500.0, iq16=True)
+
+
+def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0, iq16=False):
     """(also driven by tools/fuzz_campaign.py over many seeds)  flags & 4 (SONDE_FLAG_PIPELINE): the submits are queued with two
     in flight and the frames fetched per ticket; the state is compared at the end.  cfo_max_hz: carrier offsets up to this
-    (the AFC of SPEC 3.0b at work; beyond +-2 kHz frames are lost on both sides alike)."""
+    (the AFC of SPEC 3.0b at work; beyond +-2 kHz frames are lost on both sides alike).  iq16: the rows go to the GPU as 16-bit
+    integers (SONDE_INPUT_IQ16, full scale 4096 per unit amplitude: the quantisation is part of the signal), the oracle gets the same
+    integers as floats."""
     types_cycle = (0, 1, 2, 3, 6)                       # the GFSK family (the AFSK sondes need 16384-sample submits: below)
     per, n_sub, n = 10, 3, TILE * 32
     parts, types = [], []
@@ -37,8 +44,11 @@ def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0):
     perm = np.random.default_rng(seed).permutation(len(types))
     iq, types = iq[torch.from_numpy(perm)].contiguous(), types[perm]
     C = len(types)
-    b = SondeBatch(C, n, types=types, flags=flags)
-    dev = iq.cuda()
+    if iq16:
+        q = torch.clamp(torch.round(iq * 4096.0), -32768, 32767).to(torch.int16)
+        iq = q.to(torch.float32)
+    b = SondeBatch(C, n, types=types, flags=flags, input_kind=2 if iq16 else 0)
+    dev = q.cuda() if iq16 else iq.cuda()
     chs = [oracle_lib.Channel(int(types[c]), c) for c in range(C)]
     x = iq.numpy()
     total = 0
@@ -66,7 +76,7 @@ def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0):
             assert b.nbits(c) == len(ch.bits())
         n_sub = 0
     for k in range(n_sub):
-        b.submit(dev[:, k * n:(k + 1) * n])
+        b.submit(dev[:, k * n:(k + 1) * n].contiguous() if iq16 else dev[:, k * n:(k + 1) * n])
         b.sync()
         got = b.frames()
         n_before = [len(ch.frames()) for ch in chs]

@@ -1,0 +1,98 @@
+"""SONDE_INPUT_IQ16 (16-bit integer IQ rows: what SDR hardware and WAV recordings hold; the step in front of `vfo->output`,
+/root/reference/src/main.cpp:55-57): the kernel converts int16 -> float exactly in its load path and then runs SONDE_INPUT_IQ's
+arithmetic, so bits, loop state and frames must equal (a) the float path fed with the same integers as floats and (b) the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib
+from sdrpp_radiosonde_amd import _lib, synth
+from sdrpp_radiosonde_amd.batch import SondeBatch, strided_rows
+
+pytestmark = pytest.mark.gpu
+TILE = 2048
+
+
+def quantise(iq: torch.Tensor, full_scale: float = 8192.0) -> torch.Tensor:
+    return torch.clamp(torch.round(iq * full_scale), -32768, 32767).to(torch.int16)
+
+
+def run(kind, x, types, chunks, flags=0, strided=False):
+    C, n = x.shape[0], x.shape[1]
+    b = SondeBatch(C, max(chunks) * TILE, types=types, input_kind=kind, flags=flags)
+    frames, pos = [], 0
+    for k in chunks:
+        blk = x[:, pos:pos + k * TILE].contiguous()
+        if strided:
+            blk = strided_rows(blk)
+        b.submit(blk)
+        frames.append(b.frames().copy())
+        pos += k * TILE
+    bits = [b.read_bits(c, 0, b.nbits(c)) for c in range(C)]
+    state = [b.state(c) for c in range(C)]
+    b.close()
+    return np.concatenate(frames), bits, state
+
+
+@pytest.mark.parametrize("stype,flags,chunks", [(0, 0, (8, 16)), (1, 0, (24,)), (3, 0, (5, 7, 12)), (2, 0, (24,)), (6, 0, (24,)), (0, 8, (24,)), (3, 8, (12, 12))])
+def test_iq16_equals_float_path_and_oracle(stype, flags, chunks):
+    C, n = 6, sum(chunks) * TILE
+    sb = synth.make_batch(stype, C, n, seed=300 + stype, ebn0_db=13.0, device="cuda", cfo_max_hz=1500.0)
+    x16 = quantise(sb.iq)
+    xf = x16.to(torch.float32)
+    types = np.full(C, stype, dtype=np.uint8)
+    f16, b16, s16 = run(_lib.INPUT_IQ16, x16, types, chunks, flags, strided=True)
+    ff, bf, sf = run(_lib.INPUT_IQ, xf, types, chunks, flags)
+    assert len(f16) > 0 and np.array_equal(f16, ff)
+    for c in range(C):
+        assert np.array_equal(b16[c], bf[c]) and s16[c] == sf[c]
+    if flags == 0:
+        xh = xf.cpu().numpy()
+        for c in range(2):
+            ch = oracle_lib.Channel(stype, c)
+            ch.feed(xh[c], is_iq=True)
+            ref = ch.frames()
+            got = f16[f16["channel"] == c]
+            got = got[np.argsort(got["bitpos"], kind="stable")]
+            ref = ref[np.argsort(ref["bitpos"], kind="stable")]
+            assert len(ref) == len(got) and got.tobytes() == ref.tobytes()
+            assert np.array_equal(ch.bits(), b16[c]) and ch.state() == s16[c]
+
+
+def test_iq16_mixed_types_pipelined():
+    """Mixed batch (launch units per type, channel lists) on 16-bit rows."""
+    C, n = 48, 24 * TILE
+    types = np.array([(0, 3, 1)[c % 3] for c in range(C)], dtype=np.uint8)
+    x = torch.empty((C, n, 2), dtype=torch.float32, device="cuda")
+    for t in (0, 3, 1):
+        idx = np.nonzero(types == t)[0]
+        x[torch.from_numpy(idx).cuda()] = synth.make_batch(t, len(idx), n, seed=40 + t, ebn0_db=14.0, device="cuda").iq
+    x16 = quantise(x)
+    for flags in (0, 4):
+        f16, b16, s16 = run(_lib.INPUT_IQ16, x16, types, (24,), flags)
+        ff, bf, sf = run(_lib.INPUT_IQ, x16.to(torch.float32), types, (24,), flags)
+        assert len(f16) >= C and np.array_equal(f16, ff)
+        assert all(np.array_equal(b16[c], bf[c]) and s16[c] == sf[c] for c in range(C))
+
+
+def test_iq16_refuses_afsk_and_checks_dtype():
+    with pytest.raises(Exception):
+        SondeBatch(4, 8 * TILE, types=np.array([0, 4, 0, 0], dtype=np.uint8), input_kind=_lib.INPUT_IQ16)
+    b = SondeBatch(2, 8 * TILE, input_kind=_lib.INPUT_IQ16)
+    with pytest.raises(Exception):
+        b.submit(torch.zeros((2, 8 * TILE, 2), dtype=torch.float32, device="cuda"))
+    b.submit(torch.zeros((2, 8 * TILE, 2), dtype=torch.int16, device="cuda"))
+    assert b.sync() == 0                               # all-zero input: atan2q(0, 0) = 0, nothing decodes, nothing breaks
+    b.close()
+
+
+def test_iq16_from_host_memory():
+    C, n = 8, 24 * TILE
+    sb = synth.make_rs41_batch(C, n, seed=9, ebn0_db=14.0, device="cuda")
+    x16 = quantise(sb.iq)
+    f_dev, _, _ = run(_lib.INPUT_IQ16, x16, None, (24,))
+    b = SondeBatch(C, n, input_kind=_lib.INPUT_IQ16)
+    b.submit_host(x16.cpu().numpy())
+    f_host = b.frames().copy()
+    b.close()
+    assert len(f_dev) >= 1 and np.array_equal(f_dev, f_host)

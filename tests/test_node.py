@@ -31,6 +31,27 @@ def test_node_abi_exports():
 
 
 @pytest.mark.gpu
+def test_node_takes_16_bit_iq():
+    """SONDE_INPUT_IQ16 through the node host (4-byte elements in the ingest copy / scatter): frames of the float path on the same integers."""
+    import torch
+    from sdrpp_radiosonde_amd import _lib, synth
+    from sdrpp_radiosonde_amd.batch import SondeBatch
+    from sdrpp_radiosonde_amd.node import SondeNode
+    C_, n = 21, 24 * TILE
+    sb = synth.make_rs41_batch(C_, n, seed=62, ebn0_db=14.0, device="cuda:0")
+    x16 = torch.clamp(torch.round(sb.iq * 8192.0), -32768, 32767).to(torch.int16)
+    nd = SondeNode(C_, n, devices=(0,), input_kind=_lib.INPUT_IQ16)
+    nd.submit(x16)
+    a = nd.frames()
+    nd.close()
+    bt = SondeBatch(C_, n)
+    bt.submit(x16.to(torch.float32))
+    b = bt.frames()
+    bt.close()
+    assert len(a) >= C_ // 2 and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("strided", [False, True])
 def test_node_of_one_device_equals_a_batch(strided):
     import torch
