@@ -86,6 +86,7 @@ def parse_args():
     ap.add_argument("--wb-streams", type=int, default=1, help="--wideband: independent 10 MS/s streams processed per step")
     ap.add_argument("--wb-dual", action="store_true", help="--wideband: both stackings of every stream (even + odd-stacked bank: 1024 channels per stream, "
                     "every carrier within 4.9 kHz of a bin centre)")
+    ap.add_argument("--wb-iq16", action="store_true", help="--wideband: the blocks as int16 I, Q pairs (sonde_chan_set_input: what a 10 MS/s receiver delivers)")
     ap.add_argument("--wb-overlap", action="store_true", help="--wideband: filter bank and decoder on two internal streams (consecutive submits may overlap)")
     ap.add_argument("--wb-blocks", type=int, default=1, choices=(1, 2, 4, 8), help="--wideband: blocks of 1 280 000 samples (0.128 s) per submit")
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
@@ -699,11 +700,12 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
             others["rt1250_host_e2e_cs16"]["workload"] = "the same from 16-bit integer IQ in host memory (SONDE_INPUT_IQ16)"
         except Exception as e:                    # (never lets the line fail: the headline above does not depend on it)
             others["rt1250_host_e2e"] = {"error": f"{type(e).__name__}: {e}"}
-        for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8x4", 8, 4), ("wideband4_dual", 4, 1)):
+        for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8x4", 8, 4), ("wideband4_dual", 4, 1), ("wideband8_cs16", 8, 1)):
             import copy
             a = copy.copy(args)
             a.wb_streams, a.wb_blocks = S, B
             a.wb_dual = name.endswith("_dual")
+            a.wb_iq16 = name.endswith("_cs16")
             a.steps, a.warmup, a.ramp_ms = max(40, min(args.steps, 50)), max(8, min(args.warmup, 10)), min(args.ramp_ms, 100.0)
             w = run_wideband(a, rank, local_rank, world, dev, barrier, reduce_max_sum)
             others[name] = {
@@ -791,13 +793,17 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
 
     S = args.wb_streams
     dual = bool(getattr(args, "wb_dual", False))
-    chan = SondeChannelizer(blocks_per_submit=args.wb_blocks, device=local_rank, n_streams=S, overlap=getattr(args, "wb_overlap", False), dual=dual)      # ONE object: every stage is one launch over all S streams
+    iq16 = bool(getattr(args, "wb_iq16", False))                       # the wideband blocks as int16 I, Q pairs (sonde_chan_set_input)
+    chan = SondeChannelizer(blocks_per_submit=args.wb_blocks, device=local_rank, n_streams=S, overlap=getattr(args, "wb_overlap", False), dual=dual,
+                            input_kind=2 if iq16 else 0)      # ONE object: every stage is one launch over all S streams
     nwb = chan.samples_per_submit
     bins_active = list(range(8, 504, 8))
     # a 1.024 s scene (8 blocks of 0.128 s) with 16 RS41 transmitters, cycled block by block so that the per-bin streams
     # are continuous (one discontinuity per wrap) and frames really decode; stream s runs s blocks ahead of stream 0
     NB = 8 // args.wb_blocks
     scene, _ = synth.make_wideband_rs41(bins_active[:16], NB * nwb, seed=7 + rank, ebn0_db=30.0, device=dev)
+    if iq16:
+        scene = torch.clamp(torch.round(scene * 1024.0), -32768, 32767).to(torch.int16)      # (16 carriers of unit amplitude + noise: well inside 16 bits)
     one = [scene[i * nwb: (i + 1) * nwb] for i in range(NB)]
     blocks = [torch.stack([one[(i + s) % NB] for s in range(S)]).contiguous() if S > 1 else one[i] for i in range(NB)]
     del scene
@@ -823,7 +829,7 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
     samples_per_step = S * nwb * world
     msps = samples_per_step * args.steps / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
-    alg_bytes = S * nwb * 8                               # every stream's block read once (the filter-bank launch covers all S streams)
+    alg_bytes = S * nwb * (4 if iq16 else 8)              # every stream's block read once (the filter-bank launch covers all S streams)
     achieved = alg_bytes / (pfb_ms * 1e-3) / 1e9
     return {
         "metric": "wideband IQ Msamples/s through channelizer+demod+FEC @ 10 MS/s/stream",

@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "sonde_last_error", "sonde_version", "sonde_hbm_read_probe", "sonde_dewpt", "sonde_altitude_to_pressure",
     "sonde_gpx_open", "sonde_gpx_close", "sonde_gpx_start_track", "sonde_gpx_stop_track", "sonde_gpx_add_point",
     "sonde_ptu_open", "sonde_ptu_close", "sonde_ptu_add_point",
-    "sonde_chan_create", "sonde_chan_create_multi", "sonde_chan_create_dual", "sonde_chan_streams", "sonde_chan_channels", "sonde_chan_set_fused", "sonde_chan_set_overlap", "sonde_chan_destroy", "sonde_chan_samples_per_submit", "sonde_chan_submit", "sonde_chan_batch",
+    "sonde_chan_create", "sonde_chan_create_multi", "sonde_chan_create_dual", "sonde_chan_streams", "sonde_chan_channels", "sonde_chan_set_fused", "sonde_chan_set_input", "sonde_chan_set_overlap", "sonde_chan_destroy", "sonde_chan_samples_per_submit", "sonde_chan_submit", "sonde_chan_batch",
     "sonde_chan_read", "sonde_chan_tables", "sonde_chan_kernel_ms",
     "sonde_vfo_create", "sonde_vfo_destroy", "sonde_vfo_ratio", "sonde_vfo_out_samples", "sonde_vfo_process", "sonde_vfo_process_host", "sonde_vfo_taps",
 ] + [f"{x}_{fn}" for x in ("rs41", "dfm09", "ims100", "m10", "imet4", "c50", "mrzn1")

@@ -187,7 +187,7 @@ class SondeChannelizer:
     sondes; an M10 channel (50 kHz wide) does not fit a 19.5 kHz bin: use SondeVfo for those."""
 
     def __init__(self, types=None, blocks_per_submit: int = 1, device: int = 0, n_streams: int = 1, fused: bool | None = None, overlap: bool | None = None,
-                 dual: bool = False):
+                 dual: bool = False, input_kind: int = INPUT_IQ):
         """dual: both stackings of every stream (SPEC 3.5c): 1024 channels per stream, 1024 p + k = even bin k (centre k x 19531.25 Hz),
         1024 p + 512 + k = odd bin k (centre (k + 1/2) x 19531.25 Hz): every carrier lies within 4.9 kHz of a bin centre."""
         self.L = _lib.load()
@@ -210,6 +210,10 @@ class SondeChannelizer:
         self.fused = bool(self.L.sonde_chan_set_fused(self.h, 1 if fused else 0)) if fused is not None else bool(self.L.sonde_chan_set_fused(self.h, -1))
         # overlap (an option, off by default): filter bank of submit k+1 beside the decoder of submit k, on internal streams
         self.overlap = bool(self.L.sonde_chan_set_overlap(self.h, 1)) if overlap else False
+        # input_kind: INPUT_IQ (complex64 blocks) or INPUT_IQ16 (int16 I, Q pairs: the receiver's own format)
+        self.input_kind = int(self.L.sonde_chan_set_input(self.h, input_kind))
+        if self.input_kind != input_kind:
+            raise SondeError("sonde_chan_set_input: input kind not accepted")
         self.samples_per_submit = int(self.L.sonde_chan_samples_per_submit(self.h))
         self.n_steps = self.samples_per_submit // 500
         self.batch = SondeBatch.__new__(SondeBatch)          # borrowed view of the embedded 512-channel batch
@@ -221,6 +225,9 @@ class SondeChannelizer:
     def submit(self, iq, stream: int | None = None):
         assert tuple(iq.shape) in ((self.samples_per_submit, 2), (self.n_streams, self.samples_per_submit, 2)) and iq.is_contiguous()
         assert self.n_streams == 1 or iq.dim() == 3
+        want = "int16" if self.input_kind == INPUT_IQ16 else "float32"
+        if not str(iq.dtype).endswith(want):
+            raise SondeError(f"wideband block must be {want}, got {iq.dtype}")
         self._keep = iq
         if self.L.sonde_chan_submit(self.h, C.c_void_p(iq.data_ptr()), self.samples_per_submit, C.c_void_p(stream or 0)) != 0:
             raise SondeError(_lib.last_error() or "sonde_chan_submit failed")

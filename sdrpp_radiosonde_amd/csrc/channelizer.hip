@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <string>
 #include <vector>
 #include "sd_math.h"
@@ -107,8 +108,11 @@ __device__ __forceinline__ void pfb_fft512(float2 *fb, const float2 *s_tw, int l
 	for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], s_tw[lane + 64 * j]);
 }
 
-__global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const float2 *__restrict__ iq_all, size_t stream_stride,
-                                                           const float2 *__restrict__ hist_in_all, float2 *__restrict__ hist_out_all,
+// I16: the wideband stream (and the carried history) as 16-bit integer I, Q pairs -- what a 10 MS/s receiver delivers -- converted on
+// the way into LDS (exactly, no scaling: a phase does not see the amplitude); everything behind the window is the float path
+template <bool I16>
+__global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
+                                                           const void *__restrict__ hist_in_all_, void *__restrict__ hist_out_all_,
                                                            const float *__restrict__ h_even, const float2 *__restrict__ tw,
                                                            float *__restrict__ phi_all, uint32_t n_steps, uint32_t xcd_map,
                                                            uint32_t dual, const float *__restrict__ h_odd, const float2 *__restrict__ twist)
@@ -128,31 +132,39 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const float2 *__restric
 	const bool odd = dual && (sidx & 1u);
 	const uint32_t phys = dual ? sidx >> 1 : sidx;
 	const float *h = odd ? h_odd : h_even;
-	const float2 *iq = iq_all + (size_t)phys * stream_stride;
-	const float2 *hist_in = hist_in_all + (size_t)phys * CH_H;
+	using ET = typename std::conditional<I16, uint32_t, float2>::type;       // one complex sample
+	using PT = typename std::conditional<I16, uint2, float4>::type;          // a pair of them: what a staging load moves
+	const ET *iq = reinterpret_cast<const ET *>(iq_all_) + (size_t)phys * stream_stride;
+	const ET *hist_in = reinterpret_cast<const ET *>(hist_in_all_) + (size_t)phys * CH_H;
+	ET *hist_out_all = reinterpret_cast<ET *>(hist_out_all_);
 	float *phi = phi_all + (size_t)sidx * CH_M * n_steps;
 	const long p0 = (long)m0 * CH_D - CH_H;                   // stream position of window sample 0 (even)
 	constexpr int NQ = (P_CHW / 2 + P_NT - 1) / P_NT;
-	auto load_round = [&](int c, float4 (&tmp)[NQ]) {          // taps c*P_TC ..: window samples [c * P_TC * 512, + P_CHW)
-		const long base = p0 + (long)c * P_TC * CH_M;           // even: a float4 never straddles the block's first sample
-		const float4 *src_iq = reinterpret_cast<const float4 *>(iq);
-		const float4 *src_h = reinterpret_cast<const float4 *>(hist_in);
+	auto load_round = [&](int c, PT (&tmp)[NQ]) {              // taps c*P_TC ..: window samples [c * P_TC * 512, + P_CHW)
+		const long base = p0 + (long)c * P_TC * CH_M;           // even: a pair never straddles the block's first sample
+		const PT *src_iq = reinterpret_cast<const PT *>(iq);
+		const PT *src_h = reinterpret_cast<const PT *>(hist_in);
 #pragma unroll
 		for (int q = 0; q < NQ; q++) {
 			const int i = tid + P_NT * q;
 			const long pos = base + 2 * (long)i;
-			tmp[q] = i < P_CHW / 2 ? (pos < 0 ? src_h[(CH_H + pos) / 2] : src_iq[pos / 2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+			if (i < P_CHW / 2) tmp[q] = pos < 0 ? src_h[(CH_H + pos) / 2] : src_iq[pos / 2];
+			else if constexpr (I16) tmp[q] = make_uint2(0u, 0u);
+			else tmp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 		}
 	};
-	auto store_round = [&](const float4 (&tmp)[NQ]) {
+	auto store_round = [&](const PT (&tmp)[NQ]) {
 		float4 *dst = reinterpret_cast<float4 *>(s_x);
 #pragma unroll
 		for (int q = 0; q < NQ; q++) {
 			const int i = tid + P_NT * q;
-			if (i < P_CHW / 2) dst[i] = tmp[q];
+			if (i < P_CHW / 2) {
+				if constexpr (I16) dst[i] = make_float4((float)(int16_t)(tmp[q].x & 0xffffu), (float)((int32_t)tmp[q].x >> 16), (float)(int16_t)(tmp[q].y & 0xffffu), (float)((int32_t)tmp[q].y >> 16));
+				else dst[i] = tmp[q];
+			}
 		}
 	};
-	float4 ta[NQ], tb[NQ];
+	PT ta[NQ], tb[NQ];
 	load_round(0, ta);
 	const float2 twv = tid < CH_M / 2 ? tw[tid] : make_float2(0.f, 0.f);
 	const int r = tid;
@@ -160,8 +172,8 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const float2 *__restric
 #pragma unroll
 	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
 	if (grp == gridDim.x - 1 && !odd) {     // the last CH_H samples of the block are the next submit's history (n_steps * 500 >= CH_H)
-		const float4 *tail = reinterpret_cast<const float4 *>(iq + (size_t)n_steps * CH_D - CH_H);
-		float4 *ho = reinterpret_cast<float4 *>(hist_out_all + (size_t)phys * CH_H);
+		const PT *tail = reinterpret_cast<const PT *>(iq + (size_t)n_steps * CH_D - CH_H);
+		PT *ho = reinterpret_cast<PT *>(hist_out_all + (size_t)phys * CH_H);
 		for (int i = tid; i < CH_H / 2; i += P_NT) ho[i] = tail[i];
 	}
 	store_round(ta);
@@ -267,6 +279,7 @@ extern "C" const char *sonde_last_error(void);
 struct SondeChannelizer {
 	int device = 0;
 	uint32_t n_steps = 0, n_streams = 1;     // n_streams: LOGICAL streams (grid.y, 512 decoder channels each)
+	int input_kind = SONDE_INPUT_IQ;       // what sonde_chan_submit's block holds: complex64 or (sonde_chan_set_input) 16-bit integer IQ
 	uint32_t n_phys = 1, dual = 0;            // physical input streams; dual: every physical stream feeds an even and an odd-stacked bank (SPEC 3.5c)
 	float *d_h_odd = nullptr; float2 *d_twist = nullptr;
 	bool fused = false;                    // the decoder kernel takes the bins themselves (discriminator + resampler in its load path): two launches per submit
@@ -492,6 +505,27 @@ static bool chan_overlap_setup(SondeChannelizer *c)
 	return ok;
 }
 
+// What the wideband block holds: SONDE_INPUT_IQ (complex64, the default) or SONDE_INPUT_IQ16 (int16 I, int16 Q: what a 10 MS/s
+// receiver delivers; half the bytes to move).  Before the first submit only (the carried window is kept in the input's format).
+// Returns the kind in force, or -1.
+extern "C" int sonde_chan_set_input(SondeChannelizer *c, int input_kind)
+{
+	if (!c) return -1;
+	if (c->n_blocks == 0 && (input_kind == SONDE_INPUT_IQ || input_kind == SONDE_INPUT_IQ16)) c->input_kind = input_kind;
+	return c->input_kind;
+}
+
+static void launch_pfb(SondeChannelizer *c, hipStream_t st, const void *iq_dev, size_t n_samples, float *bins)
+{
+	const dim3 g(c->n_steps / P_S, c->n_streams), blk(P_NT);
+	const void *hin = c->d_hist[c->n_blocks & 1];
+	void *hout = c->d_hist[(c->n_blocks + 1) & 1];
+	if (c->input_kind == SONDE_INPUT_IQ16)
+		hipLaunchKernelGGL(sd_pfb_kernel<true>, g, blk, 0, st, iq_dev, n_samples, hin, hout, c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
+	else
+		hipLaunchKernelGGL(sd_pfb_kernel<false>, g, blk, 0, st, iq_dev, n_samples, hin, hout, c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
+}
+
 extern "C" uint32_t sonde_chan_samples_per_submit(const SondeChannelizer *c) { return c ? c->n_steps * CH_D : 0; }
 extern "C" SondeBatch *sonde_chan_batch(SondeChannelizer *c) { return c ? c->batch : nullptr; }
 
@@ -521,8 +555,7 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		if (hipEventRecord(c->ev_in, stream) != hipSuccess || hipStreamWaitEvent(c->s_pfb, c->ev_in, 0) != hipSuccess) return -1;
 		if (c->n_blocks >= 2 && hipStreamWaitEvent(c->s_pfb, c->ev_dec[b], 0) != hipSuccess) return -1;
 		if (timed) (void)hipEventRecord(c->ev[0], c->s_pfb);
-		hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / P_S, c->n_streams), dim3(P_NT), 0, c->s_pfb, (const float2 *)iq_dev, n_samples,
-		                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
+		launch_pfb(c, c->s_pfb, iq_dev, n_samples, bins);
 		c->n_blocks++;
 		c->d_bins_last = bins;
 		if (timed) { (void)hipEventRecord(c->ev[1], c->s_pfb); (void)hipEventRecord(c->ev[2], c->s_pfb); c->ev_pending = true; }
@@ -542,8 +575,7 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 	}
 	c->last_stream = stream;
 	if (timed) (void)hipEventRecord(c->ev[0], stream);
-	hipLaunchKernelGGL(sd_pfb_kernel, dim3(c->n_steps / P_S, c->n_streams), dim3(P_NT), 0, stream, (const float2 *)iq_dev, n_samples,
-	                   c->d_hist[c->n_blocks & 1], c->d_hist[(c->n_blocks + 1) & 1], c->d_h, c->d_tw, c->d_bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
+	launch_pfb(c, stream, iq_dev, n_samples, c->d_bins);
 	c->n_blocks++;
 	c->d_bins_last = c->d_bins;
 	if (timed) (void)hipEventRecord(c->ev[1], stream);

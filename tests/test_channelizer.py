@@ -305,6 +305,48 @@ def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_channelizer_takes_16_bit_wideband_blocks(oracle, fused):
+    """sonde_chan_set_input(SONDE_INPUT_IQ16): the wideband block as int16 I, Q pairs (what a 10 MS/s receiver delivers).  Converted
+    exactly on the way into the filter bank's window: phases (every bin), frames, bits and loop state equal those of the float
+    block holding the same integers, and the frames equal the oracle's on those floats.  Two streams, two blocks per submit, five
+    submits (the carried window is kept as integers from submit to submit)."""
+    import torch
+    from sdrpp_radiosonde_amd import _lib
+    from sdrpp_radiosonde_amd.batch import SondeChannelizer
+    bins_active, streams, bps, nblk = [9, 130, 257, 500], 2, 2, 10
+    scenes = [synth.make_wideband_rs41(bins_active, nblk * BLOCK, seed=70 + s, ebn0_db=33.0, device="cuda:0")[0] for s in range(streams)]
+    x16 = [torch.clamp(torch.round(sc * 2048.0), -32768, 32767).to(torch.int16) for sc in scenes]
+    chz_i = SondeChannelizer(blocks_per_submit=bps, n_streams=streams, fused=fused, input_kind=_lib.INPUT_IQ16)
+    chz_f = SondeChannelizer(blocks_per_submit=bps, n_streams=streams, fused=fused)
+    with pytest.raises(Exception):
+        chz_i.submit(torch.stack([x[:bps * BLOCK].to(torch.float32) for x in x16]).contiguous())      # a float block into the integer object
+    gi, gf = [], []
+    for b in range(nblk // bps):
+        chz_i.submit(torch.stack([x[b * bps * BLOCK: (b + 1) * bps * BLOCK] for x in x16]).contiguous())
+        chz_f.submit(torch.stack([x[b * bps * BLOCK: (b + 1) * bps * BLOCK].to(torch.float32) for x in x16]).contiguous())
+        gi.append(chz_i.frames())
+        gf.append(chz_f.frames())
+        pi, oi = chz_i.read()
+        pf, of = chz_f.read()
+        assert np.array_equal(pi.view(np.uint32), pf.view(np.uint32)), b            # the phases of every bin and step
+        assert fused or np.array_equal(oi.view(np.uint32), of.view(np.uint32))
+    gi, gf = np.concatenate(gi), np.concatenate(gf)
+    assert len(gi) >= len(bins_active) * streams and gi.tobytes() == gf.tobytes()
+    for c in (9, 512 + 257, 7):
+        assert chz_i.batch.nbits(c) == chz_f.batch.nbits(c) and chz_i.batch.state(c) == chz_f.batch.state(c)
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    refs = []
+    for s_ in range(streams):
+        dec, _ = _oracle_decode_wideband(oracle, x16[s_].to(torch.float32).cpu().numpy(), bins_active, composite=fused)
+        for k in bins_active:
+            r = dec[k].frames().copy()
+            r["channel"] = 512 * s_ + k
+            refs.append(r)
+    assert key(gi).tobytes() == key(np.concatenate(refs)).tobytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fused,streams", [(True, 4), (False, 2)])
 def test_dual_stacking_equals_oracle_and_covers_the_band(oracle, fused, streams):
     """sonde_chan_create_dual (SPEC 3.5c): the even and the odd-stacked bank over the same samples, two streams.  Stream 0 carries
