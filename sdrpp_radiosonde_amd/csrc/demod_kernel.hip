@@ -42,6 +42,14 @@ static __device__ __forceinline__ float2 sd_cs16_sum4(uint4 q)
 	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.w), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.w), hi, j, false);
 	return make_float2((float)i, (float)j);
 }
+// the same sums in plain integer arithmetic: for WAVE-UNIFORM operands (the scalar-loaded samples in front of a wave's first one) the
+// compiler keeps this on the scalar unit; v_dot2c has no scalar form and would spend eight vector instructions per tile on one value
+static __device__ __forceinline__ float2 sd_cs16_sum4_uniform(uint4 q)
+{
+	const int i = (int)(int16_t)(q.x & 0xffffu) + (int)(int16_t)(q.y & 0xffffu) + (int)(int16_t)(q.z & 0xffffu) + (int)(int16_t)(q.w & 0xffffu);
+	const int j = ((int32_t)q.x >> 16) + ((int32_t)q.y >> 16) + ((int32_t)q.z >> 16) + ((int32_t)q.w >> 16);
+	return make_float2((float)i, (float)j);
+}
 // SD_IN_IQ16: two complex samples of 16-bit integers (I0 Q0 I1 Q1, little endian) -> the float4 the float path would have loaded
 // (int16 -> float is exact; no scaling: the discriminator's output does not depend on the amplitude)
 static __device__ __forceinline__ float4 sd_cs16_f4(uint2 q)
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		const float rc = __builtin_fmaf(-afc_u, afc_u, 1.0f), rs = afc_u + afc_u;
 		if constexpr (IQ16D4) {
 			// 16-bit input, 4:1: load g of lane l IS decimated sample 128 kw + 64 g + l (no exchange between lanes as in the float path)
-			float2 c = sd_cs16_sum4(pvraw);
+			float2 c = sd_cs16_sum4_uniform(pvraw);
 			float cx = c.x, cy = c.y;
 			if (tile == 0 && kw == 0) { cx = st.iq_last[0]; cy = st.iq_last[1]; }       // the carried (decimated) sample
 #pragma unroll
