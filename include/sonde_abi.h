@@ -137,6 +137,10 @@ typedef struct {
  * throughput that no longer depends on the channel count being a multiple of 1024 (1250 channels x 1 s: 0.56 -> 0.74 of the HBM
  * peak), for hosts that keep two or more submits queued. */
 #define SONDE_FLAG_PIPELINE  4u
+/* SONDE_FLAG_WIDE for the sonde types whose channel is 20 kHz or wider in the reference only (iMS-100 / RS-11G and MRZ-N1: 20 kHz,
+ * M10 / M20: 50 kHz; /root/reference/src/main.hpp:47-51); RS41 (10 kHz) and DFM (15 kHz) keep the default classes.  The per-type
+ * choice sonde::IqStreamDecoder makes for its one channel, for a batch of mixed types.  IQ input only. */
+#define SONDE_FLAG_WIDE_AUTO 8u
 
 typedef struct SondeBatch SondeBatch;
 

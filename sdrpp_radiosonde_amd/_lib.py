@@ -48,6 +48,7 @@ FLAG_WIDE = 1            # one decimation step less for every GFSK sonde (SONDE_
 FLAG_RS41_WIDE = FLAG_WIDE
 FLAG_SPLIT_FEC = 2
 FLAG_PIPELINE = 4        # mixed batches: class streams are not joined into the caller's stream (SONDE_FLAG_PIPELINE)
+FLAG_WIDE_AUTO = 8       # SONDE_FLAG_WIDE for the types whose reference channel is >= 20 kHz only (iMS-100, MRZ-N1, M10)
 
 
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them

@@ -236,8 +236,13 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	b->input_kind = cfg->input_kind;
 	b->device = cfg->device;
 	for (int t = 0; t < SONDE_NTYPES; t++) b->md[t] = k_modems[t];
-	if ((cfg->flags & SONDE_FLAG_WIDE) && cfg->input_kind != SONDE_INPUT_REAL)
-		for (int t = 0; t < SONDE_NTYPES; t++) if (b->md[t].pre == 1) b->md[t].decim /= 2;       // one decimation step less (SPEC 3.0)
+	if ((cfg->flags & (SONDE_FLAG_WIDE | SONDE_FLAG_WIDE_AUTO)) && cfg->input_kind != SONDE_INPUT_REAL)
+		for (int t = 0; t < SONDE_NTYPES; t++) {
+			// SONDE_FLAG_WIDE: every GFSK sonde; SONDE_FLAG_WIDE_AUTO: the types whose channel is 20 kHz or wider in the reference
+			// (iMS-100 / RS-11G, MRZ-N1: 20 kHz, M10 / M20: 50 kHz, /root/reference/src/main.hpp:47-51) -- per type, for mixed batches
+			const bool wide_type = (cfg->flags & SONDE_FLAG_WIDE) || t == SONDE_IMS100 || t == SONDE_MRZN1 || t == SONDE_M10;
+			if (b->md[t].pre == 1 && wide_type) b->md[t].decim /= 2;       // one decimation step less (SPEC 3.0)
+		}
 	const ModemDef *md = b->md;
 	b->types.assign(cfg->n_channels, SONDE_RS41);
 	if (cfg->types) b->types.assign(cfg->types, cfg->types + cfg->n_channels);

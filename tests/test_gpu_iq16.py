@@ -34,13 +34,14 @@ def run(kind, x, types, chunks, flags=0, strided=False):
     return np.concatenate(frames), bits, state
 
 
-@pytest.mark.parametrize("stype,flags,chunks", [(0, 0, (8, 16)), (1, 0, (24,)), (3, 0, (5, 7, 12)), (2, 0, (24,)), (6, 0, (24,)), (0, 8, (24,)), (3, 8, (12, 12))])
+@pytest.mark.parametrize("stype,flags,chunks", [(0, 0, (8, 16)), (1, 0, (24,)), (3, 0, (5, 7, 12)), (2, 0, (24,)), (6, 0, (24,)), (0, 1, (24,)), (3, 1, (12, 12))])
 def test_iq16_equals_float_path_and_oracle(stype, flags, chunks):
     C, n = 6, sum(chunks) * TILE
     sb = synth.make_batch(stype, C, n, seed=300 + stype, ebn0_db=13.0, device="cuda", cfo_max_hz=1500.0)
     x16 = quantise(sb.iq)
     xf = x16.to(torch.float32)
     types = np.full(C, stype, dtype=np.uint8)
+    # (flags 1 = SONDE_FLAG_WIDE: the (2:1, 16 taps) and (none, 16 taps) classes: 8-byte loads of two samples, converted)
     f16, b16, s16 = run(_lib.INPUT_IQ16, x16, types, chunks, flags, strided=True)
     ff, bf, sf = run(_lib.INPUT_IQ, xf, types, chunks, flags)
     assert len(f16) > 0 and np.array_equal(f16, ff)

@@ -329,6 +329,43 @@ def test_wide_mode_other_types(oracle, stype, wide_decim, cfo):
     del n_narrow                            # (as above: not asserted at 22 dB)
 
 
+def test_wide_auto_is_wide_per_type(oracle):
+    """SONDE_FLAG_WIDE_AUTO: a mixed batch whose iMS-100 and M10 channels (20 / 50 kHz wide in the reference, main.hpp:47-51) run the wide
+    classes while RS41 and DFM keep the default ones -- per type what sonde::IqStreamDecoder picks for its one channel.  Frames of
+    every channel == the oracle with the same per-type decimations; carriers 3 kHz (iMS-100) / 7 kHz (M10) off decode."""
+    from sdrpp_radiosonde_amd._lib import FLAG_WIDE_AUTO
+    per, n = 4, TILE * 48
+    plan = [(0, 4, 4, 1000.0), (1, 4, 4, 1000.0), (2, 2, 4, 3000.0), (3, 1, 2, 7000.0)]       # (type, decimation under the flag, default, carrier offset)
+    parts, types = [], []
+    for t, _, _, cfo in plan:
+        sb = synth.make_batch(t, per, n, seed=500 + t, ebn0_db=22.0, cfo_max_hz=cfo)
+        parts.append(sb.iq)
+        types += [t] * per
+    x = torch.cat(parts).numpy()
+    types = np.array(types, dtype=np.uint8)
+    b = SondeBatch(len(types), n, types=types, flags=FLAG_WIDE_AUTO)
+    b.submit(_dev(torch.from_numpy(x)))
+    got = b.frames()
+    b.close()
+    L = oracle.lib()
+    refs = []
+    for t, dec_flag, dec_default, _ in plan:
+        L.or_modem_set_decim(t, dec_flag)
+        try:
+            for c in np.nonzero(types == t)[0]:
+                ch = oracle.Channel(t, int(c))
+                ch.feed(x[c])
+                refs.append(ch.frames().copy())
+        finally:
+            L.or_modem_set_decim(t, dec_default)
+    ref = np.concatenate(refs)
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    assert key(got).tobytes() == key(ref).tobytes()
+    for t, _, _, _ in plan:
+        sel = got[np.isin(got["channel"], np.nonzero(types == t)[0])]
+        assert len(sel) > 0 and ((sel["nerr"] >= 0).all(axis=1)).sum() >= len(sel) // 2, t
+
+
 def test_split_fec_kernel_equals_fused_epilogue(oracle):
     """SONDE_FLAG_SPLIT_FEC (Reed-Solomon as its own kernel) and the default (in the demod kernel's epilogue) give the
     same frame records, both equal to the oracle's, across several submits (frames straddle submit boundaries)."""
