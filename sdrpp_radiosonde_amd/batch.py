@@ -83,7 +83,10 @@ class SondeBatch:
         self._chk(self.L.sonde_batch_submit(self.h, C.c_void_p(samples.data_ptr()), n, stride, C.c_void_p(stream or 0)))
 
     def submit_host(self, samples: np.ndarray):
-        samples = np.ascontiguousarray(samples, dtype=np.int16 if self.input_kind == INPUT_IQ16 else np.float32)
+        want = np.int16 if self.input_kind == INPUT_IQ16 else np.float32
+        if self.input_kind == INPUT_IQ16 and np.asarray(samples).dtype != np.int16:
+            raise SondeError(f"samples must be int16 for INPUT_IQ16, got {np.asarray(samples).dtype} (no silent conversion)")
+        samples = np.ascontiguousarray(samples, dtype=want)
         n = samples.shape[1]
         self._chk(self.L.sonde_batch_submit_host(self.h, samples.ctypes.data_as(C.c_void_p), n, n))
 
