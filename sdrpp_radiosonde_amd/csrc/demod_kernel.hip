@@ -734,7 +734,29 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		__syncthreads();
 		// phase `tile`: tile+1 goes from registers into the other LDS buffer, tile+3 is requested from HBM
 		// (two phases of latency budget); the loop is unrolled by two so the register sets are static
-		for (int tile = 0; tile < n_tiles; tile += 2) {
+		int tile = 0;
+		// Steady state with every load of an iteration issued UNCONDITIONALLY (16-bit input only).  The compiler inserts the s_waitcnt in
+		// front of a register set's first use; with `if (tile + 3 < n_tiles) ldB(...)` in the loop it cannot know whether the four
+		// loads of the OTHER set are in flight behind the set it waits for, must assume they are not, and waits for vmcnt(3..0): for
+		// everything, the tile requested a moment ago included -- the second register set then prefetches less than a tile ahead.
+		// With unconditional loads it counts the newer ones and waits for vmcnt(6), (4).  Measured, interleaved
+		// (profiles/r4_ab_uncond.txt): 16-bit rows 1024 x 96 tiles -2.5 %, 4096 x 96 -1.7 %; FLOAT rows: 8192 x 24 -1.5 % but the
+		// one-residency headline +4 % (0.2548-0.2620 -> 0.2685-0.2707 ms) and 4096 x 96 +1.5 %: with 16 KB tiles the launch does
+		// better with FEWER bytes in flight per workgroup (the memory system's latency grows faster than the bytes: r4_notes.md),
+		// so the float classes keep the conditional loop and its conservative waits.  The last iterations run the general loop below.
+		if constexpr (IQ16) {
+			for (; tile + 4 < n_tiles; tile += 2) {
+				if (t < SD_LH) s.A[1][t] = s.A[0][IT + t];                // history roll into the other buffer
+				k1B(1, tile + 1);
+				ldB(tile + 3);
+				for (int r = 0; r < rounds; r++) __syncthreads();
+				if (t < SD_LH) s.A[0][t] = s.A[1][IT + t];
+				k1A(0, tile + 2);
+				ldA(tile + 4);
+				for (int r = 0; r < rounds; r++) __syncthreads();
+			}
+		}
+		for (; tile < n_tiles; tile += 2) {
 			if (tile + 1 < n_tiles) {
 				if (t < SD_LH) s.A[1][t] = s.A[0][IT + t];            // history roll into the other buffer
 				k1B(1, tile + 1);
