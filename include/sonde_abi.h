@@ -93,7 +93,7 @@ enum { SONDE_INPUT_IQ = 0,      /* complex64 interleaved I,Q at 48 kS/s (vfo->ou
                                  * what SDR hardware and WAV recordings hold before SDR++'s sources convert to float.  Converted in the
                                  * kernel's load path (exactly; no scaling: the discriminator does not depend on the amplitude), so the
                                  * frames are those of SONDE_INPUT_IQ fed with the same integers as floats, for half the bytes over PCIe,
-                                 * xGMI and HBM.  Batch / node API only; not for the tone-demodulated sondes (iMet-4, SRS-C50). */
+                                 * xGMI and HBM.  Batch / node API, all seven sonde types. */
 
 #define SONDE_TILE       2048   /* samples; submit lengths are multiples of this */
 #define SONDE_FRAME_MAX  528

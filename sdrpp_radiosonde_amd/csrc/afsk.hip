@@ -14,17 +14,18 @@
 
 #define AF_T 256      // threads = block sums per 2048-sample tile
 
-template <bool IS_IQ, int PER, int NW>    // mixer table period, boxcar length in blocks of 8 samples (<= 5)
+template <int KIND, int PER, int NW>    // KIND: 0 real (discriminator samples), 1 complex64, 2 int16 I, Q pairs (SD_IN_IQ16: converted exactly, no scaling); mixer table period; boxcar length in blocks of 8 samples (<= 5)
 __global__ __launch_bounds__(AF_T) void sd_afsk_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles, const uint32_t *__restrict__ chlist,
 	SdAfskState *__restrict__ astates, const float2 *__restrict__ wtab, float *__restrict__ out, size_t out_stride)
 {
 	__shared__ float2 bs[AF_T + 4];       // block sums: [0..3] the four before this tile, [4 + t] this tile's
 	__shared__ float2 zs[AF_T + 1];       // boxcar outputs: [0] the one before this tile
+	constexpr bool IS_IQ = KIND != 0;
 	const int t = threadIdx.x;
 	const uint32_t ch = chlist[blockIdx.x];
 	SdAfskState st = astates[ch];
-	const float *src = in + (IS_IQ ? 2 : 1) * (size_t)ch * ch_stride;
+	const float *src = in + (KIND == 1 ? 2 : 1) * (size_t)ch * ch_stride;      // (4-byte elements for real input and for int16 pairs)
 	float *dst = out + (size_t)blockIdx.x * out_stride;
 	if (t < 4) bs[t] = make_float2(st.b[t][0], st.b[t][1]);
 	if (t == 0) zs[0] = make_float2(st.z[0], st.z[1]);
@@ -36,10 +37,15 @@ __global__ __launch_bounds__(AF_T) void sd_afsk_kernel(
 		float d[8];
 		if (IS_IQ) {
 			const float2 *x = reinterpret_cast<const float2 *>(src) + s0;
-			float2 p = s0 ? x[-1] : last;
+			const uint32_t *x16 = reinterpret_cast<const uint32_t *>(src) + s0;
+			auto sample = [&](int i) -> float2 {
+				if (KIND == 2) { const uint32_t q = x16[i]; return make_float2((float)(int16_t)(q & 0xffffu), (float)((int32_t)q >> 16)); }
+				return x[i];
+			};
+			float2 p = s0 ? sample(-1) : last;
 #pragma unroll
 			for (int i = 0; i < 8; i++) {
-				const float2 c = x[i];
+				const float2 c = sample(i);
 				d[i] = sd_disc(c.x, c.y, p.x, p.y);
 				p = c;
 			}
@@ -81,13 +87,13 @@ __global__ __launch_bounds__(AF_T) void sd_afsk_kernel(
 	if (IS_IQ && t == AF_T - 1) { astates[ch].iq_last[0] = last.x; astates[ch].iq_last[1] = last.y; }
 }
 
-void sd_launch_afsk(int type, bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
+void sd_launch_afsk(int type, int kind /* 0 real, 1 complex64, 2 int16 IQ */, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
 	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride)
 {
 #define AF_GO(IQ, PER, NW) hipLaunchKernelGGL((sd_afsk_kernel<IQ, PER, NW>), dim3(n_list), dim3(AF_T), 0, stream, in, ch_stride, n_tiles, chlist, astates, \
 		(const float2 *)wtab, out, out_stride)
-	if (type == SONDE_C50) { if (is_iq) AF_GO(true, SD_C50_PER, 2); else AF_GO(false, SD_C50_PER, 2); }
-	else { if (is_iq) AF_GO(true, SD_AF_PER, 5); else AF_GO(false, SD_AF_PER, 5); }
+	if (type == SONDE_C50) { if (kind == 2) AF_GO(2, SD_C50_PER, 2); else if (kind == 1) AF_GO(1, SD_C50_PER, 2); else AF_GO(0, SD_C50_PER, 2); }
+	else { if (kind == 2) AF_GO(2, SD_AF_PER, 5); else if (kind == 1) AF_GO(1, SD_AF_PER, 5); else AF_GO(0, SD_AF_PER, 5); }
 #undef AF_GO
 }
 

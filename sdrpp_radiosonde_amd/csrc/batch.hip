@@ -291,7 +291,6 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	for (int t = 0; t < SONDE_NTYPES; t++)
 		if (!b->chlist[t].empty()) ALLOC(b->d_chlist[t], b->chlist[t].size() * sizeof(uint32_t));
 	const size_t n_afsk = b->chlist[SONDE_IMET4].size() + b->chlist[SONDE_C50].size();      // tone-demodulated sondes
-	if (n_afsk && cfg->input_kind == SONDE_INPUT_IQ16) { sonde_batch_destroy(b); return fail("sonde_batch_create: 16-bit IQ input does not serve the tone-demodulated sondes (iMet-4, SRS-C50)"); }
 	std::vector<uint32_t> cls[4];               // index: demod-kernel class (k_cls_decim, k_cls_nt)
 	for (uint32_t c = 0; c < b->n_channels; c++) {
 		if (b->types[c] == SONDE_IMET4 || b->types[c] == SONDE_C50) continue;
@@ -609,7 +608,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 				// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows
 				// (one kernel-A tile = 2048 scratch samples = 16384 input samples)
 				float *rows = b->d_afq + u.row0 * (size_t)(b->max_samples / SD_AF_DEC);
-				sd_launch_afsk(u.type, iq == SD_IN_IQ, u.n, u.st, (const float *)samples, channel_stride, n_tiles,
+				sd_launch_afsk(u.type, iq == SD_IN_IQ ? 1 : (iq == SD_IN_IQ16 ? 2 : 0), u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_chlist[u.type], b->d_astates, u.type == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
 				sd_launch_demod(SD_IN_REAL, 1, 16, u.n, u.st, rows, nq, (int)(nq / SONDE_TILE),
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo, nullptr, u.type);

@@ -30,7 +30,7 @@ void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStr
 int sd_batch_submit_bins(SondeBatch *b, const void *bins, size_t n_steps, size_t channel_stride, const SdBinsIn *d_bins_in, void *stream);
 int sd_batch_bins_capable(const SondeBatch *b);      // 1: every channel's class has a bins instantiation (no AFSK sonde, no class without one)
 
-void sd_launch_afsk(int type /* SONDE_IMET4 or SONDE_C50 */, bool is_iq, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
+void sd_launch_afsk(int type /* SONDE_IMET4 or SONDE_C50 */, int kind /* 0 real, 1 complex64, 2 int16 IQ pairs */, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
 	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride);
 void sd_launch_framer_imet(uint32_t n_list, hipStream_t stream, const SdChanState *states, SdFramerState *fstates,
 	const uint32_t *bitring, uint32_t ring_words, SondeFrame *frames, uint32_t *counts, uint32_t max_frames, const uint32_t *chlist);

@@ -28,7 +28,7 @@ def run(kind, x, types, chunks, flags=0, strided=False):
         b.submit(blk)
         frames.append(b.frames().copy())
         pos += k * TILE
-    bits = [b.read_bits(c, 0, b.nbits(c)) for c in range(C)]
+    bits = [(b.nbits(c), b.read_bits(c, max(0, b.nbits(c) - 4000), min(4000, b.nbits(c)))) for c in range(C)]      # (the newest 4000: the ring is finite)
     state = [b.state(c) for c in range(C)]
     b.close()
     return np.concatenate(frames), bits, state
@@ -46,7 +46,7 @@ def test_iq16_equals_float_path_and_oracle(stype, flags, chunks):
     ff, bf, sf = run(_lib.INPUT_IQ, xf, types, chunks, flags)
     assert len(f16) > 0 and np.array_equal(f16, ff)
     for c in range(C):
-        assert np.array_equal(b16[c], bf[c]) and s16[c] == sf[c]
+        assert b16[c][0] == bf[c][0] and np.array_equal(b16[c][1], bf[c][1]) and s16[c] == sf[c]
     if flags == 0:
         xh = xf.cpu().numpy()
         for c in range(2):
@@ -57,7 +57,8 @@ def test_iq16_equals_float_path_and_oracle(stype, flags, chunks):
             got = got[np.argsort(got["bitpos"], kind="stable")]
             ref = ref[np.argsort(ref["bitpos"], kind="stable")]
             assert len(ref) == len(got) and got.tobytes() == ref.tobytes()
-            assert np.array_equal(ch.bits(), b16[c]) and ch.state() == s16[c]
+            rb = ch.bits()
+            assert len(rb) == b16[c][0] and np.array_equal(rb[-len(b16[c][1]):] if len(b16[c][1]) else rb[:0], b16[c][1]) and ch.state() == s16[c]
 
 
 def test_iq16_mixed_types_pipelined():
@@ -73,18 +74,34 @@ def test_iq16_mixed_types_pipelined():
         f16, b16, s16 = run(_lib.INPUT_IQ16, x16, types, (24,), flags)
         ff, bf, sf = run(_lib.INPUT_IQ, x16.to(torch.float32), types, (24,), flags)
         assert len(f16) >= C and np.array_equal(f16, ff)
-        assert all(np.array_equal(b16[c], bf[c]) and s16[c] == sf[c] for c in range(C))
+        assert all(b16[c][0] == bf[c][0] and np.array_equal(b16[c][1], bf[c][1]) and s16[c] == sf[c] for c in range(C))
 
 
-def test_iq16_refuses_afsk_and_checks_dtype():
-    with pytest.raises(Exception):
-        SondeBatch(4, 8 * TILE, types=np.array([0, 4, 0, 0], dtype=np.uint8), input_kind=_lib.INPUT_IQ16)
+def test_iq16_checks_dtype_and_survives_silence():
     b = SondeBatch(2, 8 * TILE, input_kind=_lib.INPUT_IQ16)
     with pytest.raises(Exception):
         b.submit(torch.zeros((2, 8 * TILE, 2), dtype=torch.float32, device="cuda"))
     b.submit(torch.zeros((2, 8 * TILE, 2), dtype=torch.int16, device="cuda"))
     assert b.sync() == 0                               # all-zero input: atan2q(0, 0) = 0, nothing decodes, nothing breaks
     b.close()
+
+
+@pytest.mark.parametrize("snr", [10.0, 20.0])
+def test_iq16_tone_demodulated_sondes(snr):
+    """iMet-4 and SRS-C50 (AFSK on FM: tone demodulator kernel in front of kernel A) from 16-bit rows, beside RS41 channels in one batch:
+    frames, bits and loop state of the float path on the same integers; two submits of 16384-sample granules."""
+    per, n = 4, 16384 * 6
+    a = synth.make_imet_batch(per, 2 * n, seed=71, snr_db=snr)
+    c5 = synth.make_c50_batch(per, 2 * n, seed=72, snr_db=snr)
+    r = synth.make_rs41_batch(per, 2 * n, seed=73, ebn0_db=14.0)
+    x16 = quantise(torch.cat([a.iq, c5.iq, r.iq]).cuda())
+    types = np.array([4] * per + [5] * per + [0] * per, dtype=np.uint8)
+    f16, b16, s16 = run(_lib.INPUT_IQ16, x16, types, (48, 48))
+    ff, bf, sf = run(_lib.INPUT_IQ, x16.to(torch.float32), types, (48, 48))
+    assert len(f16) >= 2 * per and np.array_equal(f16, ff)
+    assert {int(t) for t in types[np.unique(f16["channel"])]} == {0, 4, 5}          # every sonde type decoded something
+    for c in range(3 * per):
+        assert b16[c][0] == bf[c][0] and np.array_equal(b16[c][1], bf[c][1]) and s16[c] == sf[c]
 
 
 def test_iq16_from_host_memory():
