@@ -95,6 +95,7 @@ def parse_args():
     ap.add_argument("--flags", type=int, default=None, help="SondeBatchConfig.flags (1: wide, 2: FEC as its own kernel, 4: pipelined class streams; "
                     "default 0, with --mix 4)")
     ap.add_argument("--iq16", action="store_true", help="experiment: ONLY the 16-bit integer IQ entry at --channels x --tiles (prints its record)")
+    ap.add_argument("--iq8", action="store_true", help="experiment: ONLY the 8-bit integer IQ entry at --channels x --tiles (prints its record)")
     ap.add_argument("--no-others", action="store_true", help="headline only: skip the other BASELINE configurations (other_configs), the low-SNR "
                     "line and the rocprofv3 traffic passes that the default run appends")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # the sub-run rocprofv3 --pmc wraps (roofline.traffic)
@@ -369,7 +370,7 @@ def restride(blocks, args):
     return out
 
 
-def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream, ebn0=None, steps=None, warmup=None, iq16=False):
+def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream, ebn0=None, steps=None, warmup=None, iq16=False, iq8=False):
     """One of the non-headline configurations, measured in this process: a compact record for other_configs / low_snr.
     iq16: the same signal as 16-bit integer IQ rows (SONDE_INPUT_IQ16: full scale 8192 per unit amplitude), 4 bytes per sample."""
     import copy
@@ -383,8 +384,11 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     if iq16:
         for i in range(len(blocks)):
             blocks[i] = torch.clamp(torch.round(blocks[i] * 8192.0), -32768, 32767).to(torch.int16)
+    if iq8:                                                    # (SONDE_INPUT_IQ8: the unit-amplitude signal at 16 counts)
+        for i in range(len(blocks)):
+            blocks[i] = torch.clamp(torch.round(blocks[i] * 16.0), -128, 127).to(torch.int8)
     blocks = restride(blocks, args)
-    m = measure(blocks, types, flags, a, local_rank, barrier, stream, input_kind=2 if iq16 else 0)
+    m = measure(blocks, types, flags, a, local_rank, barrier, stream, input_kind=3 if iq8 else (2 if iq16 else 0))
     stride_samples = int(blocks[0].stride(0) // 2)
     del blocks
     torch.cuda.empty_cache()
@@ -392,10 +396,12 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     ms = m["dt"] / a.steps * 1e3
     rec = {"channels": C, "samples_per_channel": n, "channel_stride_samples": stride_samples, "blocks_cycled": NB, "flags": flags, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 4), "value": round(C * n / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s",
-           "step_frac": round(alg_bytes_of(C, n, 4 if iq16 else 8) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "step_frac": round(alg_bytes_of(C, n, 2 if iq8 else (4 if iq16 else 8)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "frames_per_step_steady": round(m["nfr_step"], 2)}
     if iq16:
         rec["input"] = "int16 IQ (SONDE_INPUT_IQ16): 4 bytes per sample; step_frac counts those"
+    if iq8:
+        rec["input"] = "int8 IQ (SONDE_INPUT_IQ8): 2 bytes per sample; step_frac counts those"
     if m["class_ms"]:
         rec["kernel_ms"] = {CLASS_NAMES[k]: round(v, 4) for k, v in m["class_ms"].items()}
     else:
@@ -403,7 +409,7 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     return rec
 
 
-def host_e2e_run(C, tiles, NB, args, local_rank, dev, steps=20, iq16=False):
+def host_e2e_run(C, tiles, NB, args, local_rank, dev, steps=20, iq16=False, iq8=False):
     """The boundary's whole host path at the north_star's per-GPU shape: C channels, one second (24 tiles) at a time, from HOST memory
     (pinned) through sonde_batch_submit_host (PCIe + staging into strided rows), the kernels, and sonde_batch_poll down to
     SondeData fragments with their channel numbers (the reference's callback input, decoder.hpp:59-117, main.cpp:320-331).
@@ -415,10 +421,12 @@ def host_e2e_run(C, tiles, NB, args, local_rank, dev, steps=20, iq16=False):
     blocks, _ = make_blocks("rs41", C, tiles, NB, args.ebn0, dev, seed=1000)
     if iq16:                                  # (16-bit integer IQ in host memory: half the bytes over PCIe)
         blocks = [torch.clamp(torch.round(b * 8192.0), -32768, 32767).to(torch.int16) for b in blocks]
+    if iq8:
+        blocks = [torch.clamp(torch.round(b * 16.0), -128, 127).to(torch.int8) for b in blocks]
     host = [b.cpu().pin_memory().numpy() for b in blocks]
     del blocks
     torch.cuda.empty_cache()
-    batch = SondeBatch(C, n, device=local_rank, input_kind=2 if iq16 else 0)
+    batch = SondeBatch(C, n, device=local_rank, input_kind=3 if iq8 else (2 if iq16 else 0))
     L = batch.L
     cap = 65536
     out = (_lib.SondeData * cap)()
@@ -547,8 +555,8 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
     C, n = args.channels, args.tiles * 2048
     stream = torch.cuda.current_stream().cuda_stream
     kind = "mix" if args.mix else (args.sonde_type if args.sonde_type else "rs41")
-    if args.iq16:
-        rec = small_run(kind, C, args.tiles, args.blocks, args.flags, args, local_rank, dev, barrier, stream, iq16=True, steps=args.steps, warmup=args.warmup)
+    if args.iq16 or args.iq8:
+        rec = small_run(kind, C, args.tiles, args.blocks, args.flags, args, local_rank, dev, barrier, stream, iq16=args.iq16, iq8=args.iq8, steps=args.steps, warmup=args.warmup)
         if rank == 0:
             print(json.dumps(rec))
         return None
@@ -692,12 +700,16 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                                               "samples per step, 4 bytes per sample; frames identical to the float path on the same integers")
         others["cs16_8192x24"] = small_run("rs41", 8192, 24, 5, 0, args, local_rank, dev, barrier, stream, iq16=True)
         others["cs16_8192x24"]["workload"] = "BASELINE configs[4]'s per-GPU shard as 16-bit integer IQ rows: 8192 RS41 channels x 49152 samples per step"
+        others["cs8_1024x96"] = small_run("rs41", 1024, 96, 5, 0, args, local_rank, dev, barrier, stream, iq8=True)
+        others["cs8_1024x96"]["workload"] = "the headline's signal as 8-bit integer IQ rows (SONDE_INPUT_IQ8: 2 bytes per sample, the signal at 16 counts)"
         try:
             others["rt1250_host_e2e"] = host_e2e_run(1250, 24, 5, args, local_rank, dev)
             others["rt1250_host_e2e"]["workload"] = ("the north_star's per-GPU share, end to end through the boundary: 1250 RS41 channels, one second at a time, host "
                                                      "memory in, SondeData fragments out")
             others["rt1250_host_e2e_cs16"] = host_e2e_run(1250, 24, 5, args, local_rank, dev, iq16=True)
             others["rt1250_host_e2e_cs16"]["workload"] = "the same from 16-bit integer IQ in host memory (SONDE_INPUT_IQ16)"
+            others["rt1250_host_e2e_cs8"] = host_e2e_run(1250, 24, 5, args, local_rank, dev, iq8=True)
+            others["rt1250_host_e2e_cs8"]["workload"] = "the same from 8-bit integer IQ in host memory (SONDE_INPUT_IQ8)"
         except Exception as e:                    # (never lets the line fail: the headline above does not depend on it)
             others["rt1250_host_e2e"] = {"error": f"{type(e).__name__}: {e}"}
         for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8x4", 8, 4), ("wideband4_dual", 4, 1), ("wideband8_cs16", 8, 1)):

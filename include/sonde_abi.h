@@ -89,6 +89,9 @@ enum { SONDE_RS41 = 0, SONDE_DFM09 = 1, SONDE_IMS100 = 2, SONDE_M10 = 3, SONDE_I
 
 enum { SONDE_INPUT_IQ = 0,      /* complex64 interleaved I,Q at 48 kS/s (vfo->output level, main.cpp:57) */
        SONDE_INPUT_REAL = 1,    /* float FM-discriminator output at 48 kS/s (decoder.hpp:35 level) */
+       SONDE_INPUT_IQ8 = 3,     /* the same as 8-bit integers: int8 I, int8 Q interleaved, 2 bytes per sample (signed; an offset-binary stream
+                                 * such as RTL-SDR's cu8 becomes this by XOR 0x80 on every byte).  Enough for a sonde channel: with the signal
+                                 * at 8 counts or more nothing is lost against float (profiles/r4_iq16_scale.md).  A quarter of the bytes. */
        SONDE_INPUT_IQ16 = 2 };  /* the vfo->output level as 16-bit integers: int16 I, int16 Q interleaved at 48 kS/s, 4 bytes per sample --
                                  * what SDR hardware and WAV recordings hold before SDR++'s sources convert to float.  Converted in the
                                  * kernel's load path (exactly; no scaling: the discriminator does not depend on the amplitude), so the
@@ -112,7 +115,7 @@ typedef struct {
 	uint32_t       n_channels;
 	const uint8_t *types;            /* n_channels entries of SONDE_*; NULL = all SONDE_RS41 */
 	uint32_t       max_samples;      /* largest samples-per-channel of one submit (multiple of SONDE_TILE) */
-	int32_t        input_kind;       /* SONDE_INPUT_IQ, SONDE_INPUT_REAL or SONDE_INPUT_IQ16 */
+	int32_t        input_kind;       /* SONDE_INPUT_IQ, SONDE_INPUT_REAL, SONDE_INPUT_IQ16 or SONDE_INPUT_IQ8 */
 	int32_t        device;           /* HIP device ordinal */
 	uint32_t       flags;            /* SONDE_FLAG_*; 0 = defaults */
 } SondeBatchConfig;
@@ -159,7 +162,7 @@ void sonde_batch_destroy(SondeBatch *b);
  * its own staging buffer: the next power of two in bytes where that costs at most a third more memory (1.5 MiB rows -> 2 MiB),
  * else the next odd multiple of 64 KiB (rows of 1.01 MiB -> 1.0625 MiB, not 2 MiB); rows below 64 KiB stay back to back. */
 size_t sonde_row_stride(size_t n_samples, int input_kind);
-/* bytes per sample (element) of an input kind: 8 (IQ), 4 (REAL, IQ16) */
+/* bytes per sample (element) of an input kind: 8 (IQ), 4 (REAL, IQ16), 2 (IQ8) */
 size_t sonde_sample_bytes(int input_kind);
 int  sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream);
 /* Same, from HOST memory (staged through an internal pinned/device buffer; PCIe-inclusive). */

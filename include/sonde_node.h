@@ -36,7 +36,7 @@ typedef struct {
 	uint32_t       n_channels;    /* all channels of the node */
 	const uint8_t *types;         /* n_channels entries of SONDE_*; NULL = all SONDE_RS41 */
 	uint32_t       max_samples;   /* largest samples-per-channel of one submit (multiple of SONDE_TILE) */
-	int32_t        input_kind;    /* SONDE_INPUT_IQ, SONDE_INPUT_REAL or SONDE_INPUT_IQ16 (half the bytes over xGMI) */
+	int32_t        input_kind;    /* SONDE_INPUT_IQ, SONDE_INPUT_REAL, SONDE_INPUT_IQ16 or SONDE_INPUT_IQ8 (a half / a quarter of the bytes over xGMI) */
 	uint32_t       flags;         /* SONDE_FLAG_* of the per-device batches */
 } SondeNodeConfig;
 

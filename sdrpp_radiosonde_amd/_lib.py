@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SONDE_MI355_LIB") or os.path.join(PKG_DIR, "libsonde_
 TILE = 2048
 FRAME_MAX = 528
 (RS41, DFM09, IMS100, M10, IMET4, C50, MRZN1) = range(7)
-INPUT_IQ, INPUT_REAL, INPUT_IQ16 = 0, 1, 2
+INPUT_IQ, INPUT_REAL, INPUT_IQ16, INPUT_IQ8 = 0, 1, 2, 3
 PROCEED, PARSED = 0, 1
 DATA_SEQ, DATA_POS, DATA_SPEED, DATA_TIME, DATA_PTU, DATA_SERIAL, DATA_SHUTDOWN, DATA_OZONE = (1 << i for i in range(8))
 

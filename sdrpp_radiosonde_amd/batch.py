@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FRAME_DTYPE, INPUT_IQ, INPUT_IQ16, INPUT_REAL, TILE
+from ._lib import FRAME_DTYPE, INPUT_IQ, INPUT_IQ8, INPUT_IQ16, INPUT_REAL, TILE
 
 
 class SondeError(RuntimeError):
@@ -60,15 +60,15 @@ class SondeBatch:
         n = shape[1]
         if shape[0] != self.n_channels:
             raise SondeError("first dimension must be n_channels")
-        is_iq = self.input_kind in (INPUT_IQ, INPUT_IQ16)
+        is_iq = self.input_kind in (INPUT_IQ, INPUT_IQ16, INPUT_IQ8)
         if is_iq and (len(shape) != 3 or shape[2] != 2):
-            raise SondeError("IQ input must be [C, n, 2] (float32, or int16 for INPUT_IQ16)")
+            raise SondeError("IQ input must be [C, n, 2] (float32; int16 for INPUT_IQ16, int8 for INPUT_IQ8)")
         if not is_iq and len(shape) != 2:
             raise SondeError("real input must be [C, n] float32")
         # the C side sees only a pointer: check what it cannot (dtype, device, inner layout)
         dt = str(getattr(samples, "dtype", ""))
-        want = "int16" if self.input_kind == INPUT_IQ16 else "float32"
-        if not dt.endswith(want):
+        want = {INPUT_IQ16: "int16", INPUT_IQ8: "int8"}.get(self.input_kind, "float32")
+        if not dt.endswith(want) or dt.endswith("u" + want):
             raise SondeError(f"samples must be {want}, got {dt}")
         dev = getattr(samples, "device", None)
         if dev is None or getattr(dev, "type", "") != "cuda":
@@ -83,9 +83,9 @@ class SondeBatch:
         self._chk(self.L.sonde_batch_submit(self.h, C.c_void_p(samples.data_ptr()), n, stride, C.c_void_p(stream or 0)))
 
     def submit_host(self, samples: np.ndarray):
-        want = np.int16 if self.input_kind == INPUT_IQ16 else np.float32
-        if self.input_kind == INPUT_IQ16 and np.asarray(samples).dtype != np.int16:
-            raise SondeError(f"samples must be int16 for INPUT_IQ16, got {np.asarray(samples).dtype} (no silent conversion)")
+        want = {INPUT_IQ16: np.int16, INPUT_IQ8: np.int8}.get(self.input_kind, np.float32)
+        if want is not np.float32 and np.asarray(samples).dtype != want:
+            raise SondeError(f"samples must be {np.dtype(want).name} for this input kind, got {np.asarray(samples).dtype} (no silent conversion)")
         samples = np.ascontiguousarray(samples, dtype=want)
         n = samples.shape[1]
         self._chk(self.L.sonde_batch_submit_host(self.h, samples.ctypes.data_as(C.c_void_p), n, n))
@@ -175,7 +175,7 @@ def strided_rows(x, stride: int | None = None):
     view of the padded allocation: what submit() takes."""
     import torch
     n = x.shape[1]
-    st = stride or row_stride(n, kind=(INPUT_IQ16 if x.dtype == torch.int16 else INPUT_IQ) if x.dim() == 3 else INPUT_REAL)
+    st = stride or row_stride(n, kind={torch.int16: INPUT_IQ16, torch.int8: INPUT_IQ8}.get(x.dtype, INPUT_IQ) if x.dim() == 3 else INPUT_REAL)
     if st == n:
         return x
     buf = torch.empty((x.shape[0], st) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)

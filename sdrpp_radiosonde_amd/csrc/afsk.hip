@@ -14,7 +14,7 @@
 
 #define AF_T 256      // threads = block sums per 2048-sample tile
 
-template <int KIND, int PER, int NW>    // KIND: 0 real (discriminator samples), 1 complex64, 2 int16 I, Q pairs (SD_IN_IQ16: converted exactly, no scaling); mixer table period; boxcar length in blocks of 8 samples (<= 5)
+template <int KIND, int PER, int NW>    // KIND: 0 real (discriminator samples), 1 complex64, 2 int16 I, Q pairs, 3 int8 pairs (SD_IN_IQ16 / IQ8: converted exactly, no scaling); mixer table period; boxcar length in blocks of 8 samples (<= 5)
 __global__ __launch_bounds__(AF_T) void sd_afsk_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles, const uint32_t *__restrict__ chlist,
 	SdAfskState *__restrict__ astates, const float2 *__restrict__ wtab, float *__restrict__ out, size_t out_stride)
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(AF_T) void sd_afsk_kernel(
 	const int t = threadIdx.x;
 	const uint32_t ch = chlist[blockIdx.x];
 	SdAfskState st = astates[ch];
-	const float *src = in + (KIND == 1 ? 2 : 1) * (size_t)ch * ch_stride;      // (4-byte elements for real input and for int16 pairs)
+	const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(in) + (size_t)ch * ch_stride * (KIND == 1 ? 8 : (KIND == 3 ? 2 : 4)));
 	float *dst = out + (size_t)blockIdx.x * out_stride;
 	if (t < 4) bs[t] = make_float2(st.b[t][0], st.b[t][1]);
 	if (t == 0) zs[0] = make_float2(st.z[0], st.z[1]);
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(AF_T) void sd_afsk_kernel(
 			const uint32_t *x16 = reinterpret_cast<const uint32_t *>(src) + s0;
 			auto sample = [&](int i) -> float2 {
 				if (KIND == 2) { const uint32_t q = x16[i]; return make_float2((float)(int16_t)(q & 0xffffu), (float)((int32_t)q >> 16)); }
+				if (KIND == 3) { const uint16_t q = (reinterpret_cast<const uint16_t *>(src) + s0)[i]; return make_float2((float)(int8_t)(q & 0xffu), (float)(int8_t)(q >> 8)); }
 				return x[i];
 			};
 			float2 p = s0 ? sample(-1) : last;
@@ -87,13 +88,13 @@ __global__ __launch_bounds__(AF_T) void sd_afsk_kernel(
 	if (IS_IQ && t == AF_T - 1) { astates[ch].iq_last[0] = last.x; astates[ch].iq_last[1] = last.y; }
 }
 
-void sd_launch_afsk(int type, int kind /* 0 real, 1 complex64, 2 int16 IQ */, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
+void sd_launch_afsk(int type, int kind /* 0 real, 1 complex64, 2 int16 IQ, 3 int8 IQ */, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,
 	const uint32_t *chlist, SdAfskState *astates, const float *wtab, float *out, size_t out_stride)
 {
 #define AF_GO(IQ, PER, NW) hipLaunchKernelGGL((sd_afsk_kernel<IQ, PER, NW>), dim3(n_list), dim3(AF_T), 0, stream, in, ch_stride, n_tiles, chlist, astates, \
 		(const float2 *)wtab, out, out_stride)
-	if (type == SONDE_C50) { if (kind == 2) AF_GO(2, SD_C50_PER, 2); else if (kind == 1) AF_GO(1, SD_C50_PER, 2); else AF_GO(0, SD_C50_PER, 2); }
-	else { if (kind == 2) AF_GO(2, SD_AF_PER, 5); else if (kind == 1) AF_GO(1, SD_AF_PER, 5); else AF_GO(0, SD_AF_PER, 5); }
+	if (type == SONDE_C50) { if (kind == 3) AF_GO(3, SD_C50_PER, 2); else if (kind == 2) AF_GO(2, SD_C50_PER, 2); else if (kind == 1) AF_GO(1, SD_C50_PER, 2); else AF_GO(0, SD_C50_PER, 2); }
+	else { if (kind == 3) AF_GO(3, SD_AF_PER, 5); else if (kind == 2) AF_GO(2, SD_AF_PER, 5); else if (kind == 1) AF_GO(1, SD_AF_PER, 5); else AF_GO(0, SD_AF_PER, 5); }
 #undef AF_GO
 }
 

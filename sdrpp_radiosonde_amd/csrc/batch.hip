@@ -224,7 +224,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	*out = nullptr;
 	if (cfg->n_channels == 0) return fail("sonde_batch_create: n_channels == 0");
 	if (cfg->max_samples == 0 || cfg->max_samples % SONDE_TILE) return fail("sonde_batch_create: max_samples must be a positive multiple of SONDE_TILE");
-	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL && cfg->input_kind != SONDE_INPUT_IQ16) return fail("sonde_batch_create: bad input_kind");
+	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL && cfg->input_kind != SONDE_INPUT_IQ16 && cfg->input_kind != SONDE_INPUT_IQ8)
+		return fail("sonde_batch_create: bad input_kind");
 	int ndev = 0;
 	HIPCHK(hipGetDeviceCount(&ndev));
 	if (cfg->device < 0 || cfg->device >= ndev) return fail("sonde_batch_create: no such HIP device");
@@ -508,8 +509,8 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	if (n_samples == 0 || n_samples % b->granule || n_samples > b->max_samples) return fail("sonde_batch_submit: n_samples must be a multiple of SONDE_TILE (16384 with iMet channels) and <= max_samples");
 	if (channel_stride < n_samples) return fail("sonde_batch_submit: channel_stride < n_samples");
 	// the kernels read 16 bytes per lane: every channel row must start on a 16-byte boundary
-	if (((uintptr_t)samples & 15u) || channel_stride % (b->input_kind == SONDE_INPUT_IQ ? 2 : 4))
-		return fail("sonde_batch_submit: samples must be 16-byte aligned and channel_stride a multiple of 2 (IQ) / 4 (real, 16-bit IQ) samples");
+	if (((uintptr_t)samples & 15u) || channel_stride % (b->input_kind == SONDE_INPUT_IQ ? 2 : (b->input_kind == SONDE_INPUT_IQ8 ? 8 : 4)))
+		return fail("sonde_batch_submit: samples must be 16-byte aligned and channel_stride a multiple of 2 (IQ) / 4 (real, 16-bit IQ) / 8 (8-bit IQ) samples");
 	return submit_impl(b, samples, n_samples, channel_stride, stream_, nullptr);
 }
 
@@ -549,7 +550,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	b->n_submits++;
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	if (timed) HIPCHK(hipEventRecord(ev[0], stream));
-	const int iq = bins_in ? SD_IN_BINS : (b->input_kind == SONDE_INPUT_IQ ? SD_IN_IQ : (b->input_kind == SONDE_INPUT_IQ16 ? SD_IN_IQ16 : SD_IN_REAL));      // what the rows hold
+	const int iq = bins_in ? SD_IN_BINS : (b->input_kind == SONDE_INPUT_IQ ? SD_IN_IQ : (b->input_kind == SONDE_INPUT_IQ16 ? SD_IN_IQ16 : (b->input_kind == SONDE_INPUT_IQ8 ? SD_IN_IQ8 : SD_IN_REAL)));      // what the rows hold
 	const int slot = (int)(b->tickets & 1);
 	SondeFrame *const d_frames = b->d_frames2[slot];
 	uint32_t *const d_counts = b->d_counts2[slot];
@@ -608,7 +609,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 				// AFSK channels: tone demodulator into 6 kS/s scratch rows, then kernel A's real-input path over those rows
 				// (one kernel-A tile = 2048 scratch samples = 16384 input samples)
 				float *rows = b->d_afq + u.row0 * (size_t)(b->max_samples / SD_AF_DEC);
-				sd_launch_afsk(u.type, iq == SD_IN_IQ ? 1 : (iq == SD_IN_IQ16 ? 2 : 0), u.n, u.st, (const float *)samples, channel_stride, n_tiles,
+				sd_launch_afsk(u.type, iq == SD_IN_IQ ? 1 : (iq == SD_IN_IQ16 ? 2 : (iq == SD_IN_IQ8 ? 3 : 0)), u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_chlist[u.type], b->d_astates, u.type == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
 				sd_launch_demod(SD_IN_REAL, 1, 16, u.n, u.st, rows, nq, (int)(nq / SONDE_TILE),
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo, nullptr, u.type);
@@ -656,7 +657,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 // than the contiguous layout: how the rows that are in flight together spread over the HBM channels.
 extern "C" size_t sonde_sample_bytes(int input_kind)
 {
-	return input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : (input_kind == SONDE_INPUT_IQ16 ? 2 * sizeof(int16_t) : sizeof(float));
+	return input_kind == SONDE_INPUT_IQ ? 2 * sizeof(float) : (input_kind == SONDE_INPUT_IQ16 ? 2 * sizeof(int16_t) : (input_kind == SONDE_INPUT_IQ8 ? 2 * sizeof(int8_t) : sizeof(float)));
 }
 
 extern "C" size_t sonde_row_stride(size_t n_samples, int input_kind)

@@ -30,6 +30,25 @@ typedef float sd_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned sd_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned sd_u32x4 __attribute__((ext_vector_type(4)));
 typedef short sd_i16x2 __attribute__((ext_vector_type(2)));
+// SD_IN_IQ8: two complex samples of 8-bit integers (I0 Q0 I1 Q1) -> the float4 of the float path (exact, no scaling)
+static __device__ __forceinline__ float4 sd_cs8_f4(uint32_t q)
+{
+	return make_float4((float)(int8_t)(q & 0xffu), (float)(int8_t)((q >> 8) & 0xffu), (float)(int8_t)((q >> 16) & 0xffu), (float)((int32_t)q >> 24));
+}
+// SD_IN_IQ8, 4:1 class: one 8-byte load = four complex samples = one decimated sample: v_dot4c_i32_i8 against (1, 0, 1, 0) / (0, 1, 0, 1)
+static __device__ __forceinline__ float2 sd_cs8_sum4(uint2 q)
+{
+	int i = 0, j = 0;
+	i = __builtin_amdgcn_sdot4((int)q.x, 0x00010001, i, false); j = __builtin_amdgcn_sdot4((int)q.x, 0x01000100, j, false);
+	i = __builtin_amdgcn_sdot4((int)q.y, 0x00010001, i, false); j = __builtin_amdgcn_sdot4((int)q.y, 0x01000100, j, false);
+	return make_float2((float)i, (float)j);
+}
+static __device__ __forceinline__ float2 sd_cs8_sum4_uniform(uint2 q)      // (wave-uniform operands: scalar unit, as sd_cs16_sum4_uniform)
+{
+	const int i = (int)(int8_t)(q.x & 0xffu) + (int)(int8_t)((q.x >> 16) & 0xffu) + (int)(int8_t)(q.y & 0xffu) + (int)(int8_t)((q.y >> 16) & 0xffu);
+	const int j = (int)(int8_t)((q.x >> 8) & 0xffu) + ((int32_t)q.x >> 24) + (int)(int8_t)((q.y >> 8) & 0xffu) + ((int32_t)q.y >> 24);
+	return make_float2((float)i, (float)j);
+}
 // SD_IN_IQ16, 4:1 class: one 16-byte load = four complex samples = ONE decimated sample: I and Q sums in integers (exact, as the
 // float sums of the float path are: |sum| < 2^17), v_dot2c_i32_i16 against (1, 0) / (0, 1) extracts and adds in one instruction
 static __device__ __forceinline__ float2 sd_cs16_sum4(uint4 q)
@@ -182,10 +201,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
 	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, const SdBinsIn *__restrict__ bins_in, int utype)
 {
-	constexpr bool IQ16 = IN == SD_IN_IQ16, IS_IQ = IN == SD_IN_IQ || IQ16, BINS = IN == SD_IN_BINS;
-	constexpr bool IQ16D4 = IQ16 && DEC == 4;                                 // 16-byte loads of four samples = one decimated sample each
-	// what one lane holds per load: two input samples (IQ; four in the 16-bit 4:1 class), four (real)
-	using LoadT = typename std::conditional<IQ16, typename std::conditional<IQ16D4, uint4, uint2>::type, float4>::type;
+	// integer IQ rows: IQ16 = int16 pairs (SD_IN_IQ16) OR int8 pairs (SD_IN_IQ8): one code path, IQ8 picks the element size
+	constexpr bool IQ8 = IN == SD_IN_IQ8, IQ16 = IN == SD_IN_IQ16 || IQ8, IS_IQ = IN == SD_IN_IQ || IQ16, BINS = IN == SD_IN_BINS;
+	constexpr bool IQ16D4 = IQ16 && DEC == 4;                                 // one load of four samples = one decimated sample each (16 bytes; int8: 8)
+	// what one lane holds per load: two input samples (IQ; four in the integer 4:1 classes), four (real)
+	using LoadT = typename std::conditional<IQ8, typename std::conditional<IQ16D4, uint2, uint32_t>::type,
+	              typename std::conditional<IQ16, typename std::conditional<IQ16D4, uint4, uint2>::type, float4>::type>::type;
 	__shared__ __attribute__((aligned(16))) DemodLds s;
 
 	const int tid = threadIdx.x;
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	constexpr int NLD = (IS_IQ && !IQ16D4) ? 4 : 2;     // loads per thread per tile (float4; SD_IN_IQ16: 8 bytes, the same two samples, or 16 bytes, four)
 	constexpr int TILE_F4 = ((IS_IQ && !IQ16D4) ? 2 : 1) * SD_TILE / 4;      // load units (LoadT) per tile
 	// (ch_stride counts samples: 8 bytes each for complex64, 4 for real input and for 16-bit IQ)
-	const LoadT *src = reinterpret_cast<const LoadT *>(in + ((IS_IQ && !IQ16) ? 2 : 1) * (size_t)row * ch_stride);
+	const LoadT *src = reinterpret_cast<const LoadT *>(reinterpret_cast<const char *>(in) + (size_t)row * ch_stride * (IQ8 ? 2 : ((IS_IQ && !IQ16) ? 8 : 4)));
 	LoadT va[NLD], vb[NLD];                // two register sets: tiles are prefetched two phases ahead
 	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
 	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
@@ -211,7 +232,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	auto load_vec = [&](int tile, LoadT (&v)[NLD]) {
 #pragma unroll
 		for (int r = 0; r < NLD; r++) {                    // read-once data: streaming (nontemporal) loads
-			if constexpr (IQ16D4) {
+			if constexpr (IQ8 && IQ16D4) {
+				const sd_u32x2 q = __builtin_nontemporal_load(reinterpret_cast<const sd_u32x2 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
+				v[r] = make_uint2(q.x, q.y);
+			} else if constexpr (IQ8) {
+				v[r] = __builtin_nontemporal_load(src + (size_t)tile * TILE_F4 + f4_index(r));
+			} else if constexpr (IQ16D4) {
 				const sd_u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const sd_u32x4 *>(src + (size_t)tile * TILE_F4 + f4_index(r)));
 				v[r] = make_uint4(q.x, q.y, q.z, q.w);
 			} else if constexpr (IQ16) {
@@ -355,7 +381,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 
 	// ================================================================ discriminator role (waves 4-7)
 	LoadT pa, pb, qa, qb;                  // the float4s (two input samples each) just before the wave's first one: -1 (pa, pb), -2 (qa, qb)
-	if constexpr (IQ16D4) { pa = pb = qa = qb = make_uint4(0u, 0u, 0u, 0u); }
+	if constexpr (IQ8 && IQ16D4) { pa = pb = qa = qb = make_uint2(0u, 0u); }
+	else if constexpr (IQ8) { pa = pb = qa = qb = 0u; }
+	else if constexpr (IQ16D4) { pa = pb = qa = qb = make_uint4(0u, 0u, 0u, 0u); }
 	else if constexpr (IQ16) { pa = pb = qa = qb = make_uint2(0u, 0u); }
 	else { qa = qb = make_float4(-0.0f, -0.0f, -0.0f, -0.0f); }
 	float2 last_iq = make_float2(st.iq_last[0], st.iq_last[1]);
@@ -395,12 +423,14 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		const float rc = __builtin_fmaf(-afc_u, afc_u, 1.0f), rs = afc_u + afc_u;
 		if constexpr (IQ16D4) {
 			// 16-bit input, 4:1: load g of lane l IS decimated sample 128 kw + 64 g + l (no exchange between lanes as in the float path)
-			float2 c = sd_cs16_sum4_uniform(pvraw);
+			float2 c;
+			if constexpr (IQ8) c = sd_cs8_sum4_uniform(pvraw); else c = sd_cs16_sum4_uniform(pvraw);
 			float cx = c.x, cy = c.y;
 			if (tile == 0 && kw == 0) { cx = st.iq_last[0]; cy = st.iq_last[1]; }       // the carried (decimated) sample
 #pragma unroll
 			for (int g = 0; g < NLD; g++) {
-				const float2 z = sd_cs16_sum4(vraw[g]);
+				float2 z;
+				if constexpr (IQ8) z = sd_cs8_sum4(vraw[g]); else z = sd_cs16_sum4(vraw[g]);
 				const float px = sd_wave_shr1(z.x, cx), py = sd_wave_shr1(z.y, cy);
 				store_one(s, b, (uint32_t)(128 * kw + 64 * g + lane), sd_disc_rot(z.x, z.y, px, py, rc, rs));
 				cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z.x), 63));
@@ -411,6 +441,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		}
 		float4 v[NLD], pv, pw;
 		if constexpr (IQ16D4) {
+		} else if constexpr (IQ8) {
+#pragma unroll
+			for (int r = 0; r < NLD; r++) v[r] = sd_cs8_f4(vraw[r]);
+			pv = sd_cs8_f4(pvraw); pw = sd_cs8_f4(pwraw);
 		} else if constexpr (IQ16) {
 #pragma unroll
 			for (int r = 0; r < NLD; r++) v[r] = sd_cs16_f4(vraw[r]);
@@ -900,6 +934,8 @@ void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStr
 		// (one class, no AFSK: always the plain launch over all bins)
 		hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, false, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
 	}
+	else if (in_kind == SD_IN_IQ8 && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ8, false);
+	else if (in_kind == SD_IN_IQ8) SD_DEMOD_LAUNCH(SD_IN_IQ8, true);
 	else if (in_kind == SD_IN_IQ16 && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ16, false);
 	else if (in_kind == SD_IN_IQ16) SD_DEMOD_LAUNCH(SD_IN_IQ16, true);
 	else if (in_kind == SD_IN_IQ && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ, false);

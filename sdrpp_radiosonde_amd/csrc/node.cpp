@@ -70,7 +70,8 @@ extern "C" int sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out)
 	*out = nullptr;
 	if (cfg->n_devices < 1 || cfg->n_devices > 16 || cfg->ingest >= cfg->n_devices) return nfail("sonde_node_create: n_devices must be 1..16 and ingest one of them");
 	if (cfg->n_channels < cfg->n_devices) return nfail("sonde_node_create: fewer channels than devices");
-	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL && cfg->input_kind != SONDE_INPUT_IQ16) return nfail("sonde_node_create: bad input_kind");
+	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL && cfg->input_kind != SONDE_INPUT_IQ16 && cfg->input_kind != SONDE_INPUT_IQ8)
+		return nfail("sonde_node_create: bad input_kind");
 	int ndev = 0;
 	HCHK(hipGetDeviceCount(&ndev));
 	SondeNode *n = new SondeNode;

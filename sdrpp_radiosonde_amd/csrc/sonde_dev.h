@@ -28,6 +28,7 @@
                             // 12/5 resampler - 4:1 decimator in the kernel (SPEC 3.5b)
 #define SD_IN_IQ16 3        // 48 kS/s complex samples as 16-bit integers (I, Q interleaved: what SDR hardware and WAV recordings hold): half the
                             // bytes of SD_IN_IQ per sample; converted exactly (int16 -> float, no scaling) in the load path, then SD_IN_IQ's arithmetic
+#define SD_IN_IQ8  4        // the same as 8-bit integers (int8 I, int8 Q): 2 bytes per sample
 #define SD_RS_KT_LD 20      // row stride of the composite taps (17 in use)
 #define SD_RS_KT    17
 struct SdBinsIn {           // SD_IN_BINS: composite taps and the state carried from block to block (device pointers)

@@ -71,7 +71,8 @@ def test_argument_validation(lib):
 def test_input_kinds_sample_bytes_and_row_stride(lib):
     """complex64, float discriminator samples, 16-bit integer IQ: element sizes, and the recommended row stride in elements
     (the same BYTES for the same row: 1.5 MiB rows go 2 MiB apart whatever they hold)"""
-    assert [lib.sonde_sample_bytes(k) for k in (_lib.INPUT_IQ, _lib.INPUT_REAL, _lib.INPUT_IQ16)] == [8, 4, 4]
+    assert [lib.sonde_sample_bytes(k) for k in (_lib.INPUT_IQ, _lib.INPUT_REAL, _lib.INPUT_IQ16, _lib.INPUT_IQ8)] == [8, 4, 4, 2]
+    assert lib.sonde_row_stride(2 * 2048 * 96, _lib.INPUT_IQ8) == 524288        # 0.75 MiB -> 1 MiB
     n = 2048 * 96
     assert lib.sonde_row_stride(n, _lib.INPUT_IQ) == 262144            # 1.5 MiB -> 2 MiB
     assert lib.sonde_row_stride(n, _lib.INPUT_IQ16) == 262144          # 0.75 MiB -> 1 MiB

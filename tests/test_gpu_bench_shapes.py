@@ -8,6 +8,7 @@ other_configs.wideband8x4           tests/test_channelizer.py::test_fused_channe
 other_configs.rt1250_host_e2e       test_host_path_at_the_target_shape                 (1250 channels x 1 s from host memory to SondeData fragments)
 other_configs.cs16_1024x96, cs16_8192x24   test_16_bit_rows_at_the_bench_shapes[1024-96 / 8192-24]  (SONDE_INPUT_IQ16 rows on the recommended stride)
 other_configs.rt1250_host_e2e_cs16  test_16_bit_rows_at_the_bench_shapes[1250-24] (+ host staging: tests/test_gpu_iq16.py::test_iq16_from_host_memory)
+other_configs.cs8_1024x96, rt1250_host_e2e_cs8   test_16_bit_rows_at_the_bench_shapes[1024-96-8 / 1250-24-8]  (SONDE_INPUT_IQ8)
 other_configs.wideband8_cs16        tests/test_channelizer.py::test_channelizer_takes_16_bit_wideband_blocks (two streams; the 8-stream grid: [4-8] above)
 
 What a frame stream must equal: /root/reference/src/decode/decoder.hpp:61 (one X_decode call sequence per channel); the oracle
@@ -174,16 +175,16 @@ def test_host_path_at_the_target_shape(oracle):
     assert sum(len(v) for v in seqs.values()) == len(clean)
 
 
-@pytest.mark.parametrize("C,tiles", [(1024, 96), (8192, 24), (1250, 24)])
-def test_16_bit_rows_at_the_bench_shapes(oracle, C, tiles):
+@pytest.mark.parametrize("C,tiles,bits", [(1024, 96, 16), (8192, 24, 16), (1250, 24, 16), (1024, 96, 8), (1250, 24, 8)])
+def test_16_bit_rows_at_the_bench_shapes(oracle, C, tiles, bits):
     """SONDE_INPUT_IQ16 at the shapes of other_configs.cs16_*: the bench's own quantisation (full scale 8192 per unit amplitude), rows on the
     recommended stride, two consecutive submits.  Every frame byte for byte the oracle's on the same integers as floats."""
     from sdrpp_radiosonde_amd import _lib
     n = tiles * TILE
     sb = synth.make_rs41_batch(C, 2 * n, seed=910 + tiles, ebn0_db=14.0, device="cuda:0")
-    x16 = torch.clamp(torch.round(sb.iq * 8192.0), -32768, 32767).to(torch.int16)
+    x16 = torch.clamp(torch.round(sb.iq * 8192.0), -32768, 32767).to(torch.int16) if bits == 16 else torch.clamp(torch.round(sb.iq * 16.0), -128, 127).to(torch.int8)
     del sb
-    b = SondeBatch(C, n, input_kind=_lib.INPUT_IQ16)
+    b = SondeBatch(C, n, input_kind=_lib.INPUT_IQ16 if bits == 16 else _lib.INPUT_IQ8)
     got = []
     for k in range(2):
         b.submit(strided_rows(x16[:, k * n: (k + 1) * n].contiguous()))

@@ -19,9 +19,9 @@ def test_mixed_batch_low_snr_bit_exact(ebn0, seed, flags, cfo):
     run_mixed(ebn0, seed, check_coverage=True, flags=flags, cfo_max_hz=cfo)
 
 
-@pytest.mark.parametrize("ebn0,seed,flags", [(7.5, 5, 0), (11.0, 6, 4)])
-def test_mixed_batch_as_16_bit_iq_bit_exact(ebn0, seed, flags):
-    run_mixed(ebn0, seed, check_coverage=False, flags=flags, cfo_max_hz=1500.0, iq16=True)
+@pytest.mark.parametrize("ebn0,seed,flags,bits", [(7.5, 5, 0, 16), (11.0, 6, 4, 16), (9.0, 7, 4, 8), (12.0, 8, 0, 8)])
+def test_mixed_batch_as_16_bit_iq_bit_exact(ebn0, seed, flags, bits):
+    run_mixed(ebn0, seed, check_coverage=False, flags=flags, cfo_max_hz=1500.0, iq16=bits if bits == 8 else True)
 
 
 def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0, iq16=False):
@@ -44,10 +44,13 @@ def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0, iq16=False)
     perm = np.random.default_rng(seed).permutation(len(types))
     iq, types = iq[torch.from_numpy(perm)].contiguous(), types[perm]
     C = len(types)
-    if iq16:
+    if iq16 == 8:                                       # (iq16 = 8: int8 rows, SONDE_INPUT_IQ8, the unit-amplitude signal at 12 counts)
+        q = torch.clamp(torch.round(iq * 12.0), -128, 127).to(torch.int8)
+        iq = q.to(torch.float32)
+    elif iq16:
         q = torch.clamp(torch.round(iq * 4096.0), -32768, 32767).to(torch.int16)
         iq = q.to(torch.float32)
-    b = SondeBatch(C, n, types=types, flags=flags, input_kind=2 if iq16 else 0)
+    b = SondeBatch(C, n, types=types, flags=flags, input_kind=(3 if iq16 == 8 else 2) if iq16 else 0)
     dev = q.cuda() if iq16 else iq.cuda()
     chs = [oracle_lib.Channel(int(types[c]), c) for c in range(C)]
     x = iq.numpy()
