@@ -272,8 +272,8 @@ uint32_t    sonde_chan_channels(const SondeChannelizer *c);      /* decoder chan
  * kernel of their own (then sonde_chan_read can return the rows: parity tests).  Call before the first submit; returns the mode
  * in force (1 fused, 0 not); on < 0 only asks. */
 int         sonde_chan_set_fused(SondeChannelizer *c, int on);
-/* What sonde_chan_submit's block holds: SONDE_INPUT_IQ (complex64; the default) or SONDE_INPUT_IQ16 (int16 I, int16 Q interleaved: the
- * format a 10 MS/s receiver delivers -- half the bytes over PCIe and HBM; converted exactly, no scaling, on the way into the filter
+/* What sonde_chan_submit's block holds: SONDE_INPUT_IQ (complex64; the default), SONDE_INPUT_IQ16 (int16 I, int16 Q interleaved) or
+ * SONDE_INPUT_IQ8 (int8 pairs): the formats 10 MS/s receivers deliver -- a half / a quarter of the bytes over PCIe and HBM; converted exactly, no scaling, on the way into the filter
  * bank's window, so phases and frames are those of the float block holding the same integers).  Call before the first submit;
  * returns the kind in force (or -1). */
 int         sonde_chan_set_input(SondeChannelizer *c, int input_kind);

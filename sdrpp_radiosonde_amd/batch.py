@@ -213,7 +213,7 @@ class SondeChannelizer:
         self.fused = bool(self.L.sonde_chan_set_fused(self.h, 1 if fused else 0)) if fused is not None else bool(self.L.sonde_chan_set_fused(self.h, -1))
         # overlap (an option, off by default): filter bank of submit k+1 beside the decoder of submit k, on internal streams
         self.overlap = bool(self.L.sonde_chan_set_overlap(self.h, 1)) if overlap else False
-        # input_kind: INPUT_IQ (complex64 blocks) or INPUT_IQ16 (int16 I, Q pairs: the receiver's own format)
+        # input_kind: INPUT_IQ (complex64 blocks), INPUT_IQ16 (int16 I, Q pairs) or INPUT_IQ8 (int8 pairs): the receiver's own format
         self.input_kind = int(self.L.sonde_chan_set_input(self.h, input_kind))
         if self.input_kind != input_kind:
             raise SondeError("sonde_chan_set_input: input kind not accepted")
@@ -228,8 +228,8 @@ class SondeChannelizer:
     def submit(self, iq, stream: int | None = None):
         assert tuple(iq.shape) in ((self.samples_per_submit, 2), (self.n_streams, self.samples_per_submit, 2)) and iq.is_contiguous()
         assert self.n_streams == 1 or iq.dim() == 3
-        want = "int16" if self.input_kind == INPUT_IQ16 else "float32"
-        if not str(iq.dtype).endswith(want):
+        want = {INPUT_IQ16: "int16", INPUT_IQ8: "int8"}.get(self.input_kind, "float32")
+        if not str(iq.dtype).endswith(want) or str(iq.dtype).endswith("u" + want):
             raise SondeError(f"wideband block must be {want}, got {iq.dtype}")
         self._keep = iq
         if self.L.sonde_chan_submit(self.h, C.c_void_p(iq.data_ptr()), self.samples_per_submit, C.c_void_p(stream or 0)) != 0:

@@ -110,7 +110,8 @@ __device__ __forceinline__ void pfb_fft512(float2 *fb, const float2 *s_tw, int l
 
 // I16: the wideband stream (and the carried history) as 16-bit integer I, Q pairs -- what a 10 MS/s receiver delivers -- converted on
 // the way into LDS (exactly, no scaling: a phase does not see the amplitude); everything behind the window is the float path
-template <bool I16>
+// (IK: 0 complex64, 1 int16 pairs, 2 int8 pairs -- a 10 MS/s 8-bit receiver's format)
+template <int IK>
 __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
                                                            const void *__restrict__ hist_in_all_, void *__restrict__ hist_out_all_,
                                                            const float *__restrict__ h_even, const float2 *__restrict__ tw,
@@ -132,8 +133,9 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 	const bool odd = dual && (sidx & 1u);
 	const uint32_t phys = dual ? sidx >> 1 : sidx;
 	const float *h = odd ? h_odd : h_even;
-	using ET = typename std::conditional<I16, uint32_t, float2>::type;       // one complex sample
-	using PT = typename std::conditional<I16, uint2, float4>::type;          // a pair of them: what a staging load moves
+	constexpr bool I16 = IK == 1, I8 = IK == 2;
+	using ET = typename std::conditional<I8, uint16_t, typename std::conditional<I16, uint32_t, float2>::type>::type;       // one complex sample
+	using PT = typename std::conditional<I8, uint32_t, typename std::conditional<I16, uint2, float4>::type>::type;          // a pair of them: what a staging load moves
 	const ET *iq = reinterpret_cast<const ET *>(iq_all_) + (size_t)phys * stream_stride;
 	const ET *hist_in = reinterpret_cast<const ET *>(hist_in_all_) + (size_t)phys * CH_H;
 	ET *hist_out_all = reinterpret_cast<ET *>(hist_out_all_);
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 			const int i = tid + P_NT * q;
 			const long pos = base + 2 * (long)i;
 			if (i < P_CHW / 2) tmp[q] = pos < 0 ? src_h[(CH_H + pos) / 2] : src_iq[pos / 2];
+			else if constexpr (I8) tmp[q] = 0u;
 			else if constexpr (I16) tmp[q] = make_uint2(0u, 0u);
 			else tmp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 		}
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 		for (int q = 0; q < NQ; q++) {
 			const int i = tid + P_NT * q;
 			if (i < P_CHW / 2) {
-				if constexpr (I16) dst[i] = make_float4((float)(int16_t)(tmp[q].x & 0xffffu), (float)((int32_t)tmp[q].x >> 16), (float)(int16_t)(tmp[q].y & 0xffffu), (float)((int32_t)tmp[q].y >> 16));
+				if constexpr (I8) dst[i] = make_float4((float)(int8_t)(tmp[q] & 0xffu), (float)(int8_t)((tmp[q] >> 8) & 0xffu), (float)(int8_t)((tmp[q] >> 16) & 0xffu), (float)((int32_t)tmp[q] >> 24));
+				else if constexpr (I16) dst[i] = make_float4((float)(int16_t)(tmp[q].x & 0xffffu), (float)((int32_t)tmp[q].x >> 16), (float)(int16_t)(tmp[q].y & 0xffffu), (float)((int32_t)tmp[q].y >> 16));
 				else dst[i] = tmp[q];
 			}
 		}
@@ -511,7 +515,7 @@ static bool chan_overlap_setup(SondeChannelizer *c)
 extern "C" int sonde_chan_set_input(SondeChannelizer *c, int input_kind)
 {
 	if (!c) return -1;
-	if (c->n_blocks == 0 && (input_kind == SONDE_INPUT_IQ || input_kind == SONDE_INPUT_IQ16)) c->input_kind = input_kind;
+	if (c->n_blocks == 0 && (input_kind == SONDE_INPUT_IQ || input_kind == SONDE_INPUT_IQ16 || input_kind == SONDE_INPUT_IQ8)) c->input_kind = input_kind;
 	return c->input_kind;
 }
 
@@ -520,10 +524,12 @@ static void launch_pfb(SondeChannelizer *c, hipStream_t st, const void *iq_dev, 
 	const dim3 g(c->n_steps / P_S, c->n_streams), blk(P_NT);
 	const void *hin = c->d_hist[c->n_blocks & 1];
 	void *hout = c->d_hist[(c->n_blocks + 1) & 1];
-	if (c->input_kind == SONDE_INPUT_IQ16)
-		hipLaunchKernelGGL(sd_pfb_kernel<true>, g, blk, 0, st, iq_dev, n_samples, hin, hout, c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
+	if (c->input_kind == SONDE_INPUT_IQ8)
+		hipLaunchKernelGGL(sd_pfb_kernel<2>, g, blk, 0, st, iq_dev, n_samples, hin, hout, c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
+	else if (c->input_kind == SONDE_INPUT_IQ16)
+		hipLaunchKernelGGL(sd_pfb_kernel<1>, g, blk, 0, st, iq_dev, n_samples, hin, hout, c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
 	else
-		hipLaunchKernelGGL(sd_pfb_kernel<false>, g, blk, 0, st, iq_dev, n_samples, hin, hout, c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
+		hipLaunchKernelGGL(sd_pfb_kernel<0>, g, blk, 0, st, iq_dev, n_samples, hin, hout, c->d_h, c->d_tw, bins, c->n_steps, c->xcd_map, c->dual, c->d_h_odd, c->d_twist);
 }
 
 extern "C" uint32_t sonde_chan_samples_per_submit(const SondeChannelizer *c) { return c ? c->n_steps * CH_D : 0; }

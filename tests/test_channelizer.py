@@ -305,8 +305,8 @@ def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [True, False])
-def test_channelizer_takes_16_bit_wideband_blocks(oracle, fused):
+@pytest.mark.parametrize("fused,bits", [(True, 16), (False, 16), (True, 8), (False, 8)])
+def test_channelizer_takes_16_bit_wideband_blocks(oracle, fused, bits):
     """sonde_chan_set_input(SONDE_INPUT_IQ16): the wideband block as int16 I, Q pairs (what a 10 MS/s receiver delivers).  Converted
     exactly on the way into the filter bank's window: phases (every bin), frames, bits and loop state equal those of the float
     block holding the same integers, and the frames equal the oracle's on those floats.  Two streams, two blocks per submit, five
@@ -316,8 +316,11 @@ def test_channelizer_takes_16_bit_wideband_blocks(oracle, fused):
     from sdrpp_radiosonde_amd.batch import SondeChannelizer
     bins_active, streams, bps, nblk = [9, 130, 257, 500], 2, 2, 10
     scenes = [synth.make_wideband_rs41(bins_active, nblk * BLOCK, seed=70 + s, ebn0_db=33.0, device="cuda:0")[0] for s in range(streams)]
-    x16 = [torch.clamp(torch.round(sc * 2048.0), -32768, 32767).to(torch.int16) for sc in scenes]
-    chz_i = SondeChannelizer(blocks_per_submit=bps, n_streams=streams, fused=fused, input_kind=_lib.INPUT_IQ16)
+    if bits == 8:       # (SONDE_INPUT_IQ8: four unit-amplitude carriers + noise at 12 counts per unit: inside +-127)
+        x16 = [torch.clamp(torch.round(sc * 12.0), -128, 127).to(torch.int8) for sc in scenes]
+    else:
+        x16 = [torch.clamp(torch.round(sc * 2048.0), -32768, 32767).to(torch.int16) for sc in scenes]
+    chz_i = SondeChannelizer(blocks_per_submit=bps, n_streams=streams, fused=fused, input_kind=_lib.INPUT_IQ16 if bits == 16 else _lib.INPUT_IQ8)
     chz_f = SondeChannelizer(blocks_per_submit=bps, n_streams=streams, fused=fused)
     with pytest.raises(Exception):
         chz_i.submit(torch.stack([x[:bps * BLOCK].to(torch.float32) for x in x16]).contiguous())      # a float block into the integer object

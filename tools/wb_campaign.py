@@ -31,8 +31,11 @@ for it in range(n):
     active = sorted(int(x) for x in rng.choice(np.arange(2, 510), size=4, replace=False))
     m10 = [int(x) for x in rng.choice([b for b in range(2, 510) if b not in active], size=2, replace=False)]
     scenes = [synth.make_wideband_rs41(active, nblk * tc.BLOCK, seed=seed + s, ebn0_db=ebn0, device="cuda:0", offset_hz=offset)[0] for s in range(streams)]
-    iq16 = bool(rng.integers(0, 3) == 0)                 # a third of the scenes as int16 I, Q blocks (sonde_chan_set_input)
-    if iq16:
+    iq16 = (False, False, True, 8)[int(rng.integers(0, 4))]   # a quarter of the scenes as int16 I, Q blocks, a quarter as int8 (sonde_chan_set_input)
+    if iq16 == 8:
+        q16 = [torch.clamp(torch.round(sc * 12.0), -128, 127).to(torch.int8) for sc in scenes]
+        scenes = [q.to(torch.float32) for q in q16]
+    elif iq16:
         q16 = [torch.clamp(torch.round(sc * 2048.0), -32768, 32767).to(torch.int16) for sc in scenes]
         scenes = [q.to(torch.float32) for q in q16]      # (the oracle sees the same integers as floats)
     per = 1024 if dual else 512
@@ -41,7 +44,7 @@ for it in range(n):
         types[[per * s_ + k for k in m10]] = 1          # silent bins of another sonde type (DFM)
         if dual:
             types[[per * s_ + 512 + k for k in m10]] = 1
-    chz = SondeChannelizer(types=types, blocks_per_submit=bps, n_streams=streams, dual=dual, input_kind=2 if iq16 else 0)
+    chz = SondeChannelizer(types=types, blocks_per_submit=bps, n_streams=streams, dual=dual, input_kind=(3 if iq16 == 8 else 2) if iq16 else 0)
     assert chz.fused
     got = []
     for b in range(nblk // bps):
@@ -71,6 +74,6 @@ for it in range(n):
     sel = got[np.isin(got["channel"], [per * s_ + o + k for s_ in range(streams) for o in ((0, 512) if dual else (0,)) for k in active + m10])]
     assert key(sel).tobytes() == key(ref).tobytes(), it
     chz.close()
-    print(f"[{it + 1}/{n}] seed {seed} Eb/N0 {ebn0:5.1f} dB streams {streams} blocks/submit {bps} dual {int(dual)}{' int16' if iq16 else ''} offset {offset:.0f} Hz bins {active} + DFM {m10}: "
+    print(f"[{it + 1}/{n}] seed {seed} Eb/N0 {ebn0:5.1f} dB streams {streams} blocks/submit {bps} dual {int(dual)}{' int8' if iq16 == 8 else (' int16' if iq16 else '')} offset {offset:.0f} Hz bins {active} + DFM {m10}: "
           f"{len(ref)} frames, {nbits} ring bits, loop state of {len(active + m10) * streams} bins identical to the oracle", flush=True)
 print(f"wideband campaign done in {time.time() - t0:.0f} s")
