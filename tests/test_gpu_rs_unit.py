@@ -93,3 +93,22 @@ def test_corrector_against_textbook_decoder(n):
             seen[st] = seen.get(st, 0) + 1
     assert seen.get(-1, 0) > 200 and all(seen.get(k, 0) > 20 for k in range(0, 13)), seen
     b.close()
+
+
+@pytest.mark.parametrize("n", [24 + 132, 255])
+def test_corrector_against_independent_pgz_fixture(n):
+    """tests/golden/rs255_pgz.npz: words, decisions and corrected words from an independent Peterson-Gorenstein-Zierler decoder
+    (tests/golden/make_rs_fixtures.py: a direct solve of the syndrome matrix in pure Python, no Berlekamp-Massey, no Forney)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rs255_pgz.npz"))
+    words, want_st, want = g[f"words{n}"], g[f"status{n}"], g[f"fixed{n}"]
+    assert len(words) % 2 == 0
+    pairs = np.zeros((len(words) // 2, 2, 256), dtype=np.uint8)
+    pairs.reshape(-1, 256)[:, :255] = words
+    status = np.zeros((len(pairs), 2), dtype=np.int32)
+    b = SondeBatch(1, 2048)
+    rc = b.L.sonde_batch_test_rs255(b.h, pairs.ctypes.data_as(C.c_void_p), len(pairs), n, status.ctypes.data_as(C.c_void_p))
+    assert rc == 0, _lib.last_error()
+    assert np.array_equal(status.reshape(-1), want_st)
+    assert np.array_equal(pairs.reshape(-1, 256)[:, :n], want[:, :n])
+    b.close()

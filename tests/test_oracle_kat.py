@@ -315,3 +315,18 @@ def test_m10_checksum_is_gf2_linear(oracle):
             b = rng.integers(0, 256, n, dtype=np.uint8)
             x = a ^ b
             assert L.or_m10_checksum(oracle.u8ptr(x), n) == L.or_m10_checksum(oracle.u8ptr(a), n) ^ L.or_m10_checksum(oracle.u8ptr(b), n)
+
+
+@pytest.mark.parametrize("n", [24 + 132, 255])
+def test_rs255_against_independent_pgz_fixture(oracle, n):
+    """tests/golden/rs255_pgz.npz (tests/golden/make_rs_fixtures.py): an independent Peterson-Gorenstein-Zierler decoder's
+    decisions and corrected words, weights 0..14, errors confined to the parity, codewords that differ in the padding of the
+    shortened code: the oracle's Berlekamp-Massey / Chien / Forney decoder makes the same decisions."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rs255_pgz.npz"))
+    L = oracle.lib()
+    for w, st, fx in zip(g[f"words{n}"], g[f"status{n}"], g[f"fixed{n}"]):
+        buf = np.ascontiguousarray(w[:255].copy())
+        got = L.or_rs255_decode(oracle.u8ptr(buf), n)
+        assert got == st and np.array_equal(buf[:n], fx[:n]), (n, got, st)
+    assert (g[f"status{n}"] == -1).sum() > 40 and (g[f"status{n}"] == 12).sum() > 20
