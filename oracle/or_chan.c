@@ -260,14 +260,15 @@ void or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, flo
 			im[(r + shift) & (OR_CH_M - 1)] = ai;
 		}
 		or_fft512(re, im, c->tw);
-		if (c->odd) {
-			const float ramp = or_chan_ramp(m);
-			for (int k = 0; k < OR_CH_M; k++) {
-				const float t = or_atan2(im[k], re[k]) - ramp;
-				bl[(size_t)k * n_steps + m] = fmaf(-4.0f, rintf(0.25f * t), t);
-			}
-		} else
-		for (int k = 0; k < OR_CH_M; k++) bl[(size_t)k * n_steps + m] = or_atan2(im[k], re[k]);
+		/* SPEC 3.5 (round 5): the phase leaves the bank as a 16-bit fraction of a turn, q = rint(16384 atan2q) mod 2^16 (int16: a full
+		 * turn is 65536, so every later phase operation -- the odd bank's ramp, the discriminator's wrapped difference -- is EXACT
+		 * 16-bit integer arithmetic); 2 bytes per bin and step in HBM instead of 4.  Resolution 9.6e-5 rad: a twentieth of atan2q's
+		 * own error.  The odd bank takes the step's common phase -(125 / 64) m quadrants = -32000 m (mod 2^16) off in integers. */
+		for (int k = 0; k < OR_CH_M; k++) {
+			uint16_t q = (uint16_t)((long)lrintf(or_atan2(im[k], re[k]) * 16384.0f) & 0xFFFF);
+			if (c->odd) q = (uint16_t)(q - (uint16_t)(32000u * (unsigned)(m & 0xFFFFu)));
+			bl[(size_t)k * n_steps + m] = (float)(int16_t)q * (1.0f / 16384.0f);
+		}
 	}
 	memcpy(c->hist, buf + 2 * N, 2 * H * sizeof(float));   /* last L-D samples of [hist|block] */
 	free(buf);
@@ -278,12 +279,13 @@ void or_chan_block2(OrChan *c, const float *iq, size_t n_steps, float *bins, flo
 		or_chan_composite_taps(c->g, 4, G4);
 		for (int k = 0; k < OR_CH_M; k++) {
 			memcpy(d, c->dhist[k], OR_RS_T * sizeof(float));
-			/* discriminator: the wrapped difference of consecutive phases, quadrants in [-2, 2] */
+			/* discriminator: the wrapped difference of consecutive phases as a 16-bit integer subtraction, quadrants in [-2, 2) */
 			float prev = c->phi_last[k];
 			for (size_t m = 0; m < n_steps; m++) {
 				const float ph = bl[(size_t)k * n_steps + m];
-				const float t = ph - prev;
-				d[OR_RS_T + m] = fmaf(-4.0f, rintf(0.25f * t), t);
+				/* (both are multiples of 2^-14 in [-2, 2): back to the 16-bit integers, exactly) */
+				const uint16_t dq = (uint16_t)((uint16_t)(int16_t)(ph * 16384.0f) - (uint16_t)(int16_t)(prev * 16384.0f));
+				d[OR_RS_T + m] = (float)(int16_t)dq * (1.0f / 16384.0f);
 				prev = ph;
 			}
 			c->phi_last[k] = prev;

@@ -140,6 +140,8 @@ struct SondeBatch {
 	uint16_t *d_m10tab = nullptr;          // Meteomodem checksum as a GF(2) matrix product: rows A^k B, sd_fixed.h
 	uint32_t fuse_fec = 1;                 // RS41 FEC in the demod kernel's epilogue (default) or as its own kernel (SONDE_FLAG_SPLIT_FEC)
 	SdFramerOut *d_fo2[2] = {};            // where the demod kernel's in-kernel sync search keeps its state and lists frames (device copies)
+	SdFramerOut h_fo2[2] = {};             // host copies: the bins decoder takes the descriptor by value (bins_kernel.hip)
+	SdModem h_modems[SONDE_NTYPES] = {};
 	uint32_t *d_gfswar = nullptr;          // byte-slice tables of the 24 syndrome multipliers alpha^(4j), framer_kernel.hip
 	void *d_descs = nullptr;
 	uint32_t *d_chlist[SONDE_NTYPES] = {};
@@ -351,6 +353,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	}
 	CHK(hipMemcpy(b->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
 	CHK(hipMemcpy(b->d_modems, modems, sizeof(modems), hipMemcpyHostToDevice));
+	memcpy(b->h_modems, modems, sizeof(modems));
 	// GF(2^8) tables, primitive polynomial 0x11D
 	uint8_t gexp[512], glog[256];
 	{
@@ -418,6 +421,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			const uint32_t loop_wg = getenv("SONDE_NO_LOOP_FEC") ? 0u : 4u * (uint32_t)prop.multiProcessorCount;
 			const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts2[k], b->max_frames, b->fuse_fec, loop_wg, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames2[k] };
 			CHK(hipMemcpy(b->d_fo2[k], &fo, sizeof(fo), hipMemcpyHostToDevice));
+			b->h_fo2[k] = fo;
 			CHK(hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming));
 		}
 		CHK(hipEventCreateWithFlags(&b->ev_xs, SD_EV_ORDER));
@@ -501,7 +505,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	return 0;
 }
 
-static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_, const SdBinsIn *bins_in);
+static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_, const SdBinsArgs *bins_in);
 
 extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_)
 {
@@ -514,9 +518,10 @@ extern "C" int sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_s
 	return submit_impl(b, samples, n_samples, channel_stride, stream_, nullptr);
 }
 
-// The channelizer's decoder batch (created with SONDE_INPUT_REAL) takes its rows as 20 kS/s PHASE samples instead: n_steps floats
-// per channel (a multiple of 2560 = 3 tiles of 48 kS/s output), the per-bin discriminator (wrapped phase difference) and the
-// composite 12/5 resampler - 4:1 decimator run in the demod kernel's load path (SPEC 3.5 / 3.5b).  The 12 kS/s sondes only (class
+// The channelizer's decoder batch (created with SONDE_INPUT_REAL) takes its rows as 20 kS/s PHASE samples instead: n_steps 16-bit
+// fractions of a turn per channel (a multiple of 2560 = 3 tiles of 48 kS/s output) behind the 16 carried ones; the per-bin
+// discriminator (wrapped phase difference), the composite 12/5 resampler - 4:1 decimator (SPEC 3.5 / 3.5b) and everything behind
+// them run in bins_kernel.hip, one wave per bin.  The 12 kS/s sondes only (class
 // (4, 8)): a 19.5 kHz bin cannot carry an M10 channel (50 kHz in the reference, /root/reference/src/main.hpp:48), and the AFSK
 // sondes want 48 kS/s rows.  Internal to the library (channelizer.hip).
 int sd_batch_bins_capable(const SondeBatch *b)
@@ -530,16 +535,16 @@ int sd_batch_bins_capable(const SondeBatch *b)
 	}
 	return 1;
 }
-int sd_batch_submit_bins(SondeBatch *b, const void *bins, size_t n_steps, size_t channel_stride, const SdBinsIn *d_bins_in, void *stream_)
+int sd_batch_submit_bins(SondeBatch *b, const SdBinsArgs *ba, size_t n_steps, void *stream_)
 {
-	if (!b || !bins || !d_bins_in || !sd_batch_bins_capable(b)) return fail("sd_batch_submit_bins: bad argument");
+	if (!b || !ba || !ba->phases || !ba->carry_rows || !ba->g_comp || !sd_batch_bins_capable(b)) return fail("sd_batch_submit_bins: bad argument");
 	const size_t n_out = n_steps / 5 * 12;
-	if (n_steps == 0 || n_steps % 2560 || n_out > b->max_samples || channel_stride < n_steps || ((uintptr_t)bins & 3u))
+	if (n_steps == 0 || n_steps % 2560 || n_out > b->max_samples || ba->row_stride < n_steps + 16 || (ba->row_stride & 1) || ((uintptr_t)ba->phases & 3u))
 		return fail("sd_batch_submit_bins: n_steps must be a multiple of 2560 within max_samples");
-	return submit_impl(b, bins, n_out, channel_stride, stream_, d_bins_in);
+	return submit_impl(b, ba->phases, n_out, ba->row_stride, stream_, ba);
 }
 
-static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_, const SdBinsIn *bins_in)
+static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_, const SdBinsArgs *bins_in)
 {
 	HIPCHK(hipSetDevice(b->device));
 	hipStream_t stream = (hipStream_t)stream_;
@@ -550,7 +555,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	b->n_submits++;
 	hipEvent_t *ev = b->ev + 3 * (b->ev_used % SondeBatch::kEvSlots);
 	if (timed) HIPCHK(hipEventRecord(ev[0], stream));
-	const int iq = bins_in ? SD_IN_BINS : (b->input_kind == SONDE_INPUT_IQ ? SD_IN_IQ : (b->input_kind == SONDE_INPUT_IQ16 ? SD_IN_IQ16 : (b->input_kind == SONDE_INPUT_IQ8 ? SD_IN_IQ8 : SD_IN_REAL)));      // what the rows hold
+	const int iq = (b->input_kind == SONDE_INPUT_IQ ? SD_IN_IQ : (b->input_kind == SONDE_INPUT_IQ16 ? SD_IN_IQ16 : (b->input_kind == SONDE_INPUT_IQ8 ? SD_IN_IQ8 : SD_IN_REAL)));      // what the rows hold
 	const int slot = (int)(b->tickets & 1);
 	SondeFrame *const d_frames = b->d_frames2[slot];
 	uint32_t *const d_counts = b->d_counts2[slot];
@@ -589,8 +594,12 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	};
 	const bool one_launch = b->units.empty();
 	if (one_launch) {
+		if (bins_in)      // channelizer bins: one wave per bin (bins_kernel.hip); n_tiles = 3 per block of 2560 phases
+			sd_launch_bins(b->n_channels, stream, bins_in->phases, bins_in->row_stride, n_tiles / 3, bins_in->carry_rows, bins_in->carry_stride,
+				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->h_modems, &b->h_fo2[slot], bins_in->g_comp, b->cls_type[b->only_class]);
+		else
 		sd_launch_demod(iq, k_cls_decim[b->only_class], k_cls_nt[b->only_class], b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
-			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, bins_in, b->cls_type[b->only_class]);
+			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, b->cls_type[b->only_class]);
 		HIPCHK(hipGetLastError());
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
 		for (int t = 0; t < SONDE_NTYPES; t++) if (launch_framers(t, stream)) return -1;
@@ -612,11 +621,11 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 				sd_launch_afsk(u.type, iq == SD_IN_IQ ? 1 : (iq == SD_IN_IQ16 ? 2 : (iq == SD_IN_IQ8 ? 3 : 0)), u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_chlist[u.type], b->d_astates, u.type == SONDE_C50 ? b->d_wtab_c50 : b->d_wtab, rows, nq);
 				sd_launch_demod(SD_IN_REAL, 1, 16, u.n, u.st, rows, nq, (int)(nq / SONDE_TILE),
-					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo, nullptr, u.type);
+					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo, u.type);
 			} else {
 				sd_launch_demod(iq, k_cls_decim[u.cls], k_cls_nt[u.cls], u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems,
-					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo, bins_in, u.type < 0 ? b->cls_type[u.cls] : u.type);
+					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo, u.type < 0 ? b->cls_type[u.cls] : u.type);
 			}
 			HIPCHK(hipGetLastError());
 			if (timed) HIPCHK(hipEventRecord(ec[1], u.st));

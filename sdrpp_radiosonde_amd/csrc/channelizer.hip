@@ -1,6 +1,6 @@
 // channelizer.hip -- wideband front-end (BASELINE config 4):
 //   10 MS/s complex IQ -> 512-bin polyphase filter bank (decimation 500 -> 20 kS/s per bin, 1.024 x oversampled) -> per-bin
-//   instantaneous PHASE (one float per bin and step) -> FM discriminator = wrapped phase difference at 20 kS/s
+//   instantaneous PHASE (a 16-bit fraction of a turn per bin and step, round 5) -> FM discriminator = wrapped 16-bit phase difference at 20 kS/s
 //   -> real rational resampler 12/5 -> 48 kS/s -> kernel A (real input)
 // (round 4: the bank ran at 40 kS/s per bin and stored complex bins in rounds 2-3 -- 16.4 B written and re-read per wideband
 // sample; a bin now leaves the filter bank as 4 B per 500 wideband samples: 0.8 B per wideband sample)
@@ -8,7 +8,7 @@
 // (/root/reference/src/main.cpp:55-60) for all 512 bins at once.  SPEC: DESIGN.md section 3.5; the CPU oracle is
 // oracle/or_chan.c.  One object takes S wideband streams per submit (grid.y = stream): the filter bank, the per-bin
 // discriminator + resampler and the decoders of all S x 512 bins are one launch each.  By default the discriminator and the
-// resampler run inside the decoder kernel's load path (SD_IN_BINS, demod_kernel.hip): a submit is two launches.
+// resampler run inside the bins decoder (bins_kernel.hip, one wave per bin): a submit is two launches.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
@@ -29,6 +29,7 @@
 #define RS_UP 12
 #define RS_DN 5
 #define RS_TAPS 16
+#define PH_HEAD 16                  // phases of the previous block kept at the head of every bin's row (bins_kernel.hip)
 
 // ---- the filter bank: 8 output steps per 512-thread workgroup, blockIdx.y = wideband stream.
 //   1. the window of the 8 steps (8192 + 7*500 samples) is staged in LDS in TWO halves of the prototype's 16 taps (taps 0-7, then
@@ -115,7 +116,7 @@ template <int IK>
 __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
                                                            const void *__restrict__ hist_in_all_, void *__restrict__ hist_out_all_,
                                                            const float *__restrict__ h_even, const float2 *__restrict__ tw,
-                                                           float *__restrict__ phi_all, uint32_t n_steps, uint32_t xcd_map,
+                                                           int16_t *__restrict__ phi_all, uint32_t n_steps, uint32_t xcd_map,
                                                            uint32_t dual, const float *__restrict__ h_odd, const float2 *__restrict__ twist)
 {
 	__shared__ __attribute__((aligned(16))) float2 s_x[P_CHW];
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 	const ET *iq = reinterpret_cast<const ET *>(iq_all_) + (size_t)phys * stream_stride;
 	const ET *hist_in = reinterpret_cast<const ET *>(hist_in_all_) + (size_t)phys * CH_H;
 	ET *hist_out_all = reinterpret_cast<ET *>(hist_out_all_);
-	float *phi = phi_all + (size_t)sidx * CH_M * n_steps;
+	const size_t prow = (size_t)n_steps + PH_HEAD;                     // a bin's row: [16 carried phases | n_steps]
+	int16_t *phi = phi_all + (size_t)sidx * CH_M * prow + PH_HEAD;
 	const long p0 = (long)m0 * CH_D - CH_H;                   // stream position of window sample 0 (even)
 	constexpr int NQ = (P_CHW / 2 + P_NT - 1) / P_NT;
 	auto load_round = [&](int c, PT (&tmp)[NQ]) {              // taps c*P_TC ..: window samples [c * P_TC * 512, + P_CHW)
@@ -228,41 +230,43 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 	float ph[8];
 #pragma unroll
 	for (int j = 0; j < 8; j++) ph[j] = sd_atan2q(e0[j].y, e0[j].x);
-	if (odd) {                              // the step's common phase -(125 / 64) m quadrants (256 steps = whole turns; a block is a multiple of 256 steps)
-		const float t = (float)(125u * ((m0 + (uint32_t)wave) & 255u)) * (1.0f / 64.0f);
-		const float ramp = __builtin_fmaf(-4.0f, __builtin_rintf(0.25f * t), t);
-#pragma unroll
-		for (int j = 0; j < 8; j++) ph[j] = sd_phase_diff(ph[j], ramp);
-	}
 	__syncthreads();                       // every wave has left its FFT buffer: the phase tile aliases them
 	float *const s_t = reinterpret_cast<float *>(s_x);
 #pragma unroll
 	for (int j = 0; j < 8; j++) s_t[(lane + 64 * j) * P_OT + wave] = ph[j];
 	__syncthreads();
-	// two lanes per bin row: a store instruction writes 32 whole 32-byte runs
+	// SPEC 3.5 (round 5): a phase leaves the bank as a 16-bit fraction of a turn, q = rint(16384 atan2q) mod 2^16; the odd bank takes
+	// the step's common phase -(125 / 64) m quadrants = -32000 m (mod 2^16) off in integers (exact; 256 steps = whole turns).
+	// Thread = bin: its 8 steps are one aligned 16-byte store.
+	{
+		const float *row = s_t + tid * P_OT;
+		uint32_t q[P_S];
 #pragma unroll
-	for (int k = 0; k < 2; k++) {
-		const int idx = tid + P_NT * k, bin = idx >> 1, part = idx & 1;
-		const float *row = s_t + bin * P_OT + 4 * part;
-		*reinterpret_cast<float4 *>(phi + (size_t)bin * n_steps + m0 + 4 * part) = make_float4(row[0], row[1], row[2], row[3]);
+		for (int j = 0; j < P_S; j++) {
+			q[j] = (uint32_t)__float2int_rn(row[j] * 16384.0f);
+			if (odd) q[j] -= 32000u * (m0 + (uint32_t)j);
+			q[j] &= 0xffffu;
+		}
+		*reinterpret_cast<uint4 *>(phi + (size_t)tid * prow + m0) = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16));
 	}
 }
 
 // ---- per bin: discriminator (wrapped difference of consecutive phases) at 20 kS/s + 12/5 polyphase resampler to 48 kS/s, as a
 // kernel of its own (bins with AFSK sondes, which want 48 kS/s rows, and the parity tests' unfused mode).  One workgroup per bin.
-__global__ __launch_bounds__(256) void sd_phase_resamp_kernel(const float *__restrict__ phi, uint32_t n_steps,
-                                                               const float *__restrict__ g, float *__restrict__ phi_last,
+__global__ __launch_bounds__(256) void sd_phase_resamp_kernel(const int16_t *__restrict__ phi, uint32_t n_steps,
+                                                               const float *__restrict__ g, int32_t *__restrict__ phi_last,
                                                                float *__restrict__ dhist, float *__restrict__ out48)
 {
 	extern __shared__ float s_d[];            // [RS_TAPS history | n_steps]
 	__shared__ float s_g[RS_UP * RS_TAPS];
 	const uint32_t k = blockIdx.x;
 	const int tid = threadIdx.x;
-	const float *x = phi + (size_t)k * n_steps;
+	const int16_t *x = phi + (size_t)k * (n_steps + PH_HEAD) + PH_HEAD;
 	if (tid < RS_UP * RS_TAPS) s_g[tid] = g[tid];
 	if (tid < RS_TAPS) s_d[tid] = dhist[(size_t)k * RS_TAPS + tid];
-	const float first_prev = phi_last[k];
-	for (uint32_t i = tid; i < n_steps; i += 256) s_d[RS_TAPS + i] = sd_phase_diff(x[i], i ? x[i - 1] : first_prev);
+	const int first_prev = phi_last[k];
+	// the discriminator: a wrapped 16-bit difference, in quadrants (SPEC 3.5)
+	for (uint32_t i = tid; i < n_steps; i += 256) s_d[RS_TAPS + i] = (float)(int16_t)(uint16_t)((int)x[i] - (i ? (int)x[i - 1] : first_prev)) * (1.0f / 16384.0f);
 	__syncthreads();
 	const uint32_t n_out = n_steps * RS_UP / RS_DN;
 	for (uint32_t j = tid; j < n_out; j += 256) {
@@ -287,7 +291,6 @@ struct SondeChannelizer {
 	uint32_t n_phys = 1, dual = 0;            // physical input streams; dual: every physical stream feeds an even and an odd-stacked bank (SPEC 3.5c)
 	float *d_h_odd = nullptr; float2 *d_twist = nullptr;
 	bool fused = false;                    // the decoder kernel takes the bins themselves (discriminator + resampler in its load path): two launches per submit
-	SdBinsIn *d_bins_in = nullptr;
 	hipStream_t last_stream = nullptr;     // a submit on another stream waits for the previous one (the state is carried)
 	hipEvent_t ev_xs = nullptr;
 	// overlapped form (an OPTION: SONDE_CHAN_OVERLAP / sonde_chan_set_overlap(c, 1); fused mode only): the filter bank runs on
@@ -299,11 +302,12 @@ struct SondeChannelizer {
 	bool overlap = false;
 	hipStream_t s_pfb = nullptr, s_dec = nullptr;
 	hipEvent_t ev_in = nullptr, ev_pfb[2] = {}, ev_dec[2] = {};
-	float *d_bins_b = nullptr;             // the second phase buffer (allocated at the first overlapped submit)
-	float *d_bins_last = nullptr;          // the phases of the last submit (sonde_chan_read)
+	int16_t *d_bins_b = nullptr;           // the second phase buffer (allocated at the first overlapped submit)
+	int16_t *d_bins_last = nullptr;        // the phases of the last submit (sonde_chan_read)
 	SondeBatch *batch = nullptr;
 	float2 *d_hist[2] = {}, *d_tw = nullptr;
-	float *d_bins = nullptr, *d_philast = nullptr;       // per bin and step: the phase (quadrants); per bin: the last phase of the previous block
+	int16_t *d_bins = nullptr;             // per bin: [16 phases carried from the previous block | n_steps phases], 16-bit fractions of a turn
+	int32_t *d_philast = nullptr;          // unfused mode: per bin, the last phase of the previous block
 	float *d_h = nullptr, *d_g = nullptr, *d_gc = nullptr, *d_dhist = nullptr, *d_out48 = nullptr;
 	// kernel timing (HIP events on the submit stream), sampled: every 8th submit
 	hipEvent_t ev[3] = {};
@@ -385,7 +389,7 @@ extern "C" void sonde_chan_destroy(SondeChannelizer *c)
 	if (c->s_dec) (void)hipStreamDestroy(c->s_dec);
 	(void)hipFree(c->d_bins_b);
 	(void)hipFree(c->d_hist[0]); (void)hipFree(c->d_hist[1]); (void)hipFree(c->d_bins); (void)hipFree(c->d_tw); (void)hipFree(c->d_philast);
-	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48); (void)hipFree(c->d_bins_in); (void)hipFree(c->d_gc); (void)hipFree(c->d_h_odd); (void)hipFree(c->d_twist);
+	(void)hipFree(c->d_h); (void)hipFree(c->d_g); (void)hipFree(c->d_dhist); (void)hipFree(c->d_out48); (void)hipFree(c->d_gc); (void)hipFree(c->d_h_odd); (void)hipFree(c->d_twist);
 	delete c;
 }
 
@@ -431,14 +435,14 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 	make_tables(h, tw, g);
 	const size_t hist_bytes = (size_t)n_phys * CH_H * sizeof(float2);
 	bool ok = hipMalloc((void **)&c->d_hist[0], hist_bytes) == hipSuccess && hipMalloc((void **)&c->d_hist[1], hist_bytes) == hipSuccess &&
-	          hipMalloc((void **)&c->d_bins, nb * c->n_steps * sizeof(float)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_bins, nb * ((size_t)c->n_steps + PH_HEAD) * sizeof(int16_t)) == hipSuccess &&
 	          (blocks_per_submit > 2 || hipMalloc((void **)&c->d_out48, nb * n_out * sizeof(float)) == hipSuccess) &&
 	          hipMalloc((void **)&c->d_h, CH_L * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_tw, CH_M * sizeof(float)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_g, RS_UP * RS_TAPS * sizeof(float)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_philast, nb * sizeof(float)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_philast, nb * sizeof(int32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dhist, nb * RS_TAPS * sizeof(float)) == hipSuccess;
-	ok = ok && hipMemset(c->d_hist[0], 0, hist_bytes) == hipSuccess && hipMemset(c->d_hist[1], 0, hist_bytes) == hipSuccess && hipMemset(c->d_philast, 0, nb * sizeof(float)) == hipSuccess &&
+	ok = ok && hipMemset(c->d_hist[0], 0, hist_bytes) == hipSuccess && hipMemset(c->d_hist[1], 0, hist_bytes) == hipSuccess && hipMemset(c->d_philast, 0, nb * sizeof(int32_t)) == hipSuccess && hipMemset(c->d_bins, 0, nb * ((size_t)c->n_steps + PH_HEAD) * sizeof(int16_t)) == hipSuccess &&
 	     hipMemset(c->d_dhist, 0, nb * RS_TAPS * sizeof(float)) == hipSuccess &&
 	     hipMemcpy(c->d_h, h.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_tw, tw.data(), CH_M * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
@@ -458,8 +462,6 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 			     hipMemcpy(c->d_h_odd, ho.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 			     hipMemcpy(c->d_twist, wt.data(), CH_M * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
 		}
-		const SdBinsIn bi = { c->d_gc, c->d_philast, c->d_dhist };
-		ok = ok && hipMalloc((void **)&c->d_bins_in, sizeof(bi)) == hipSuccess && hipMemcpy(c->d_bins_in, &bi, sizeof(bi), hipMemcpyHostToDevice) == hipSuccess;
 		// fused unless a bin's sonde type needs 48 kS/s rows (AFSK) or the host asks for the rows (sonde_chan_set_fused, SONDE_CHAN_UNFUSED)
 		c->fused = sd_batch_bins_capable(c->batch) && !getenv("SONDE_CHAN_UNFUSED");
 		if (!c->fused && blocks_per_submit > 2) ok = false;      // (AFSK bins: the three-kernel form, 1-2 blocks per submit)
@@ -519,7 +521,7 @@ extern "C" int sonde_chan_set_input(SondeChannelizer *c, int input_kind)
 	return c->input_kind;
 }
 
-static void launch_pfb(SondeChannelizer *c, hipStream_t st, const void *iq_dev, size_t n_samples, float *bins)
+static void launch_pfb(SondeChannelizer *c, hipStream_t st, const void *iq_dev, size_t n_samples, int16_t *bins)
 {
 	const dim3 g(c->n_steps / P_S, c->n_streams), blk(P_NT);
 	const void *hin = c->d_hist[c->n_blocks & 1];
@@ -556,7 +558,8 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 	if (c->overlap) {
 		if (!chan_overlap_setup(c)) return -1;
 		const int b = (int)(c->n_blocks & 1);
-		float *bins = b ? c->d_bins_b : c->d_bins;
+		int16_t *bins = b ? c->d_bins_b : c->d_bins;
+		int16_t *bins_next = b ? c->d_bins : c->d_bins_b;      // the next submit's buffer takes this submit's last 16 phases
 		// the block is ready where the caller's stream stands now; bins[b] is free once the decoder of two submits ago is done
 		if (hipEventRecord(c->ev_in, stream) != hipSuccess || hipStreamWaitEvent(c->s_pfb, c->ev_in, 0) != hipSuccess) return -1;
 		if (c->n_blocks >= 2 && hipStreamWaitEvent(c->s_pfb, c->ev_dec[b], 0) != hipSuccess) return -1;
@@ -571,7 +574,8 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		if (hipStreamWaitEvent(stream, c->ev_pfb[b], 0) != hipSuccess || hipStreamWaitEvent(c->s_dec, c->ev_pfb[b], 0) != hipSuccess) return -1;
 		if (hipGetLastError() != hipSuccess) return -1;
 		c->last_stream = stream;
-		if (sd_batch_submit_bins(c->batch, bins, c->n_steps, c->n_steps, c->d_bins_in, (void *)c->s_dec) != 0) return -1;
+		const SdBinsArgs ba = { bins, (size_t)c->n_steps + PH_HEAD, bins_next, (size_t)c->n_steps + PH_HEAD, c->d_gc };
+		if (sd_batch_submit_bins(c->batch, &ba, c->n_steps, (void *)c->s_dec) != 0) return -1;
 		return hipEventRecord(c->ev_dec[b], c->s_dec) == hipSuccess ? 0 : -1;
 	}
 	// the front-end kernels carry state too (window history, discriminator history): a submit on another stream waits for
@@ -590,7 +594,10 @@ extern "C" int sonde_chan_submit(SondeChannelizer *c, const void *iq_dev, size_t
 		                   c->d_bins, c->n_steps, c->d_g, c->d_philast, c->d_dhist, c->d_out48);
 	if (timed) { (void)hipEventRecord(c->ev[2], stream); c->ev_pending = true; }
 	if (hipGetLastError() != hipSuccess) return -1;
-	if (c->fused) return sd_batch_submit_bins(c->batch, c->d_bins, c->n_steps, c->n_steps, c->d_bins_in, stream_);
+	if (c->fused) {
+		const SdBinsArgs ba = { c->d_bins, (size_t)c->n_steps + PH_HEAD, c->d_bins, (size_t)c->n_steps + PH_HEAD, c->d_gc };
+		return sd_batch_submit_bins(c->batch, &ba, c->n_steps, stream_);
+	}
 	return sonde_batch_submit(c->batch, c->d_out48, n_out, n_out, stream_);
 }
 
@@ -623,7 +630,13 @@ extern "C" int sonde_chan_read(SondeChannelizer *c, float *bins /* [512][n_steps
 	if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
 	const size_t nb = (size_t)c->n_streams * CH_M;
-	if (bins && hipMemcpy(bins, c->d_bins_last ? c->d_bins_last : c->d_bins, nb * c->n_steps * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if (bins) {           // the 16-bit phases as quadrants (q / 16384: exact), without the carried head of each row
+		const size_t prow = (size_t)c->n_steps + PH_HEAD;
+		std::vector<int16_t> tmp(nb * prow);
+		if (hipMemcpy(tmp.data(), c->d_bins_last ? c->d_bins_last : c->d_bins, tmp.size() * sizeof(int16_t), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+		for (size_t k = 0; k < nb; k++)
+			for (size_t m = 0; m < c->n_steps; m++) bins[k * c->n_steps + m] = (float)tmp[k * prow + PH_HEAD + m] * (1.0f / 16384.0f);
+	}
 	if (out48 && c->fused) return -1;      // the rows are never materialised in fused mode: sonde_chan_set_fused(c, 0) before the first submit
 	if (out48 && hipMemcpy(out48, c->d_out48, nb * n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return 0;

@@ -21,6 +21,7 @@
 #include "sonde_dev.h"
 
 #include "sd_math.h"
+#include "sd_wave.h"
 #include "sd_rs41.h"
 #include "sd_rsdec.h"
 #include "sd_fixed.h"
@@ -76,26 +77,6 @@ static __device__ __forceinline__ float4 sd_cs16_f4(uint2 q)
 	return make_float4((float)(int16_t)(q.x & 0xffffu), (float)((int32_t)q.x >> 16), (float)(int16_t)(q.y & 0xffffu), (float)((int32_t)q.y >> 16));
 }
 
-// min(max(v, lo), hi) as ONE v_med3_f32 (equal for every non-NaN v; the fminf / fmaxf pair costs a canonicalising v_max_f32 more)
-__device__ __forceinline__ float sd_clamp(float v, float lo, float hi)
-{
-	return __builtin_amdgcn_fmed3f(v, lo, hi);
-}
-
-// Integer wave reduction with DPP (VALU, no LDS crossbar): rows of 16, then row broadcasts; the total
-// lands in lane 63.  Integer addition is associative, so the tree shape is free (SPEC 3).
-__device__ __forceinline__ int wave_sum(int v)
-{
-	v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-	v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-	v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
-	v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
-	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast:15 -> rows 1,3
-	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast:31 -> rows 2,3
-	return __builtin_amdgcn_readlane(v, 63);
-}
-
-#define SD_LH      64     // samples of history kept in front of the tile in LDS
 #define SD_BUF     (SD_LH + SD_TILE + 4)
 #define SD_WGT     512    // workgroup: waves 0-3 run the timing-loop rounds, waves 4-7 the discriminator
 // K4 (sync search) runs on round wave 3; on a discriminator wave it measured equal for RS41 and 40 % slower for DFM (profiles/r2_notes.md)
@@ -120,8 +101,6 @@ struct DemodLds {
 	// what the lead round wave (wave 0) computes once per round and the other round waves pick up:
 	// the PI loop filter runs on one wave instead of four (it is ~35 % of a round wave's VALU work)
 	struct { long long t_next; int period; float bias; int K; unsigned flag; unsigned long long wpos; } pub;
-	alignas(16) float rs_g[64];                         // SD_IN_BINS: the 3 x 20 composite taps (SPEC 3.5b); rs_dh: the 16 carried discriminator samples
-	float rs_dh[16];
 	uint32_t mirror[SD_MIRROR_WORDS];       // the newest 2048 bits of the bit ring, for the in-kernel sync search (K4)
 	SdSyncRun k4;                           // K4's state between steps (wave 3 only)
 	SdFecJob fec;                           // the in-loop decoder of clean RS41 frames (wave 2 only, sd_rsdec.h)
@@ -133,48 +112,16 @@ __device__ __forceinline__ void store_pair(DemodLds &s, int b, uint32_t i, float
 	*reinterpret_cast<float2 *>(&s.A[b][SD_LH + i]) = make_float2(d0, d1);
 }
 
-// v of the lane below, lane 0: `first` (DPP wave_shr:1, GFX9; lanes without a source keep the old value)
-__device__ __forceinline__ float sd_wave_shr1(float v, float first)
-{
-	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
-}
-
 // one sample i of a tile into buffer b
 __device__ __forceinline__ void store_one(DemodLds &s, int b, uint32_t i, float d0)
 {
 	s.A[b][SD_LH + i] = d0;
 }
 
-// y(pos) = (sum_{j even} H[p][j] d[n+16-j]) + (sum_{j odd} H[p][j] d[n+16-j]), each an fmaf chain with j
-// ascending (SPEC 3.2): one v_pk_fma_f32 per tap pair.  The tap rows are stored pair-swapped
-// (T[2i] = H[2i+1], T[2i+1] = H[2i]) so that they line up with the (d[x], d[x+1]) pairs.
-// rel = pos relative to A[0], Q16.
-template <int NT>   // taps in use
-__device__ __forceinline__ float interp(const float *A, const float *taps, uint32_t rel)
-{
-	const uint32_t top = (rel >> 16) + NT / 2;                          // buffer index of d for j = 0
-	const float *h = taps + ((rel >> 11) & (SD_NPHASE - 1)) * SD_TAPS_LD;
-	// pair i holds (d[top-1-2i], d[top-2i]): pairs at any alignment, read as two dwords each (ds_read2_b32)
-	const float *lo = A + (top - (NT - 1));
-	f32x2 acc = {0.0f, 0.0f};                                           // (odd chain, even chain)
-#pragma unroll
-	for (int q = 0; q < NT / 4; q++) {
-		const float4 hv = *reinterpret_cast<const float4 *>(h + 4 * q);
-		const float2 v0 = make_float2(lo[(NT - 2) - 4 * q], lo[(NT - 1) - 4 * q]);
-		const float2 v1 = make_float2(lo[(NT - 4) - 4 * q], lo[(NT - 3) - 4 * q]);
-		const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
-		const f32x2 d0 = {v0.x, v0.y}, d1 = {v1.x, v1.y};
-		acc = pk_fma(h0, d0, acc);
-		acc = pk_fma(h1, d1, acc);
-	}
-	return acc.y + acc.x;
-}
-
 // FEC epilogue (RS41 channels): the GF tables sit, for the whole launch, in X[1] (placed as if behind the part of a buffer that a decimated
 // tile uses (decimation 4 or 2: <= 64 + 1024 + 4 floats of 2116), the per-wave work areas alias the tile buffers,
 // which are dead by then.
 #define SD_EPI_TAB_OFF 1100                 // floats into X[1]
-struct EpiTabs { FramerTabs tabs; alignas(16) uint32_t swar[RS_R * 8]; };
 static_assert(SD_LH + SD_TILE / 2 + 4 <= SD_EPI_TAB_OFF, "the tables must stay clear of a 2:1 tile");
 static_assert(sizeof(EpiTabs) <= (SD_BUF - SD_EPI_TAB_OFF) * sizeof(float), "GF tables do not fit behind the tile");
 static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "per-wave FEC work areas do not fit into the tile buffers");
@@ -188,21 +135,19 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 // factor and the taps per filter row of every channel of this launch (the host launches once per class), so that the
 // discriminator and FIR variants do not share one register allocation.  Classes in use: (4, 8) RS41 / DFM / iMS-100 / MRZ-N1,
 // (2, 8) M10, (2, 16) and (1, 16) the same two groups under SONDE_FLAG_WIDE, (1, 16) also the 6 kS/s AFSK streams.
-// IN: what `in` holds per channel: SD_IN_REAL 48 kS/s discriminator samples, SD_IN_IQ 48 kS/s complex samples, SD_IN_BINS
-// 20 kS/s phase samples of a channelizer bin (the per-bin FM discriminator -- a wrapped phase difference -- and the composite
-// 12/5 resampler - decimator of SPEC 3.5b then run in this kernel's load path: the 48 kS/s rows are never written to HBM).
+// IN: what `in` holds per channel: SD_IN_REAL 48 kS/s discriminator samples, SD_IN_IQ 48 kS/s complex samples, SD_IN_IQ16 / SD_IN_IQ8 the
+// same as 16- / 8-bit integer pairs.  (Channelizer bins have their own kernel: bins_kernel.hip, one wave per bin.)
 template <int IN, bool LIST, int DEC, int NT>
-// (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU.  Round 3's SD_IN_BINS form -- complex 40 kS/s bins, the
-// discriminator in here -- needed 80 VGPRs; the round-4 form, phases in, fits: 4096 bins x 3 tiles 57.7 -> 50.3 us, r4_notes.md)
+// (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU)
 __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
-	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, const SdBinsIn *__restrict__ bins_in, int utype)
+	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, int utype)
 {
 	// integer IQ rows: IQ16 = int16 pairs (SD_IN_IQ16) OR int8 pairs (SD_IN_IQ8): one code path, IQ8 picks the element size
-	constexpr bool IQ8 = IN == SD_IN_IQ8, IQ16 = IN == SD_IN_IQ16 || IQ8, IS_IQ = IN == SD_IN_IQ || IQ16, BINS = IN == SD_IN_BINS;
+	constexpr bool IQ8 = IN == SD_IN_IQ8, IQ16 = IN == SD_IN_IQ16 || IQ8, IS_IQ = IN == SD_IN_IQ || IQ16;
 	constexpr bool IQ16D4 = IQ16 && DEC == 4;                                 // one load of four samples = one decimated sample each (16 bytes; int8: 8)
 	// what one lane holds per load: two input samples (IQ; four in the integer 4:1 classes), four (real)
 	using LoadT = typename std::conditional<IQ8, typename std::conditional<IQ16D4, uint2, uint32_t>::type,
@@ -249,32 +194,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			}
 		}
 	};
-	// SD_IN_BINS (SPEC 3.5 / 3.5b, round 4): the rows hold one PHASE sample (quadrants) per 20 kS/s step of a channelizer bin.  Wave kw
-	// produces the decimated samples n in [N0, N0 + 128), N0 = 512 tile + 128 kw, in groups u = a_grp + lane of three (the three
-	// that the five discriminator samples d[5u .. 5u + 4] complete), a_grp = floor((2048 tile + 512 kw) / 12); it needs
-	// d[5 a_grp - 15 .. 5 a_grp + 224], i.e. the phases from index 5 a_grp - 16 on: 4 four-byte loads per lane, element
-	// e = lane + 64 q <-> phi[5 a_grp - 16 + e] (block-relative)
-	constexpr int NB2 = 4;
-	float wa[NB2];
-	const int bins_n = BINS ? (n_tiles / 3) * 2560 : 0;                       // phase samples per bin in this submit (3 tiles = 6144 outputs = 2560 inputs)
-	auto bins_grp = [&](int tile) { return (2048u * (uint32_t)tile + 512u * (uint32_t)kw) / 12u; };
-	auto load_bins = [&](int tile, float (&w)[NB2]) {
-		const float *x = in + (size_t)row * ch_stride;
-		const int base = 5 * (int)bins_grp(tile) - 16 + lane;
-#pragma unroll
-		for (int q = 0; q < NB2; q++) {
-			int i = base + 64 * q;
-			i = i < 0 ? 0 : (i >= bins_n ? bins_n - 1 : i);                       // elements outside the block are never used (or patched, tile 0)
-			w[q] = x[i];
-		}
-	};
 	if (is_k) {
-		if (BINS) {
-			load_bins(0, wa);
-		} else {
-			load_vec(0, va);
-			if (n_tiles > 1) load_vec(1, vb);
-		}
+		load_vec(0, va);
+		if (n_tiles > 1) load_vec(1, vb);
 	}
 
 	SdChanState st = states[ch];
@@ -361,12 +283,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const bool fec_here = is_rs41 && fuse;     // workgroup-uniform
 	EpiTabs &et = *reinterpret_cast<EpiTabs *>(&s.X[1][SD_EPI_TAB_OFF]);
 	// Round 3: clean frames can be decoded INSIDE the tile loop, by round wave 2, a step per round (sd_rs41_loop_step); its
-	// work area sits in the part of A[1] no decimated tile uses (the bins path keeps its scratch there).
+	// work area sits in the part of A[1] no decimated tile uses.
 	// Only where it pays (interleaved A/B, tools/ab_repeat.sh, profiles/r3_notes.md): launches whose workgroups are ALL resident at
 	// once -- their epilogues coincide, nothing else streams meanwhile: 1024 x 96 tiles -1.6 % at 14 dB, -1.1 % at 9 dB -- and long
 	// enough (>= 48 tiles; at 24 the steps of the 1.6 frames a submit completes stall as much as they save).  In launches of several
 	// generations the epilogues overlap other workgroups' streaming for free and the steps only stall: 4096 x 96 tiles +7 %.
-	const bool fec_loop = fec_here && !BINS && n_tiles >= 48 && gridDim.x <= fo->loop_fec_max_wg;
+	const bool fec_loop = fec_here && n_tiles >= 48 && gridDim.x <= fo->loop_fec_max_wg;
 	FramerLds &loop_wl = *reinterpret_cast<FramerLds *>(&s.A[1][1100]);
 	static_assert(sizeof(FramerLds) <= (SD_BUF - 1100) * sizeof(float), "in-loop FEC work area");
 	if (tid == 3 * 64 - 1) { s.fec.frame = 0; s.fec.phase = 0; s.fec.done_mask = 0; }      // (wave 2: the wave that uses it)
@@ -514,84 +436,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			}
 		}
 		if (IS_IQ) last_iq = make_float2(cx, cy);      // wave 7: the last (decimated) sample of the tile
-	};
-
-	// SD_IN_BINS: discriminator (wrapped difference of consecutive phases) into a wave-private LDS scratch, then the composite
-	// resampler + decimator (SPEC 3.5b) straight into buffer b.  Scratch: the part of a tile buffer a 4:1 tile never uses (from 584),
-	// one buffer per wave, 256 floats.  Wave 3 shares X[1] with the FEC tables (at 1100): its scratch sits at X[1][600..856).
-	float *const bscr = !BINS ? nullptr : (kw == 0 ? &s.A[0][1100] : kw == 1 ? &s.A[1][1100] : kw == 2 ? &s.X[0][1100] : &s.X[1][600]);
-	static_assert(!BINS || DEC == 4, "the bins path serves the 12 kS/s sondes (4:1 class): a 19.5 kHz bin cannot carry an M10 channel");
-	static_assert(SD_LH + SD_TILE / 4 + 4 <= 600 && 600 + 64 * NB2 <= SD_EPI_TAB_OFF && 1100 + 64 * NB2 <= SD_BUF && 5 * 44 + 20 <= 64 * NB2, "scratch regions");
-	float bins_last = 0.0f;
-	if (BINS && is_k) {
-		// the composite taps (3 rows of 20): every discriminator wave writes the same 60 values (identical stores may race), then
-		// reads them behind its own stores; the first wave of the block also needs the carried history
-		if (lane < 3 * SD_RS_KT_LD) s.rs_g[lane] = bins_in->g[lane];
-		if (kw == 0) {
-			if (lane < 16) s.rs_dh[lane] = bins_in->dhist[(size_t)ch * 16 + lane];
-			bins_last = bins_in->phi_last[ch];
-		}
-	}
-	auto k1_bins = [&](int b, int tile, float (&w)[NB2]) {
-		const bool first = tile == 0 && kw == 0;                 // wave-uniform: the block's first wave (elements 0..15 lie before the block)
-		const uint32_t a_grp = bins_grp(tile);
-		float cx = 0.0f;
-#pragma unroll
-		for (int q = 0; q < NB2; q++) {
-			// lane l takes lane l - 1's phase, lane 0 the carry: one DPP move (wave_shr:1)
-			float pv = sd_wave_shr1(w[q], cx);
-			if (q == 0 && first && lane == 16) pv = bins_last;                              // element 16 is phi[0]: its predecessor is carried
-			float d = sd_phase_diff(w[q], pv);
-			if (q == 0 && first && lane < 16) d = s.rs_dh[lane];                             // elements 1..15 are d[-15..-1]: carried
-			// element e = lane + 64 q is d[5 a_grp - 16 + e]; the scratch starts at d[5 a_grp - 15]: element 0 only carries a phase
-			if (q > 0 || lane > 0) bscr[lane + 64 * q - 1] = d;
-			cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[q]), 63));
-		}
-		const float w_last = w[NB2 - 1];
-		// the phases are consumed: the next tile's go out into the same registers now (ONE register set)
-		if (tile + 1 < n_tiles) load_bins(tile + 1, w);
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		// SPEC 3.5b: resampler and boxcar decimator as ONE polyphase filter, z[n] = sum_k fmaf(G[n mod 3][k], d[b(n) - k], acc),
-		// k < 17 ascending, b(n) = floor(5 (4 n + 3) / 12).  Lane <-> group u: the 3 decimated samples n = 3 u + c that the five
-		// discriminator samples d[5 u .. 5 u + 4] complete (12 resampler outputs); it reads d[5 u - 15 .. 5 u + 4] from LDS once (20
-		// dwords, lanes 20 bytes apart: conflict-free) and indexes them statically; the tap row of sample c is the same for every lane:
-		// broadcast reads.  17 multiply-adds per decimated sample where "resample, then average" took 64.
-		constexpr int PER_WAVE = SD_TILE / DEC / 4;              // decimated samples a wave produces per tile: 128
-		const uint32_t N0 = (2048u * (uint32_t)tile + 512u * (uint32_t)kw) / (uint32_t)DEC;
-		{
-			const int ul = lane < 45 ? lane : 45;                                // 43-44 groups carry outputs of this wave
-			const float *dp = bscr + 5 * ul;
-			float dv[20];
-#pragma unroll
-			for (int k = 0; k < 20; k++) dv[k] = dp[k];
-#pragma unroll
-			for (int c = 0; c < 3; c++) {
-				constexpr int BO[3] = {1, 2, 4};
-				const int bo = BO[c] + 15;                                         // dv index of d[b(n)]
-				float gt[20];
-#pragma unroll
-				for (int q = 0; q < 5; q++) {
-					const float4 g4 = *reinterpret_cast<const float4 *>(&s.rs_g[SD_RS_KT_LD * c + 4 * q]);
-					gt[4 * q] = g4.x; gt[4 * q + 1] = g4.y; gt[4 * q + 2] = g4.z; gt[4 * q + 3] = g4.w;
-				}
-				float acc = 0.0f;
-#pragma unroll
-				for (int t = 0; t < SD_RS_KT; t++) acc = __builtin_fmaf(gt[t], dv[bo - t], acc);
-				const uint32_t jr = 3u * (a_grp + (uint32_t)ul) + (uint32_t)c - N0;      // index inside the wave's span (wraps below N0)
-				if (jr < (uint32_t)PER_WAVE && lane < 45) store_one(s, b, (uint32_t)PER_WAVE * (uint32_t)kw + jr, acc);
-			}
-		}
-		if (tile == n_tiles - 1 && kw == 3) {
-			// the block's last wave: carry the last 16 discriminator samples and the last phase to the next submit (read by the first
-			// wave at the top of the next launch).  For this wave 5 a_grp - 16 = bins_n - 231: phi[bins_n - 1] is element 230
-			// (lane 38 of load 3), d[bins_n - 16 ..] the scratch entries 214..229
-			constexpr int E_LAST = 230;
-			if (lane < 16) bins_in->dhist[(size_t)ch * 16 + lane] = bscr[E_LAST - 16 + lane];
-			if (lane == (E_LAST & 63)) bins_in->phi_last[ch] = w_last;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-		__builtin_amdgcn_wave_barrier();                         // the next k1 of this wave rewrites the scratch
 	};
 
 	// ================================================================ round role (waves 0-3)
@@ -755,14 +599,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	};
 	if (is_k) {
 		// register set A holds the even tiles, set B the odd ones (the arguments are literals at every call: static register sets)
-		auto k1A = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, tile, va, pa, qa); };
-		auto k1B = [&](int b, int tile) { if constexpr (BINS) k1_bins(b, tile, wa); else k1_tile(b, tile, vb, pb, qb); };
-		auto ldA = [&](int tile) { if constexpr (!BINS) load_tile(tile, va, pa, qa); };
-		auto ldB = [&](int tile) { if constexpr (!BINS) load_tile(tile, vb, pb, qb); };
-		if (!BINS) {
-			load_prev(0, pa, qa);          // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
-			if (n_tiles > 1) load_prev(1, pb, qb);
-		}
+		auto k1A = [&](int b, int tile) { k1_tile(b, tile, va, pa, qa); };
+		auto k1B = [&](int b, int tile) { k1_tile(b, tile, vb, pb, qb); };
+		auto ldA = [&](int tile) { load_tile(tile, va, pa, qa); };
+		auto ldB = [&](int tile) { load_tile(tile, vb, pb, qb); };
+		load_prev(0, pa, qa);          // (the vector loads of tiles 0 and 1 went out at the top of the kernel)
+		if (n_tiles > 1) load_prev(1, pb, qb);
 		k1A(0, 0);
 		if (n_tiles > 2) ldA(2);
 		__syncthreads();
@@ -918,23 +760,17 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */, const SdBinsIn *bins_in /* device memory; SD_IN_BINS only */,
-	int utype)
+	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */, int utype)
 {
 	const dim3 g(n_channels), blk(SD_WGT);
 	const int ci = compact_in ? 1 : 0;
-#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo, bins_in, utype
+#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo, utype
 #define SD_DEMOD_LAUNCH(KIND, LS) do { \
 		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else if (decim == 2 && nt == 8) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else if (decim == 2) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 2, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 1, 16>), g, blk, 0, stream, SD_DEMOD_ARGS); } while (0)
-	if (in_kind == SD_IN_BINS) {
-		// channelizer bins (20 kS/s phases): the 12 kS/s sondes only, class (4, 8) (the host checks: sd_batch_bins_capable)
-		// (one class, no AFSK: always the plain launch over all bins)
-		hipLaunchKernelGGL((sd_demod_kernel<SD_IN_BINS, false, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS);
-	}
-	else if (in_kind == SD_IN_IQ8 && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ8, false);
+	if (in_kind == SD_IN_IQ8 && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ8, false);
 	else if (in_kind == SD_IN_IQ8) SD_DEMOD_LAUNCH(SD_IN_IQ8, true);
 	else if (in_kind == SD_IN_IQ16 && !chlist) SD_DEMOD_LAUNCH(SD_IN_IQ16, false);
 	else if (in_kind == SD_IN_IQ16) SD_DEMOD_LAUNCH(SD_IN_IQ16, true);

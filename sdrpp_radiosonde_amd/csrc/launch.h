@@ -18,16 +18,21 @@ struct SdFramerOut {
 	const uint8_t *gf64;                    // GF(2^6) tables of the iMS-100 BCH decoder
 	SondeFrame *frames;
 };
-// in_kind: SD_IN_REAL / SD_IN_IQ (48 kS/s rows) or SD_IN_BINS (40 kS/s complex channelizer bins: the kernel runs the per-bin
-// discriminator and the 6/5 resampler in its load path; bins_in: taps and carried state, device memory)
+// in_kind: what the 48 kS/s rows hold (SD_IN_REAL / SD_IN_IQ / SD_IN_IQ16 / SD_IN_IQ8)
 void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */,
-	const SdBinsIn *bins_in /* SD_IN_BINS only, else null */,
 	int utype /* >= 0: every channel of the launch is of this sonde type (taps / modem loads need not wait for the state); -1: per channel */);
-// the batch object behind a channelizer takes its input as bins (channelizer.hip): 3 tiles per 5120 bin samples
-int sd_batch_submit_bins(SondeBatch *b, const void *bins, size_t n_steps, size_t channel_stride, const SdBinsIn *d_bins_in, void *stream);
+// The decoder behind the filter bank (bins_kernel.hip): one wave per bin; rows of 16-bit phases [16 carried | n_steps]; the last 16
+// phases of the submit go to the head of carry_rows' rows (the buffer the next submit reads: the same one unless double-buffered)
+struct SdBinsArgs { const int16_t *phases; size_t row_stride; int16_t *carry_rows; size_t carry_stride; const float *g_comp /* [3][SD_RS_KT_LD], device */; };
+void sd_launch_bins(uint32_t n_channels, hipStream_t stream, const int16_t *phases, size_t row_stride, int n_blocks,
+	int16_t *carry_rows, size_t carry_stride, SdChanState *states, float *hist, uint32_t *bitring, uint32_t ring_words,
+	const float *taps_all, const SdModem *modems_host /* [SONDE_NTYPES], HOST memory: passed by value */, const SdFramerOut *fo_host /* HOST copy: by value */,
+	const float *g_comp, int utype /* >= 0: every bin is of this sonde type; -1: per bin */);
+// the batch object behind a channelizer takes its input as phase rows (channelizer.hip): 3 tiles per 2560 phase samples
+int sd_batch_submit_bins(SondeBatch *b, const SdBinsArgs *ba, size_t n_steps, void *stream);
 int sd_batch_bins_capable(const SondeBatch *b);      // 1: every channel's class has a bins instantiation (no AFSK sonde, no class without one)
 
 void sd_launch_afsk(int type /* SONDE_IMET4 or SONDE_C50 */, int kind /* 0 real, 1 complex64, 2 int16 IQ pairs */, uint32_t n_list, hipStream_t stream, const float *in, size_t ch_stride, int n_tiles,

@@ -65,11 +65,12 @@ __device__ __forceinline__ bool sync_match(uint32_t w0, uint32_t w1, uint32_t w2
 
 // K4 for one fixed-length sonde type: the state machine of sd_sync_fixed_kernel (framer2_kernel.hip), advanced over
 // the bits [.., wp) with one candidate position per lane; `mirror` as in sd_rs41_sync_step.
-template <int T>
+template <int T, bool REG = false>      // REG: as sd_rs41_sync_step
 __device__ __forceinline__ void sd_fixed_sync_step(SdSyncRun &lds_state, uint64_t wp, const uint32_t *mirror, int lane,
-	SdFrameDesc *__restrict__ descs_ch, uint32_t max_frames)
+	SdFrameDesc *__restrict__ descs_ch, uint32_t max_frames, SdFrameDesc *list = nullptr)
 {
 	typedef SyncTraits<T> Tr;
+	if (!REG) list = lds_state.list;
 	SdSyncRun fs;
 	fs.rpos = sd_uniform64(lds_state.rpos); fs.fstart = sd_uniform64(lds_state.fstart);
 	fs.collecting = __builtin_amdgcn_readfirstlane(lds_state.collecting);
@@ -80,23 +81,33 @@ __device__ __forceinline__ void sd_fixed_sync_step(SdSyncRun &lds_state, uint64_
 		if (!fs.collecting) {
 			bool found = false;
 			while (fs.rpos + Tr::WIN <= wp) {
-				const uint64_t pos = fs.rpos + (uint64_t)lane;
-				const uint32_t wi = (uint32_t)(pos >> 5);
-				const int sh = (int)((uint32_t)pos & 31u);
-				const uint32_t w0 = mirror[wi & (SD_MIRROR_WORDS - 1)], w1 = mirror[(wi + 1) & (SD_MIRROR_WORDS - 1)],
-				               w2 = mirror[(wi + 2) & (SD_MIRROR_WORDS - 1)];
-				int inv;
-				const bool hit = sync_match<T>(w0, w1, w2, sh, inv) && pos + Tr::WIN <= wp;
-				const unsigned long long hm = __ballot(hit);
-				if (hm) {
-					const int fl = __ffsll((long long)hm) - 1;            // the earliest position wins
-					fs.fstart = fs.rpos + (uint64_t)fl;
-					fs.inv = __builtin_amdgcn_readlane(inv, fl);
-					fs.collecting = 1;
-					found = true;
-					break;
+				constexpr int NCH = REG ? 4 : 1;          // chunks of 64 candidate positions per trip (as sd_rs41_sync_step)
+				unsigned long long hm[NCH];
+				int invv[NCH];
+#pragma unroll
+				for (int j = 0; j < NCH; j++) {
+					const uint64_t pos = fs.rpos + (uint64_t)(64 * j + lane);
+					const uint32_t wi = (uint32_t)(pos >> 5);
+					const int sh = (int)((uint32_t)pos & 31u);
+					const uint32_t w0 = mirror[wi & (SD_MIRROR_WORDS - 1)], w1 = mirror[(wi + 1) & (SD_MIRROR_WORDS - 1)],
+					               w2 = mirror[(wi + 2) & (SD_MIRROR_WORDS - 1)];
+					int inv;
+					const bool hit = sync_match<T>(w0, w1, w2, sh, inv) && pos + Tr::WIN <= wp;
+					hm[j] = __ballot(hit);
+					invv[j] = inv;
 				}
-				uint64_t next = fs.rpos + 64;
+#pragma unroll
+				for (int j = 0; j < NCH; j++) {
+					if (!found && hm[j]) {
+						const int fl = __ffsll((long long)hm[j]) - 1;         // the earliest position wins
+						fs.fstart = fs.rpos + (uint64_t)(64 * j + fl);
+						fs.inv = __builtin_amdgcn_readlane(invv[j], fl);
+						fs.collecting = 1;
+						found = true;
+					}
+				}
+				if (found) break;
+				uint64_t next = fs.rpos + 64 * NCH;
 				if (next > wp - (Tr::WIN - 1)) next = wp - (Tr::WIN - 1);
 				fs.rpos = next;
 			}
@@ -107,11 +118,16 @@ __device__ __forceinline__ void sd_fixed_sync_step(SdSyncRun &lds_state, uint64_
 			SdFrameDesc d;
 			d.fstart = fs.fstart; d.flen = Tr::FRAME_CHIPS; d.inv = fs.inv;
 			descs_ch[fs.nout] = d;
-			if (fs.nout < SD_K4_LIST) lds_state.list[fs.nout] = d;
+			if (fs.nout < SD_K4_LIST) list[fs.nout] = d;
 		}
 		fs.nout++;
 		fs.rpos = fs.fstart + (uint64_t)Tr::FRAME_CHIPS;
 		fs.collecting = 0;
+	}
+	if (REG) {
+		lds_state.rpos = fs.rpos; lds_state.fstart = fs.fstart;
+		lds_state.collecting = fs.collecting; lds_state.inv = fs.inv; lds_state.flen = 0; lds_state.nout = fs.nout;
+		return;
 	}
 	if (lane == 0) {
 		lds_state.rpos = fs.rpos; lds_state.fstart = fs.fstart;

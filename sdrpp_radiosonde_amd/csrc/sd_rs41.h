@@ -42,9 +42,13 @@ __device__ __forceinline__ uint64_t sd_uniform64(unsigned long long v)    // a v
 // SD_MIRROR_WORDS * 32 bits (word w of the stream at mirror[w % SD_MIRROR_WORDS]); the caller guarantees that the
 // search never trails wp by more than that (it is called at least once per tile).  Wave-synchronous, 64 lanes,
 // all control flow wave-uniform.
+// REG: `lds_state` is a register-resident copy owned by the calling wave alone (bins_kernel.hip: one wave per channel), its list of
+// the first frames lives at `list` (LDS); else the state sits in LDS between steps (kernel A) and list = lds_state.list.
+template <bool REG = false>
 __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t wp, const uint32_t *mirror, int lane,
-	SdFrameDesc *__restrict__ descs_ch, uint32_t max_frames)
+	SdFrameDesc *__restrict__ descs_ch, uint32_t max_frames, SdFrameDesc *list = nullptr)
 {
+	if (!REG) list = lds_state.list;
 	SdSyncRun fs;
 	fs.rpos = sd_uniform64(lds_state.rpos); fs.fstart = sd_uniform64(lds_state.fstart);
 	fs.collecting = __builtin_amdgcn_readfirstlane(lds_state.collecting);
@@ -57,24 +61,36 @@ __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t
 		if (!fs.collecting) {
 			bool found = false;
 			while (fs.rpos + 64 <= wp) {
-				const uint64_t pos = fs.rpos + (uint64_t)lane;
-				const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)pos & 31u;
-				const uint32_t w0 = mirror[wi & (SD_MIRROR_WORDS - 1)], w1 = mirror[(wi + 1) & (SD_MIRROR_WORDS - 1)],
-				               w2 = mirror[(wi + 2) & (SD_MIRROR_WORDS - 1)];
-				const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-				const int hd = __popc(lo ^ RS41_SYNC_LO) + __popc(hi ^ RS41_SYNC_HI);
-				const bool hit = pos + 64 <= wp && (hd <= RS41_SYNC_THR || hd >= 64 - RS41_SYNC_THR);
-				const unsigned long long hm = __ballot(hit);
-				if (hm) {
-					const int fl = __ffsll((long long)hm) - 1;            // the earliest position wins
-					fs.fstart = fs.rpos + (uint64_t)fl;
-					fs.inv = __builtin_amdgcn_readlane(hd, fl) >= 64 - RS41_SYNC_THR;
-					fs.collecting = 1;
-					fs.flen = 0;
-					found = true;
-					break;
+				// NCH chunks of 64 candidate positions per trip (REG: a wave that sees a whole tile's bits at once: one LDS round trip
+				// instead of four); positions are still tried in ascending order: the earliest hit of the earliest chunk wins
+				constexpr int NCH = REG ? 4 : 1;
+				unsigned long long hm[NCH];
+				int hdv[NCH];
+#pragma unroll
+				for (int j = 0; j < NCH; j++) {
+					const uint64_t pos = fs.rpos + (uint64_t)(64 * j + lane);
+					const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)pos & 31u;
+					const uint32_t w0 = mirror[wi & (SD_MIRROR_WORDS - 1)], w1 = mirror[(wi + 1) & (SD_MIRROR_WORDS - 1)],
+					               w2 = mirror[(wi + 2) & (SD_MIRROR_WORDS - 1)];
+					const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+					const int hd = __popc(lo ^ RS41_SYNC_LO) + __popc(hi ^ RS41_SYNC_HI);
+					const bool hit = pos + 64 <= wp && (hd <= RS41_SYNC_THR || hd >= 64 - RS41_SYNC_THR);
+					hm[j] = __ballot(hit);
+					hdv[j] = hd;
 				}
-				uint64_t next = fs.rpos + 64;
+#pragma unroll
+				for (int j = 0; j < NCH; j++) {
+					if (!found && hm[j]) {
+						const int fl = __ffsll((long long)hm[j]) - 1;         // the earliest position wins
+						fs.fstart = fs.rpos + (uint64_t)(64 * j + fl);
+						fs.inv = __builtin_amdgcn_readlane(hdv[j], fl) >= 64 - RS41_SYNC_THR;
+						fs.collecting = 1;
+						fs.flen = 0;
+						found = true;
+					}
+				}
+				if (found) break;
+				uint64_t next = fs.rpos + 64 * NCH;
 				if (next > wp - 63) next = wp - 63;                       // first position whose window is not complete yet
 				fs.rpos = next;
 			}
@@ -93,12 +109,17 @@ __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t
 			SdFrameDesc d;
 			d.fstart = fs.fstart; d.flen = fs.flen; d.inv = fs.inv;
 			descs_ch[fs.nout] = d;
-			if (fs.nout < SD_K4_LIST) lds_state.list[fs.nout] = d;
+			if (fs.nout < SD_K4_LIST) list[fs.nout] = d;
 		}
 		fs.nout++;
 		fs.rpos = fs.fstart + 8 * (uint64_t)fs.flen;
 		fs.collecting = 0;
 		fs.flen = 0;
+	}
+	if (REG) {
+		lds_state.rpos = fs.rpos; lds_state.fstart = fs.fstart;
+		lds_state.collecting = fs.collecting; lds_state.inv = fs.inv; lds_state.flen = fs.flen; lds_state.nout = fs.nout;
+		return;
 	}
 	if (lane == 0) {
 		lds_state.rpos = fs.rpos; lds_state.fstart = fs.fstart;

@@ -24,19 +24,11 @@
 // what the demod kernel's input rows hold
 #define SD_IN_REAL 0        // 48 kS/s FM-discriminator samples (float)
 #define SD_IN_IQ   1        // 48 kS/s complex samples
-#define SD_IN_BINS 2        // 20 kS/s PHASE samples of a channelizer bin (one float each): discriminator (wrapped difference) + composite
-                            // 12/5 resampler - 4:1 decimator in the kernel (SPEC 3.5b)
 #define SD_IN_IQ16 3        // 48 kS/s complex samples as 16-bit integers (I, Q interleaved: what SDR hardware and WAV recordings hold): half the
                             // bytes of SD_IN_IQ per sample; converted exactly (int16 -> float, no scaling) in the load path, then SD_IN_IQ's arithmetic
 #define SD_IN_IQ8  4        // the same as 8-bit integers (int8 I, int8 Q): 2 bytes per sample
-#define SD_RS_KT_LD 20      // row stride of the composite taps (17 in use)
+#define SD_RS_KT_LD 20      // row stride of the composite 12/5 resampler - 4:1 decimator taps of SPEC 3.5b (17 in use; bins_kernel.hip)
 #define SD_RS_KT    17
-struct SdBinsIn {           // SD_IN_BINS: composite taps and the state carried from block to block (device pointers)
-	const float *g;         // [3][SD_RS_KT_LD]
-	float       *phi_last;  // per channel: the last phase sample of the previous block
-	float       *dhist;     // per channel: the last 16 discriminator samples of the previous block, oldest first
-};
-
 struct SdModem {            // per sonde type, built on the host
 	int32_t period0;        // Q16 internal-rate samples per symbol
 	float   kp;             // proportional gain, Q16 samples per unit error
