@@ -39,7 +39,6 @@ struct BinsWaveLds {
 struct BinsLds {
 	BinsWaveLds w[BK_WAVES];
 	alignas(16) float taps[BK_SLOTS][SD_NPHASE * SD_TAPS_LD];
-	alignas(16) float rs_g[3 * SD_RS_KT_LD + 4];     // composite taps x 2^-14 (the discriminator samples stay integers)
 	EpiTabs et;
 };
 static_assert(sizeof(FramerLds) <= sizeof(float) * BK_A, "the FEC work area aliases the tile buffer");
@@ -51,9 +50,7 @@ __device__ __forceinline__ int bk_slot(int type) { return type == SONDE_RS41 ? 0
 __device__ unsigned long long g_bk_ts[64];
 extern "C" int sonde_debug_bins_ts(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bk_ts), sizeof(g_bk_ts)) == hipSuccess ? 0 : -1; }
 #define BK_STAMP(i) do { if (ch == 1000u && lane == 0) g_bk_ts[i] = __builtin_readcyclecounter(); } while (0)
-#define BK_WAITALL(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); BK_STAMP(i); } while (0)
 #else
-#define BK_WAITALL(i) do { } while (0)
 #define BK_STAMP(i) do { } while (0)
 #endif
 
@@ -72,7 +69,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 	const int16_t *__restrict__ phases, size_t row_stride /* int16 elements per bin row: [16 carried | n_steps] */, int n_blocks,
 	int16_t *__restrict__ carry_rows, size_t carry_stride /* where the last 16 phases go: the head of the row the next submit reads */,
 	SdChanState *__restrict__ states, float *__restrict__ hist, uint32_t *__restrict__ bitring, uint32_t ring_words,
-	const float *__restrict__ taps_all, const float *__restrict__ g_comp /* [3][SD_RS_KT_LD] */, uint32_t n_channels, const SdBinsParams P)
+	const float *__restrict__ taps_all, const float *__restrict__ g_comp /* [3][SD_RS_KT_LD], x 2^-14: the discriminator samples stay integers */, uint32_t n_channels, const SdBinsParams P)
 {
 	__shared__ __attribute__((aligned(16))) BinsLds s;
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -95,7 +92,6 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		// pass gp reads phase elements [320 gp - 16, 320 gp + 320) of the submit = row elements [320 gp, 320 gp + 336)
 		p = lane < 42 ? row128[40 * (size_t)gp + lane] : make_uint4(0u, 0u, 0u, 0u);
 	};
-	const float gq = lane < 3 * SD_RS_KT_LD ? g_comp[lane] : 0.0f;
 	load_pass(0, ph[0]); load_pass(1, ph[1]); load_pass(2, ph[2]);
 	// the channel's state and K4's state come through VECTOR loads (a dword per lane, fields by v_readlane): 4096 waves asking the
 	// scalar data cache for 64 private bytes each at the same moment waited 5 800 cycles for them (tools/bk_ts.py); a vector load 500
@@ -128,7 +124,6 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 			*reinterpret_cast<float4 *>(&taps[rowi * SD_TAPS_LD + 4 * c4]) = make_float4(tv.y, tv.x, tv.w, tv.z);
 		}
 	}
-	s.rs_g[lane < 3 * SD_RS_KT_LD ? lane : 3 * SD_RS_KT_LD] = gq * (1.0f / 16384.0f);      // exact: a power of two (every wave writes the same values)
 	if (lane < 10) w.chunk[lane] = 0u;
 	WAVE_SYNC();
 	BK_STAMP(1);
@@ -163,12 +158,9 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		for (int c = 0; c < 3; c++) {
 			constexpr int BO[3] = {1, 2, 4};
 			const int bo = BO[c] + 15;
-			float gt[20];
-#pragma unroll
-			for (int q = 0; q < 5; q++) {
-				const float4 g4 = *reinterpret_cast<const float4 *>(&s.rs_g[SD_RS_KT_LD * c + 4 * q]);
-				gt[4 * q] = g4.x; gt[4 * q + 1] = g4.y; gt[4 * q + 2] = g4.z; gt[4 * q + 3] = g4.w;
-			}
+			// the composite tap row: wave-uniform addresses of a read-only table = scalar loads, the taps SGPR operands of the multiply-adds
+			// (as broadcast LDS reads they were 15 of a pass's 31 LDS instructions, and the LDS pipe is this kernel's busiest unit)
+			const float *gt = g_comp + SD_RS_KT_LD * c;
 			float acc = 0.0f;
 #pragma unroll
 			for (int t = 0; t < SD_RS_KT; t++) acc = __builtin_fmaf(gt[t], dv[bo - t], acc);
@@ -219,10 +211,8 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 				if (lane == 0) { w.chunk[1 + 2 * (hh + h)] = (uint32_t)bal; w.chunk[2 + 2 * (hh + h)] = (uint32_t)(bal >> 32); }
 			}
 		}
-		BK_STAMP(20);
 		const int E = wave_sum(Ei), S1 = wave_sum(S1i), S0 = wave_sum(S0i);
 		WAVE_SYNC();
-		BK_STAMP(21);
 		if (K <= 0) return;
 		// ---- the round's bits into the ring (HBM) and its mirror
 		if (lane < 9) {
@@ -240,7 +230,6 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		}
 		partial = (uint32_t)__builtin_amdgcn_readlane((int)partial, (int)((((uint32_t)wpos & 31u) + (uint32_t)K) >> 5));
 		wpos += (uint64_t)K;
-		BK_STAMP(22);
 		// ---- slicer levels and the PI loop filter (the lead wave's round_back of kernel A, here in line)
 		const int C0 = K - C1;
 		if (C1 > 0 && C0 > 0) {
@@ -266,7 +255,6 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		st.period += dper;
 		if (st.period < md.pmin) st.period = md.pmin;
 		if (st.period > md.pmax) st.period = md.pmax;
-		BK_STAMP(23);
 		// ---- K4: the sync search over the bits that are now in the mirror
 		if (framing) {
 			WAVE_SYNC();
@@ -278,7 +266,6 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 			else sd_fixed_sync_step<SONDE_MRZN1, true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
 		}
 	};
-	// (stamps 20-23 are overwritten by every tile: the last tile's remain)
 	// the tile is consumed: its last 64 samples become the history, what the last pass produced beyond it the head of the next tile
 	auto roll = [&]() {
 		const float h0 = w.A[BK_IT + lane], h1 = w.A[BK_IT + 64 + lane], h2 = w.A[BK_IT + 128 + lane];
@@ -290,8 +277,8 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 	// ---- a block = 8 passes = 3 tiles: passes 0-2 complete tile 0 (64 samples beyond it), 3-5 tile 1 (128 beyond), 6-7 tile 2
 	for (int b = 0; b < n_blocks; b++) {
 		const int gp = 8 * b;
-		load_pass(gp + 3, ph[3]);                         pass(ph[0], SD_LH + 0);     BK_STAMP(3);
-		load_pass(gp + 4, ph[0]);                         pass(ph[1], SD_LH + 192);   BK_STAMP(4);
+		load_pass(gp + 3, ph[3]);                         pass(ph[0], SD_LH + 0);     
+		load_pass(gp + 4, ph[0]);                         pass(ph[1], SD_LH + 192);   
 		load_pass(gp + 5, ph[1]);                         pass(ph[2], SD_LH + 384);   BK_STAMP(5);
 		if (b == 0) {
 			// what the timing loop needs from the head of the wave's life has arrived by now: history, the ring's newest words, K4's state
@@ -304,12 +291,12 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 			WAVE_SYNC();
 			BK_STAMP(2);
 		}
-		tile_rounds(); BK_STAMP(6); roll(); BK_STAMP(7);
-		load_pass(gp + 6, ph[2]);                         pass(ph[3], SD_LH + 64);    BK_STAMP(8);
-		load_pass(gp + 7, ph[3]);                         pass(ph[0], SD_LH + 256);   BK_STAMP(9);
+		tile_rounds(); BK_STAMP(6); roll(); 
+		load_pass(gp + 6, ph[2]);                         pass(ph[3], SD_LH + 64);    
+		load_pass(gp + 7, ph[3]);                         pass(ph[0], SD_LH + 256);   
 		if (gp + 8 < n_pass) load_pass(gp + 8, ph[0]);    pass(ph[1], SD_LH + 448);   BK_STAMP(10);
 		tile_rounds(); BK_STAMP(11); roll();
-		if (gp + 9 < n_pass) load_pass(gp + 9, ph[1]);    pass(ph[2], SD_LH + 128);   BK_STAMP(12);
+		if (gp + 9 < n_pass) load_pass(gp + 9, ph[1]);    pass(ph[2], SD_LH + 128);   
 		if (gp + 10 < n_pass) load_pass(gp + 10, ph[2]);  pass(ph[3], SD_LH + 320);   BK_STAMP(13);
 		tile_rounds(); BK_STAMP(14); roll();
 	}

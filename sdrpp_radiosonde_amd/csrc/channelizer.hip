@@ -452,6 +452,7 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 	if (ok) {
 		float gc[3 * SD_RS_KT_LD];
 		composite_rows(g, 4, gc);
+		for (float &v : gc) v *= 1.0f / 16384.0f;      // the bins decoder keeps the discriminator samples as 16-bit integers: the scale (a power of two: exact) sits in the taps
 		ok = hipMalloc((void **)&c->d_gc, sizeof(gc)) == hipSuccess && hipMemcpy(c->d_gc, gc, sizeof(gc), hipMemcpyHostToDevice) == hipSuccess;
 		if (ok && dual) {                     // the odd-stacked bank's tables: taps of odd t negated, twist exp(-j pi r / 512)
 			const double PI = 3.14159265358979323846;

@@ -18,9 +18,6 @@ assert L.sonde_debug_bins_ts(ts) == 0
 t = np.array(list(ts), dtype=np.int64)
 names = {0: "start", 1: "prologue issued", 2: "barrier", 3: "pass0", 4: "pass1", 5: "pass2", 6: "tile0 rounds", 7: "roll", 8: "pass3", 9: "pass4", 10: "pass5",
          11: "tile1 rounds", 12: "pass6", 13: "pass7", 14: "tile2 rounds", 15: "state saved", 16: "end"}
-prev = t[0]
-for i in range(17):
-    print(f"{i:2d} {names[i]:16s} +{t[i] - prev:7d}  (at {t[i] - t[0]})")
-    prev = t[i]
-print("prologue: kernargs", t[30]-t[0], "g_comp", t[31]-t[30], "phases", t[32]-t[31], "state", t[33]-t[32], "hist", t[34]-t[33], "fstate", t[35]-t[34], "rest (taps)", t[1]-t[35])
-print("last tile: front", t[20] - t[13], "reduce", t[21] - t[20], "ring", t[22] - t[21], "loop filter", t[23] - t[22], "k4", t[14] - t[23])
+for i, nm in ((0, "start"), (1, "loads issued, tables"), (5, "passes 0-2"), (2, "history / ring words in"), (6, "tile 0 rounds"), (10, "roll, passes 3-5"), (11, "tile 1 rounds"),
+              (13, "roll, passes 6-7"), (14, "tile 2 rounds"), (15, "roll, state saved"), (16, "end")):
+    print(f"{nm:26s} at {t[i] - t[0]:6d}")
