@@ -37,23 +37,29 @@
 //      second half's global loads are in flight while the first half is folded;
 //   2. fold: thread = bin residue r, the 16 taps in registers, t ascending across both halves (SPEC 3.5:
 //      v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc));
-//   3. circular shift by (m*D mod 512) + bit reversal into the step's FFT buffer (aliasing the dead window);
-//   4. 512-point radix-2 DIT FFT, one WAVE per time step, 8 points per lane, two transposes through LDS (pfb_fft512);
+//   3. circular shift by (m*D mod 512) into the step's FFT buffer (aliasing the dead window), natural order;
+//   4. 512-point radix-2 DIT FFT, one WAVE per time step, 8 points per lane, two transposes through LDS (pfb_fft512n);
 //   5. phase = atan2q(bin) of the 8 points a lane holds, transposed through LDS into [bin][step], stored as one aligned 32-byte
 //      run per bin (two lanes of 16 bytes).
 // The stream in front of the block (the last CH_H samples of the previous submit) comes from hist_in; the last workgroup of a
 // stream copies this block's tail to hist_out (the other buffer of a ping-pong pair: the first workgroups still read hist_in).
 #define P_S    8
 #define P_NT   (64 * P_S)
-#define P_NSTG 2                                       // staging rounds (halves of the prototype's taps).  Quarters (48.5 KB: three workgroups per
+#ifndef P_NSTG
+#define P_NSTG 2
+#endif                                                 // staging rounds (halves of the prototype's taps).  Quarters (48.5 KB: three workgroups per
                                                        // CU) need <= 85 VGPRs and spill 224 B per lane; the halves take 112 and none (r4_notes.md)
+#ifndef P_WGCU
+#define P_WGCU (P_NSTG == 2 ? 2 : 3)                   // workgroups per CU the staging form aims at
+#endif
 #define P_TC   (CH_T / P_NSTG)                         // taps per round
 #define P_CHW  (P_TC * CH_M + (P_S - 1) * CH_D)       // samples staged per round: 7596
 #define PFB_FB (CH_M + CH_M / 8)                      // FFT buffer per step: one pad element per 8 (bank spread)
 #define P_OT   (P_S + 1)                               // phase tile row stride (floats)
+#define P_LDS  (((P_CHW / 2 + 63) / 64) * 128)          // the window in whole 1 KB pieces (64 lanes x 16 bytes: the LDS-DMA unit): 7680 samples
 static_assert(P_NT == CH_M, "fold: one thread per bin residue; FFT: one wave per step");
-static_assert(P_S * PFB_FB + CH_M / 2 <= P_CHW && CH_M * P_OT <= 2 * P_S * PFB_FB, "FFT buffers + twiddles / phase tile alias the window");
-static_assert(2 * P_CHW * sizeof(float2) <= 160 * 1024 && P_NSTG == 2, "two workgroups per CU");
+static_assert(P_S * PFB_FB <= P_CHW && CH_M * P_OT <= 2 * P_S * PFB_FB, "FFT buffers / phase tile alias the window");
+static_assert(P_WGCU * P_LDS * sizeof(float2) <= 160 * 1024, "workgroups per CU");
 static_assert(P_CHW % 2 == 0 && (P_S * CH_D) % 2 == 0 && CH_H % 2 == 0 && (P_TC * CH_M) % 2 == 0, "16-byte staging loads");
 
 __device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
@@ -64,63 +70,90 @@ __device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
 	a = make_float2(a0.x + tr, a0.y + ti);
 	b = make_float2(a0.x - tr, a0.y - ti);
 }
-__device__ __forceinline__ int pfb_pad(int i) { return i + (i >> 3); }
 
-// 512-point FFT of the bit-reversed, padded buffer fb by one wave; the result stays in registers: e[j] = bin lane + 64 j
-__device__ __forceinline__ void pfb_fft512(float2 *fb, const float2 *s_tw, int lane, float2 (&e)[8])
+// 512-point FFT by one wave of a step's folded window in NATURAL order (fb[n], n < 512; the buffer has PFB_FB = 576 elements).
+// The arithmetic is the radix-2 decimation-in-time FFT of SPEC 3.5 / oracle or_fft512 butterfly for butterfly -- the same operands
+// meet the same twiddles in the same order -- only who holds what differs: three passes of three stages over 8 values per lane,
+//   pass 1 (stages 1-3: index bits n8 n7 n6):  lane = n mod 64,                 e[j] = x[lane + 64 brev3(j)]  (stride-1 across lanes)
+//   pass 2 (stages 4-6: n5 n4 n3):             lane = (n mod 8) + 8 lo,         lo = the pass-1 register number (= position bits 0-2)
+//   pass 3 (stages 7-9: n2 n1 n0):             lane = lo + 8 jj = position mod 64, jj the pass-2 register number; e[j] = bin lane + 64 j
+// with two transposes through the step's own buffer whose layouts ([j][72] and [lane][9]) keep every access conflict-free.
+// (Round 4 wrote the window bit-reversed -- a 4-way conflicting scatter that cost as much LDS time as the fold, r5_notes.md.)
+// The twiddles of passes 2 and 3 depend on the lane alone: tw2 / tw3 hold them in registers (read from global memory at the head
+// of the kernel, L1 hits), pass 1's are three wave-uniform values.
+struct PfbTw { float2 a2, b2[2], c2[4], a3, b3[2], c3[4]; };
+__device__ __forceinline__ PfbTw pfb_load_tw(const float2 *__restrict__ tw, int lane)
 {
-	// stages 1-3 on elements 8*lane + j
+	PfbTw t;
+	const int lo = lane >> 3;
+	t.a2 = tw[lo * 32];
 #pragma unroll
-	for (int j = 0; j < 8; j++) e[j] = fb[pfb_pad(8 * lane + j)];
+	for (int k = 0; k < 2; k++) t.b2[k] = tw[(lo + 8 * k) * 16];
 #pragma unroll
-	for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], s_tw[0]);
+	for (int k = 0; k < 4; k++) t.c2[k] = tw[(lo + 8 * k) * 8];
+	t.a3 = tw[lane * 4];
 #pragma unroll
-	for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], s_tw[(j & 1) * 128]);
+	for (int k = 0; k < 2; k++) t.b3[k] = tw[(lane + 64 * k) * 2];
 #pragma unroll
-	for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], s_tw[j * 64]);
+	for (int k = 0; k < 4; k++) t.c3[k] = tw[lane + 64 * k];
+	return t;
+}
+#define PFB_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+__device__ __forceinline__ void pfb_fft512n(float2 *fb, const float2 w64 /* tw[64] */, const float2 w128 /* tw[128] */, const float2 w192 /* tw[192] */,
+                                            const PfbTw &t, int lane, float2 (&e)[8])
+{
+	constexpr int BR3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+	const float2 w0 = make_float2(1.0f, -0.0f);                  // tw[0] = (cos 0, -sin 0)
+	// pass 1
 #pragma unroll
-	for (int j = 0; j < 8; j++) fb[pfb_pad(8 * lane + j)] = e[j];
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	// stages 4-6 on elements lo + 8 j + 64 hi
+	for (int j = 0; j < 8; j++) e[j] = fb[lane + 64 * BR3[j]];
+#pragma unroll
+	for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], w0);
+#pragma unroll
+	for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], (j & 1) ? w128 : w0);
+	pfb_bfly(e[0], e[4], w0); pfb_bfly(e[1], e[5], w64); pfb_bfly(e[2], e[6], w128); pfb_bfly(e[3], e[7], w192);
+	PFB_WSYNC();
+#pragma unroll
+	for (int j = 0; j < 8; j++) fb[72 * j + lane] = e[j];
+	PFB_WSYNC();
+	// pass 2
 	{
-		const int lo = lane & 7, hi = lane >> 3;
+		const int lo = lane >> 3, hp = lane & 7;
 #pragma unroll
-		for (int j = 0; j < 8; j++) e[j] = fb[pfb_pad(lo + 8 * j + 64 * hi)];
+		for (int j = 0; j < 8; j++) e[j] = fb[72 * lo + 8 * BR3[j] + hp];
 #pragma unroll
-		for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], s_tw[lo * 32]);
+		for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], t.a2);
 #pragma unroll
-		for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], s_tw[(lo + 8 * (j & 1)) * 16]);
+		for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], t.b2[j & 1]);
 #pragma unroll
-		for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], s_tw[(lo + 8 * j) * 8]);
+		for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], t.c2[j]);
+		PFB_WSYNC();
 #pragma unroll
-		for (int j = 0; j < 8; j++) fb[pfb_pad(lo + 8 * j + 64 * hi)] = e[j];
+		for (int j = 0; j < 8; j++) fb[9 * (lo + 8 * j) + hp] = e[j];
 	}
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	// stages 7-9 on elements lane + 64 j
+	PFB_WSYNC();
+	// pass 3
 #pragma unroll
-	for (int j = 0; j < 8; j++) e[j] = fb[pfb_pad(lane + 64 * j)];
+	for (int j = 0; j < 8; j++) e[j] = fb[9 * lane + BR3[j]];
 #pragma unroll
-	for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], s_tw[lane * 4]);
+	for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], t.a3);
 #pragma unroll
-	for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], s_tw[(lane + 64 * (j & 1)) * 2]);
+	for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], t.b3[j & 1]);
 #pragma unroll
-	for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], s_tw[lane + 64 * j]);
+	for (int j = 0; j < 4; j++) pfb_bfly(e[j], e[j + 4], t.c3[j]);
 }
 
 // I16: the wideband stream (and the carried history) as 16-bit integer I, Q pairs -- what a 10 MS/s receiver delivers -- converted on
 // the way into LDS (exactly, no scaling: a phase does not see the amplitude); everything behind the window is the float path
 // (IK: 0 complex64, 1 int16 pairs, 2 int8 pairs -- a 10 MS/s 8-bit receiver's format)
 template <int IK>
-__global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
+__global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
                                                            const void *__restrict__ hist_in_all_, void *__restrict__ hist_out_all_,
                                                            const float *__restrict__ h_even, const float2 *__restrict__ tw,
                                                            int16_t *__restrict__ phi_all, uint32_t n_steps, uint32_t xcd_map,
                                                            uint32_t dual, const float *__restrict__ h_odd, const float2 *__restrict__ twist)
 {
-	__shared__ __attribute__((aligned(16))) float2 s_x[P_CHW];
-	float2 *const s_tw = s_x + P_S * PFB_FB;                 // written once the window is dead
+	__shared__ __attribute__((aligned(16))) float2 s_x[P_LDS];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	// Workgroups go to the 8 XCDs round robin (linear id mod 8; gridDim.x is a multiple of 8): XCD x takes the x-th eighth of the
 	// block's step groups, so that the workgroups resident on one XCD are neighbours in time and the overlap of their windows is
@@ -170,9 +203,29 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 			}
 		}
 	};
-	PT ta[NQ], tb[NQ];
-	load_round(0, ta);
-	const float2 twv = tid < CH_M / 2 ? tw[tid] : make_float2(0.f, 0.f);
+	PT tb[NQ];
+	// Round 0 (taps 0-7): complex64 input goes global -> LDS directly (global_load_lds_dwordx4: a wave moves 64 x 16 bytes to
+	// consecutive LDS addresses; no staging registers, no ds_write pass -- the window stores were a fifth of the kernel's LDS time);
+	// integer input is converted on the way and keeps the register path.
+	if constexpr (IK == 0) {
+		const long base = p0;
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			const int piece = wave + 8 * q;                          // 1 KB piece of the window (wave-uniform)
+			if (64 * piece < P_CHW / 2) {
+				int i = 64 * piece + lane;
+				i = i < P_CHW / 2 ? i : P_CHW / 2 - 1;               // (the last piece's spare lanes: any valid address)
+				const long pos = base + 2 * (long)i;
+				const float4 *src = pos < 0 ? reinterpret_cast<const float4 *>(hist_in) + (CH_H + pos) / 2 : reinterpret_cast<const float4 *>(iq) + pos / 2;
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+				                                 (__attribute__((address_space(3))) void *)(s_x + 128 * piece), 16, 0, 0);
+			}
+		}
+	} else {
+		PT ta[NQ];
+		load_round(0, ta);
+		store_round(ta);
+	}
 	const int r = tid;
 	float hr[CH_T];
 #pragma unroll
@@ -182,7 +235,6 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 		PT *ho = reinterpret_cast<PT *>(hist_out_all + (size_t)phys * CH_H);
 		for (int i = tid; i < CH_H / 2; i += P_NT) ho[i] = tail[i];
 	}
-	store_round(ta);
 	load_round(1, tb);                                         // in flight while the first half is folded
 	__syncthreads();
 	// 2. fold (SPEC 3.5: v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc), t ascending)
@@ -201,12 +253,21 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 			}
 		}
 	};
-	fold_round(0);
-	__syncthreads();                       // the first half is consumed
-	store_round(tb);
-	__syncthreads();
-	fold_round(1);
-	__syncthreads();                       // the window is dead from here on
+	// the FFT's twiddles: pass 1's three are wave-uniform; passes 2 and 3 per lane, requested once the last staged part has left its
+	// registers, in flight during the last part's fold
+	float2 w64, w128, w192;
+	PfbTw twr;
+#pragma unroll
+	for (int c = 0; c < P_NSTG; c++) {
+		fold_round(c);
+		__syncthreads();                   // this part of the window is consumed (the last one: the window is dead from here on)
+		if (c + 1 < P_NSTG) {
+			store_round(tb);
+			if (c + 2 < P_NSTG) load_round(c + 2, tb);
+			else { w64 = tw[64]; w128 = tw[128]; w192 = tw[192]; twr = pfb_load_tw(tw, lane); }
+			__syncthreads();
+		}
+	}
 	if (odd) {                              // the twist W[r] = exp(-j pi r / 512) (wave-uniform branch)
 		const float2 w = twist[r];
 #pragma unroll
@@ -215,18 +276,17 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 			v[q] = make_float2(tr, ti);
 		}
 	}
-	// 3. rotate + bit-reverse into the buffer of the step; twiddles next to the buffers
+	// 3. rotate into the buffer of the step
 #pragma unroll
 	for (int q = 0; q < P_S; q++) {
 		const uint32_t shift = ((m0 + (uint32_t)q) * CH_D) & (CH_M - 1);
 		const uint32_t pos = ((uint32_t)r + shift) & (CH_M - 1);
-		s_x[q * PFB_FB + pfb_pad((int)(__brev(pos) >> 23))] = v[q];
+		s_x[q * PFB_FB + pos] = v[q];                          // natural order: consecutive lanes, consecutive addresses
 	}
-	if (tid < CH_M / 2) s_tw[tid] = twv;
 	__syncthreads();
 	// 4. FFT of step m0 + wave by this wave alone; 5. the phases of the 8 bins this lane holds
 	float2 e0[8];
-	pfb_fft512(s_x + wave * PFB_FB, s_tw, lane, e0);
+	pfb_fft512n(s_x + wave * PFB_FB, w64, w128, w192, twr, lane, e0);
 	float ph[8];
 #pragma unroll
 	for (int j = 0; j < 8; j++) ph[j] = sd_atan2q(e0[j].y, e0[j].x);
