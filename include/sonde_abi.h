@@ -118,6 +118,8 @@ typedef struct {
 	int32_t        input_kind;       /* SONDE_INPUT_IQ, SONDE_INPUT_REAL, SONDE_INPUT_IQ16 or SONDE_INPUT_IQ8 */
 	int32_t        device;           /* HIP device ordinal */
 	uint32_t       flags;            /* SONDE_FLAG_*; 0 = defaults */
+	uint32_t       launch_units;     /* 0 = the library's choice; else the number of launch units a batch of ONE sonde type is cut into when its
+	                                    submits are not joined at every call (1..16; measurements: profiles/r4_units_sweep.txt) */
 } SondeBatchConfig;
 
 /* One decimation step less before the discriminator for every GFSK sonde (RS41 / DFM / iMS-100 / MRZ-N1 2:1 instead of 4:1:
@@ -129,21 +131,30 @@ typedef struct {
 /* RS41 channels: run the Reed-Solomon stage as a kernel of its own behind the demodulator instead of in the demodulator
  * kernel's epilogue (one launch more per submit; same frames).  Kept for A/B measurements. */
 #define SONDE_FLAG_SPLIT_FEC 2u
-/* Mixed batches (several demodulator classes = several kernels on the library's own streams): do not join those streams
- * into the caller's stream at the end of each submit.  Every class then runs submit after submit on its own stream, behind
- * its own predecessor only, so the tail of one class (last workgroups draining, frame decoder) overlaps the next submit of
- * the others.  The caller's stream orders the INPUT only (the kernels start once work queued on it before the submit has
- * finished); completion is observed through sonde_batch_sync / sonde_batch_frames_of, NOT through the caller's stream:
- * the sample buffer of submit t must stay untouched until sonde_batch_sync / frames_of(t) has returned.
- * Batches of ONE sonde type (round 4): the channel list is cut into two launch units that keep their own streams the same way, so
- * that the last, part-filled generation of workgroups of one unit's submit t runs beside the other unit's submit t + 1: a
- * throughput that no longer depends on the channel count being a multiple of 1024 (1250 channels x 1 s: 0.56 -> 0.74 of the HBM
- * peak), for hosts that keep two or more submits queued. */
+/* HOW A SUBMIT COMPLETES ON THE CALLER'S STREAM.  A batch of one demodulator class and fewer than 512 channels (every B1 decoder,
+ * sonde::IqStreamDecoder, the channelizer's bins) is one kernel launch on the caller's stream: plain stream order.  Larger batches
+ * and batches of several classes are cut into LAUNCH UNITS (one per sonde type; two halves of the channel list for a batch of one
+ * type) on the library's own streams, forked from the caller's stream at each submit, because a workgroup lives for its channel's
+ * whole submit: a launch whose workgroup count is not a multiple of one residency of the GPU ends with a part-filled generation
+ * running alone (1250 channels x 1 s: 0.56 of the HBM peak).  With units that keep their own stream from submit to submit the tail
+ * of one unit's submit t runs beside the other units' submit t + 1 (0.74).  Three ways to hand completion back:
+ *   default (round 5)     one submit LATE: sonde_batch_submit t makes the caller's stream wait for the units of submit t - 1.  Work
+ *                         queued on the caller's stream after submit t returns is ordered behind submit t - 1, NOT behind submit t:
+ *                         THE SAMPLE BUFFER OF SUBMIT t MUST STAY UNTOUCHED UNTIL THE NEXT sonde_batch_submit, OR sonde_batch_sync /
+ *                         sonde_batch_frames(_of) / sonde_batch_poll, HAS BEEN CALLED -- the double-buffering every streaming host does
+ *                         anyway.  Frames are observed through sonde_batch_sync / frames / frames_of / poll as always.
+ *   SONDE_FLAG_JOIN       at every submit (rounds 1-4's default): the units are joined into the caller's stream before
+ *                         sonde_batch_submit returns; the buffer may be rewritten by work queued on that stream right away.  No
+ *                         overlap between submits.
+ *   SONDE_FLAG_PIPELINE   never: the caller's stream orders the INPUT only; completion is observed through sonde_batch_sync /
+ *                         sonde_batch_frames_of, and the sample buffer of submit t must stay untouched until one of them has returned
+ *                         for it. */
 #define SONDE_FLAG_PIPELINE  4u
 /* SONDE_FLAG_WIDE for the sonde types whose channel is 20 kHz or wider in the reference only (iMS-100 / RS-11G and MRZ-N1: 20 kHz,
  * M10 / M20: 50 kHz; /root/reference/src/main.hpp:47-51); RS41 (10 kHz) and DFM (15 kHz) keep the default classes.  The per-type
  * choice sonde::IqStreamDecoder makes for its one channel, for a batch of mixed types.  IQ input only. */
 #define SONDE_FLAG_WIDE_AUTO 8u
+#define SONDE_FLAG_JOIN      16u     /* see SONDE_FLAG_PIPELINE above */
 
 typedef struct SondeBatch SondeBatch;
 
@@ -197,6 +208,9 @@ long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t c
  * (1 = every submit, 0 = none) and restarts the count: the every_n-th submit after it is the next one timed. */
 int  sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *framer_ms);
 int  sonde_batch_set_timing(SondeBatch *b, int every_n);
+/* launch units per submit (1: one plain launch on the caller's stream) and how they are joined: 0 at every submit
+ * (SONDE_FLAG_JOIN), 1 one submit late (the default), 2 never (SONDE_FLAG_PIPELINE); see SONDE_FLAG_PIPELINE above */
+int  sonde_batch_launch_info(const SondeBatch *b, uint32_t *n_units, int32_t *join_mode);
 /* Mixed batches (several demodulator classes, one kernel each on the library's own streams): the average device time (ms) of
  * each class's demod kernel alone over the timed submits since the last call; index 0: no decimation / 16 taps (M10 wide,
  * the AFSK 6 kS/s streams), 1: 2:1 / 16 (RS41, DFM, iMS-100, MRZ-N1 wide), 2: 4:1 / 8 (the same four, default), 3: 2:1 / 8
@@ -277,7 +291,7 @@ int         sonde_chan_set_fused(SondeChannelizer *c, int on);
  * bank's window, so phases and frames are those of the float block holding the same integers).  Call before the first submit;
  * returns the kind in force (or -1). */
 int         sonde_chan_set_input(SondeChannelizer *c, int input_kind);
-/* Option (fused mode only, off by default; also SONDE_CHAN_OVERLAP in the environment): the filter bank runs on an internal
+/* Option (fused mode only, off by default): the filter bank runs on an internal
  * stream, the decoder on another, the bins are double-buffered, so the filter bank of submit k+1 may run beside the decoder
  * of submit k.  The caller's stream is made to wait (on the device) for the filter bank only -- the last reader of the
  * caller's block -- and the frames come with sonde_batch_sync / sonde_batch_frames_of on sonde_chan_batch() as always; the

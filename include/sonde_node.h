@@ -14,8 +14,13 @@
  * own sonde_batch_submit.  There is no other collective: channels are independent.  Frames come back per device straight to
  * host memory (one process: the host is shared; nothing travels back over xGMI).
  *
- * When the ingest rows already lie on the recommended stride (channel_stride == sonde_row_stride(n_samples)) a peer's shard is
- * one contiguous run (padding included): one send per peer.  Otherwise one send per row.
+ * Shape of the transfer, by the layout of the ingest rows: on the recommended stride (channel_stride == sonde_row_stride(n_samples))
+ * a peer's shard is one contiguous run, padding included: ONE send per peer, the rows land on that stride.  Back to back
+ * (channel_stride == n_samples): ONE send per peer of exactly the shard's bytes, the rows land back to back and are decoded from
+ * there (the decoder takes any stride; back-to-back rows cost it about 5 %, a re-stride copy on the peer would cost more).  Any other
+ * stride: one send per row (256 rows of every peer per group).  Round 4 sent row by row whenever the ingest block was not on the
+ * recommended stride: 57 344 sends per block of BASELINE config 5.
+ * The rows exist twice per device: submit t + 1 scatters while the decoders of submit t still read.
  *
  * All int / long calls: >= 0 ok, negative = error (text: sonde_node_last_error()).  Not thread-safe per object. */
 #ifndef SONDE_NODE_H
@@ -37,7 +42,9 @@ typedef struct {
 	const uint8_t *types;         /* n_channels entries of SONDE_*; NULL = all SONDE_RS41 */
 	uint32_t       max_samples;   /* largest samples-per-channel of one submit (multiple of SONDE_TILE) */
 	int32_t        input_kind;    /* SONDE_INPUT_IQ, SONDE_INPUT_REAL, SONDE_INPUT_IQ16 or SONDE_INPUT_IQ8 (a half / a quarter of the bytes over xGMI) */
-	uint32_t       flags;         /* SONDE_FLAG_* of the per-device batches */
+	uint32_t       flags;         /* SONDE_FLAG_* of the per-device batches (SONDE_FLAG_PIPELINE is ignored: the node's row sets need the
+	                                 per-device streams joined with their decoders, which the default mode does one submit late) */
+	uint32_t       scatter_mode;  /* 0: by the ingest layout (below); 1: always one send per row into rows on the recommended stride */
 } SondeNodeConfig;
 
 int    sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out);
@@ -50,10 +57,15 @@ SondeBatch *sonde_node_batch(SondeNode *n, uint32_t d);
 
 /* samples: DEVICE pointer on the ingest device, channel-major, channel c at element c * channel_stride (as
  * sonde_batch_submit).  Scatters, then submits on every device.  Asynchronous; the ingest buffer may be reused once
- * sonde_node_scatter_done() / sonde_node_sync() has returned. */
+ * sonde_node_scatter_done() / sonde_node_sync() has returned.
+ * The scatter runs on the node's own streams.  sonde_node_submit_on: it starts behind the work queued so far on `stream`
+ * (hipStream_t on the ingest device; NULL = the legacy default stream) -- the stream that produced the ingest buffer;
+ * sonde_node_submit = sonde_node_submit_on(..., NULL). */
 int    sonde_node_submit(SondeNode *n, const void *samples, size_t n_samples, size_t channel_stride);
+int    sonde_node_submit_on(SondeNode *n, const void *samples, size_t n_samples, size_t channel_stride, void *stream);
 /* Every device's shard is already resident on that device (rank-local ingest: no scatter): rows[d] = device pointer on device d,
- * channel-major, channel_stride elements apart. */
+ * channel-major, channel_stride elements apart.  The decoders run on the node's own streams: the rows must be COMPLETE when this
+ * is called (synchronise the streams that wrote them), and stay untouched until the submit after the next one (or sonde_node_sync). */
 int    sonde_node_submit_local(SondeNode *n, const void *const *rows, size_t n_samples, size_t channel_stride);
 int    sonde_node_scatter_done(SondeNode *n);
 /* wait for every device; returns the frames of the last submit, all devices (or negative) */
@@ -66,6 +78,9 @@ long   sonde_node_poll(SondeNode *n, SondeData *out, uint32_t *channel, size_t c
 /* device time of the last submit's scatter (ms, on the ingest device's stream; 0 for one device / submit_local), the bytes that
  * left the ingest device, and the number of ncclSend calls they took */
 int    sonde_node_scatter_stats(SondeNode *n, float *ms, uint64_t *bytes_out, uint32_t *n_sends);
+/* host time (ms) the last sonde_node_frames spent copying frame records device -> host (every device done before the clock starts),
+ * and their bytes: the return path of a step (nothing travels back over xGMI: one process, one host) */
+int    sonde_node_gather_stats(SondeNode *n, double *ms, uint64_t *bytes);
 const char *sonde_node_last_error(void);
 
 #ifdef __cplusplus

@@ -31,7 +31,10 @@ int         sonde_shard_scatter(SondeShard *s, const void *full_dev /* root only
 /* Rows into a strided destination: n_rows_total rows of row_bytes on the root (row k at full_dev + k * src_stride_bytes); rank r
  * receives the rows of sonde_shard_range(n_rows_total, world, r) (unequal shards allowed) at shard_dev + row * dst_stride_bytes,
  * i.e. straight into rows on the decoder's recommended channel stride (sonde_row_stride): no re-stride copy.  The root's own
- * shard is a device copy, not a send to itself. */
+ * shard is a device copy, not a send to itself.  Equal strides make a peer's shard one contiguous run: ONE send / receive pair per
+ * peer; else one pair per row (256 rows of every peer per group).  EVERY RANK MUST PASS THE SAME src_stride_bytes AND
+ * dst_stride_bytes (the root's source layout is an argument of the collective, not a local property: a rank that guesses another
+ * value posts receives of the other shape and the transfer hangs). */
 int         sonde_shard_scatter_rows(SondeShard *s, const void *full_dev /* root only */, size_t src_stride_bytes, void *shard_dev,
                                      size_t dst_stride_bytes, size_t row_bytes, uint32_t n_rows_total, int root, void *stream);
 /* every rank sends `bytes`; root receives block r from rank r */

@@ -41,13 +41,14 @@ class SondeData(C.Structure):
 
 class SondeBatchConfig(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("types", C.POINTER(C.c_uint8)), ("max_samples", C.c_uint32),
-                ("input_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32)]
+                ("input_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32), ("launch_units", C.c_uint32)]
 
 
 FLAG_WIDE = 1            # one decimation step less for every GFSK sonde (SONDE_FLAG_WIDE)
 FLAG_RS41_WIDE = FLAG_WIDE
 FLAG_SPLIT_FEC = 2
 FLAG_PIPELINE = 4        # mixed batches: class streams are not joined into the caller's stream (SONDE_FLAG_PIPELINE)
+FLAG_JOIN = 16           # launch units joined into the caller's stream at every submit (SONDE_FLAG_JOIN; rounds 1-4's default)
 FLAG_WIDE_AUTO = 8       # SONDE_FLAG_WIDE for the types whose reference channel is >= 20 kHz only (iMS-100, MRZ-N1, M10)
 
 
@@ -55,7 +56,7 @@ FLAG_WIDE_AUTO = 8       # SONDE_FLAG_WIDE for the types whose reference channel
 ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
     "sonde_row_stride", "sonde_sample_bytes", "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_class_ms", "sonde_batch_read_bits",
-    "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_test_rs255", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
+    "sonde_batch_launch_info", "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_test_rs255", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
     "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp", "sonde_rs41_pressure", "sonde_ozone_mpa",
     "sonde_m10_temp", "sonde_m10_rh", "sonde_m20_temp", "sonde_ims100_temp",
     "sonde_last_error", "sonde_version", "sonde_hbm_read_probe", "sonde_dewpt", "sonde_altitude_to_pressure",

@@ -79,7 +79,9 @@ class SondeBatch:
         if (is_iq and st[1:] != (2, 1)) or (not is_iq and st[1] != 1):
             raise SondeError("samples must be contiguous inside a channel (only the channel stride may be padded)")
         stride = samples.stride(0) // (2 if is_iq else 1)
-        self._keep = samples   # keep the device buffer alive until sync
+        # keep the device buffers of the last two submits alive: by default a submit of several launch units is joined into the
+        # caller's stream one submit late (include/sonde_abi.h), so the buffer of submit t may be read until submit t + 1 is queued
+        self._keep = (samples, getattr(self, "_keep", (None, None))[0])
         self._chk(self.L.sonde_batch_submit(self.h, C.c_void_p(samples.data_ptr()), n, stride, C.c_void_p(stream or 0)))
 
     def submit_host(self, samples: np.ndarray):
@@ -142,6 +144,13 @@ class SondeBatch:
         self.L.sonde_batch_class_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         n = self._chk(self.L.sonde_batch_class_ms(self.h, v))
         return {k: float(v[k]) for k in range(4) if n > 0 and v[k] >= 0.0}
+
+    def launch_info(self) -> dict:
+        """{'units': launch units per submit, 'join': 0 at every submit / 1 one submit late (default) / 2 never} (sonde_batch_launch_info)"""
+        u, j = C.c_uint32(), C.c_int32()
+        self.L.sonde_batch_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+        self._chk(self.L.sonde_batch_launch_info(self.h, C.byref(u), C.byref(j)))
+        return {"units": int(u.value), "join": int(j.value)}
 
     def set_timing(self, every_n: int):
         """Record kernel-timing events on every n-th submit only (0: never); the next submit is timed."""
@@ -209,7 +218,7 @@ class SondeChannelizer:
             raise SondeError(_lib.last_error() or "sonde_chan_create failed")
         self.h = h
         # fused (default where possible): discriminator + resampler inside the decoder kernel; fused=False keeps the 48 kS/s rows
-        # (read()); fused=None leaves the library's choice (and its SONDE_CHAN_UNFUSED switch) alone
+        # (read()); fused=None leaves the library's choice alone
         self.fused = bool(self.L.sonde_chan_set_fused(self.h, 1 if fused else 0)) if fused is not None else bool(self.L.sonde_chan_set_fused(self.h, -1))
         # overlap (an option, off by default): filter bank of submit k+1 beside the decoder of submit k, on internal streams
         self.overlap = bool(self.L.sonde_chan_set_overlap(self.h, 1)) if overlap else False

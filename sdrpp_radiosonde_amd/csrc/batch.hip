@@ -164,13 +164,17 @@ struct SondeBatch {
 	// of a class share one launch over the class's channel list, their frame decoders follow): measured 0.319 ms per step
 	// against 0.336 per type for 4096 RS41 / M10 / DFM channels x 24 tiles; pipelined (SONDE_FLAG_PIPELINE) it is the other way
 	// round, 0.321 per class against 0.289 per type, and more pieces than one only add launches (profiles/r3_notes.md).
-	struct Unit { int type, cls; uint32_t off, n; size_t row0; hipStream_t st; hipEvent_t ev_join; };
+	struct Unit { int type, cls; uint32_t off, n; size_t row0; hipStream_t st; hipEvent_t ev_join[2]; };      // ev_join[submit parity]
 	std::vector<Unit> units;
 	uint32_t *d_cls[4] = {};               // joined batches: the channel list of each class
 	int n_chunks = 1;
 	hipEvent_t ev_fork = nullptr;
-	// SONDE_FLAG_PIPELINE: the class streams are not joined into the caller's stream; this stream collects them for completion
-	bool pipeline = false;
+	// How a submit of several launch units completes (include/sonde_abi.h): 0 SONDE_FLAG_JOIN: the unit streams are joined into the
+	// caller's stream before sonde_batch_submit returns; 1 (default, round 5): one submit late -- submit t joins the units of submit
+	// t - 1 into the caller's stream, so that a unit's submit t + 1 may start beside the other units' submit t; 2 SONDE_FLAG_PIPELINE:
+	// never.  In modes 1 and 2 done_stream collects the unit streams for completion (sonde_batch_sync, tickets).
+	int join_mode = 0;
+	bool pipeline = false;                 // join_mode != 0
 	hipStream_t done_stream = nullptr;
 	uint32_t granule = SONDE_TILE;         // submit sizes must be a multiple of this
 
@@ -209,7 +213,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	if (b->ev_xs) (void)hipEventDestroy(b->ev_xs);
 	(void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
 	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_wtab_c50); (void)hipFree(b->d_afq);
-	for (auto &u : b->units) { if (u.st) (void)hipStreamDestroy(u.st); if (u.ev_join) (void)hipEventDestroy(u.ev_join); }
+	for (auto &u : b->units) { if (u.st) (void)hipStreamDestroy(u.st); for (int k = 0; k < 2; k++) if (u.ev_join[k]) (void)hipEventDestroy(u.ev_join[k]); }
 	for (int k = 0; k < 4; k++) (void)hipFree(b->d_cls[k]);
 	if (b->done_stream) (void)hipStreamDestroy(b->done_stream);
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
@@ -309,19 +313,26 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			else if (b->types[c] != b->cls_type[k]) { b->cls_type[k] = -1; break; }
 		}
 	}
-	// Round 4: a ONE-class batch created with SONDE_FLAG_PIPELINE is cut into TWO launch units (halves of the channel list, each
+	// Round 4: a ONE-class batch that is not joined at every submit (join_mode != 0) is cut into TWO launch units (halves of the channel list, each
 	// with its own stream from submit to submit).  A workgroup lives for its channel's whole submit, so a launch whose
 	// workgroup count is not a multiple of one residency (4 x 256 CUs) ends with a part-filled generation running alone; with
 	// two units in flight the tail of one unit's submit t overlaps the other unit's submit t + 1.  Measured
 	// (profiles/r4_notes.md): 1250 channels x 24 tiles 0.556 -> 0.743 of the HBM peak, 1280 x 96 0.634 -> 0.799, 1100 x 96
 	// 0.565 -> 0.756, 8192 x 24 0.765 -> 0.782, 1024 x 96 (exactly one residency) 0.779 -> 0.789; three units: equal or worse
-	// (1250 x 24: 0.626); four and more: 0.38-0.63 (more streams than the hardware runs side by side).  SONDE_UNITS overrides.
+	// (1250 x 24: 0.626); four and more: 0.38-0.63 (more streams than the hardware runs side by side).  SondeBatchConfig.launch_units
+	// overrides.  Round 5: also the DEFAULT (join_mode 1), with the caller's stream joined one submit late.
+	b->join_mode = (cfg->flags & SONDE_FLAG_PIPELINE) ? 2 : ((cfg->flags & SONDE_FLAG_JOIN) ? 0 : 1);
 	int one_class_units = 1;
-	if ((cfg->flags & SONDE_FLAG_PIPELINE) && n_afsk == 0 && b->n_classes == 1) {
+	if (b->join_mode != 0 && n_afsk == 0 && b->n_classes == 1) {
 		int n_types = 0;
 		for (int t = 0; t < SONDE_NTYPES; t++) n_types += !b->chlist[t].empty();
-		one_class_units = (n_types == 1 && b->n_channels >= 512) ? 2 : 1;
-		if (const char *e = getenv("SONDE_UNITS")) one_class_units = std::max(1, std::min(16, atoi(e)));
+		// two units where a single launch would end with a part-filled generation of workgroups (one residency = 4 workgroups per CU);
+		// a channel count that fills whole residencies stays ONE plain launch on the caller's stream (two units measured +1-2 % there:
+		// not worth the lagging join; the headline shape, 1024 channels, and BASELINE config 5's shard, 8192, are such counts)
+		hipDeviceProp_t prop0;
+		const uint32_t residency = hipGetDeviceProperties(&prop0, cfg->device) == hipSuccess ? 4u * (uint32_t)prop0.multiProcessorCount : 1024u;
+		one_class_units = (n_types == 1 && b->n_channels >= 512 && b->n_channels % residency != 0) ? 2 : 1;
+		if (cfg->launch_units) one_class_units = std::max(1, std::min(16, (int)cfg->launch_units));      // (experiments: profiles/r4_units_sweep.txt)
 	}
 	const bool need_lists = n_afsk != 0 || b->n_classes > 1 || one_class_units > 1;
 	if (n_afsk) {
@@ -418,7 +429,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			// one residency of the GPU: 4 demod workgroups (39.7 KB of LDS, 8 waves each) per CU
 			hipDeviceProp_t prop;
 			CHK(hipGetDeviceProperties(&prop, cfg->device));
-			const uint32_t loop_wg = getenv("SONDE_NO_LOOP_FEC") ? 0u : 4u * (uint32_t)prop.multiProcessorCount;
+			const uint32_t loop_wg = 4u * (uint32_t)prop.multiProcessorCount;
 			const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts2[k], b->max_frames, b->fuse_fec, loop_wg, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames2[k] };
 			CHK(hipMemcpy(b->d_fo2[k], &fo, sizeof(fo), hipMemcpyHostToDevice));
 			b->h_fo2[k] = fo;
@@ -456,10 +467,9 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	for (int i = 0; i < 3 * SondeBatch::kEvSlots; i++) CHK(hipEventCreateWithFlags(&b->ev[i], SD_EV_TIMING));
 	if (need_lists) {
 		CHK(hipEventCreateWithFlags(&b->ev_fork, SD_EV_ORDER));
-		const bool pipelined = (cfg->flags & SONDE_FLAG_PIPELINE) != 0;
-		// pieces per type (pipelined batches): one; SONDE_MIX_CHUNKS overrides for experiments (2-8 pieces measured 6-70 % slower)
+		const bool pipelined = b->join_mode != 0;
+		// pieces per type: one (2-8 pieces of every type of a mixed batch measured 6-70 % slower, profiles/r3_notes.md); a one-type batch: two
 		int R = 1;
-		if (const char *e = getenv("SONDE_MIX_CHUNKS")) R = std::max(1, std::min(16, atoi(e)));
 		if (one_class_units > 1) R = one_class_units;
 		b->n_chunks = pipelined ? R : 1;
 		static const int order[] = { SONDE_M10, SONDE_RS41, SONDE_DFM09, SONDE_IMS100, SONDE_MRZN1 };
@@ -468,7 +478,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 				for (int t : order) {
 					const size_t nt = b->chlist[t].size();
 					const size_t lo = nt * (size_t)j / (size_t)R, hi = nt * (size_t)(j + 1) / (size_t)R;
-					if (hi > lo) b->units.push_back({ t, modem_class(md, t), (uint32_t)lo, (uint32_t)(hi - lo), 0, nullptr, nullptr });
+					if (hi > lo) b->units.push_back({ t, modem_class(md, t), (uint32_t)lo, (uint32_t)(hi - lo), 0, nullptr, { nullptr, nullptr } });
 				}
 		} else {
 			// class order: the class with the longest-running workgroups (M10: twice the symbols per tile) first, then the 4:1
@@ -478,23 +488,23 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 				hipError_t e_ = hipMalloc((void **)&b->d_cls[k], cls[k].size() * sizeof(uint32_t));
 				if (e_ == hipSuccess) e_ = hipMemcpy(b->d_cls[k], cls[k].data(), cls[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice);
 				if (e_ != hipSuccess) { sonde_batch_destroy(b); return fail("hipMalloc d_cls", e_); }
-				b->units.push_back({ -1, k, 0, b->n_cls[k], 0, nullptr, nullptr });
+				b->units.push_back({ -1, k, 0, b->n_cls[k], 0, nullptr, { nullptr, nullptr } });
 			}
 		}
 		size_t row0 = 0;
 		for (int t : { SONDE_IMET4, SONDE_C50 }) {       // AFSK chains: tone demodulator -> 6 kS/s rows -> demod -> framer, one unit per type
 			if (b->chlist[t].empty()) continue;
-			b->units.push_back({ t, 0, 0, (uint32_t)b->chlist[t].size(), row0, nullptr, nullptr });
+			b->units.push_back({ t, 0, 0, (uint32_t)b->chlist[t].size(), row0, nullptr, { nullptr, nullptr } });
 			row0 += b->chlist[t].size();
 		}
 		for (auto &u : b->units) {
 			CHK(hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking));
-			CHK(hipEventCreateWithFlags(&u.ev_join, SD_EV_ORDER));
+			for (int k = 0; k < 2; k++) CHK(hipEventCreateWithFlags(&u.ev_join[k], SD_EV_ORDER));
 		}
 		const size_t nev = 2 * b->units.size() * SondeBatch::kEvSlots;
 		b->evc = new hipEvent_t[nev]();
 		for (size_t i = 0; i < nev; i++) CHK(hipEventCreateWithFlags(&b->evc[i], SD_EV_TIMING));
-		if (cfg->flags & SONDE_FLAG_PIPELINE) {
+		if (b->join_mode != 0) {
 			b->pipeline = true;
 			CHK(hipStreamCreateWithFlags(&b->done_stream, hipStreamNonBlocking));
 		}
@@ -638,9 +648,14 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 			// join: into the caller's stream (work queued there afterwards sees the submit finished), or -- pipelined -- into the
 			// library's completion stream only, so that the next submit's units start behind their OWN predecessors and the
 			// tail of one unit (its last workgroups draining, its frame decoder) overlaps the other units' next submit
-			HIPCHK(hipEventRecord(u.ev_join, u.st));
-			HIPCHK(hipStreamWaitEvent(join_to, u.ev_join, 0));
+			HIPCHK(hipEventRecord(u.ev_join[slot], u.st));
+			HIPCHK(hipStreamWaitEvent(join_to, u.ev_join[slot], 0));
 		}
+		// join_mode 1: the caller's stream is joined with the PREVIOUS submit's units now (behind this submit's fork), i.e. one submit
+		// late: work the caller queues on its stream after this call is ordered behind submit t - 1, and the tail of a unit's
+		// submit t - 1 runs beside the other units' submit t
+		if (b->join_mode == 1 && b->tickets)
+			for (const SondeBatch::Unit &u : b->units) HIPCHK(hipStreamWaitEvent((hipStream_t)stream_, u.ev_join[slot ^ 1], 0));
 		if (timed) b->evc_used++;
 		if (pipe) stream = b->done_stream;      // where the submit completes: timing end, completion event, sonde_batch_sync
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
@@ -657,6 +672,16 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	b->last_stream = stream;
 	b->pending = true;
 	b->have_counts2[slot] = false;
+	return 0;
+}
+
+// How the batch launches and joins (bench / tests label their figures with it): launch units per submit (1: one plain launch on the
+// caller's stream) and the join mode (0 at every submit, 1 one submit late, 2 never; only meaningful with more than one unit)
+extern "C" int sonde_batch_launch_info(const SondeBatch *b, uint32_t *n_units, int32_t *join_mode)
+{
+	if (!b) return fail("sonde_batch_launch_info: null argument");
+	if (n_units) *n_units = b->units.empty() ? 1u : (uint32_t)b->units.size();
+	if (join_mode) *join_mode = b->units.empty() ? 0 : b->join_mode;
 	return 0;
 }
 
@@ -682,7 +707,9 @@ extern "C" size_t sonde_row_stride(size_t n_samples, int input_kind)
 	if (3 * p <= 4 * bytes) return p / elem;
 	size_t units = (bytes + 65535) / 65536;
 	units |= 1;
-	return units * 65536 / elem;
+	// ... but never beyond the power of two (80 KiB rows got 3 x 64 KiB while 96 KiB rows got 128 KiB -- a stride that
+	// shrinks as the row grows overruns buffers sized from the stride of max_samples; capped, the rule is monotonic)
+	return std::min(units * 65536, p) / elem;
 }
 
 extern "C" int sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride)

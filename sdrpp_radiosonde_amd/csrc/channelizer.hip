@@ -353,7 +353,7 @@ struct SondeChannelizer {
 	bool fused = false;                    // the decoder kernel takes the bins themselves (discriminator + resampler in its load path): two launches per submit
 	hipStream_t last_stream = nullptr;     // a submit on another stream waits for the previous one (the state is carried)
 	hipEvent_t ev_xs = nullptr;
-	// overlapped form (an OPTION: SONDE_CHAN_OVERLAP / sonde_chan_set_overlap(c, 1); fused mode only): the filter bank runs on
+	// overlapped form (an OPTION: sonde_chan_set_overlap(c, 1); fused mode only): the filter bank runs on
 	// s_pfb, the decoder on s_dec, the bins are double-buffered, so that the filter bank of submit k+1 may run beside the decoder
 	// of submit k.  Measured (profiles/r3_notes.md): no gain at one stream (43.9 -> 48.9 us per block: the two kernels do not
 	// co-reside, two filter-bank workgroups take a CU's LDS, and the event hand-overs cost), +1-2 % at 8 streams x 4-8 blocks.
@@ -480,7 +480,7 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 	c->n_phys = n_phys;
 	c->dual = dual;
 	c->n_steps = 2560u * blocks_per_submit;                  // 2560 steps = 1.28 M wideband samples = 6144 samples at 48 kS/s
-	c->xcd_map = (c->n_steps / P_S) % 8 == 0 && (size_t)(c->n_steps / P_S) * n_streams > 1024 && !getenv("SONDE_PFB_NOXCD");
+	c->xcd_map = (c->n_steps / P_S) % 8 == 0 && (size_t)(c->n_steps / P_S) * n_streams > 1024;
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
 	const size_t nb = (size_t)n_streams * CH_M;              // bins of all streams: the decoder batch's channels, stream-major
 	SondeBatchConfig cfg;
@@ -490,6 +490,7 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 	cfg.max_samples = n_out;
 	cfg.input_kind = SONDE_INPUT_REAL;
 	cfg.device = device;
+	cfg.flags = SONDE_FLAG_JOIN;                             // the bins decoder is one launch behind the filter bank, in the caller's stream
 	if (sonde_batch_create(&cfg, &c->batch) != 0) { delete c; return -1; }
 	std::vector<float> h, tw, g;
 	make_tables(h, tw, g);
@@ -523,10 +524,10 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 			     hipMemcpy(c->d_h_odd, ho.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 			     hipMemcpy(c->d_twist, wt.data(), CH_M * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
 		}
-		// fused unless a bin's sonde type needs 48 kS/s rows (AFSK) or the host asks for the rows (sonde_chan_set_fused, SONDE_CHAN_UNFUSED)
-		c->fused = sd_batch_bins_capable(c->batch) && !getenv("SONDE_CHAN_UNFUSED");
+		// fused unless a bin's sonde type needs 48 kS/s rows (AFSK) or the host asks for the rows (sonde_chan_set_fused)
+		c->fused = sd_batch_bins_capable(c->batch);
 		if (!c->fused && blocks_per_submit > 2) ok = false;      // (AFSK bins: the three-kernel form, 1-2 blocks per submit)
-		c->overlap = c->fused && getenv("SONDE_CHAN_OVERLAP");
+		c->overlap = false;
 	}
 	if (!ok) { sonde_chan_destroy(c); return -1; }
 	*out = c;

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "../../include/sonde_node.h"
@@ -39,8 +40,16 @@ struct SondeNode {
 	std::vector<SondeBatch *> batch;
 	std::vector<ncclComm_t> comm;
 	std::vector<hipStream_t> st;
-	std::vector<void *> rows;              // per device: its shard's rows, max stride apart
+	// per device: its shard's rows, max stride apart -- TWICE: submit t scatters into set t & 1 while the decoders of submit t - 1 may
+	// still read the other set (the per-device batches join the caller's stream one submit late, include/sonde_abi.h: when the
+	// scatter of submit t is queued on a device's stream, that stream is already ordered behind submit t - 2, the last reader of set t & 1)
+	std::vector<void *> rows, rows_b;
+	uint64_t n_submits = 0;
 	size_t rows_stride_max = 0;            // elements between rows at max_samples
+	uint32_t scatter_mode = 0;
+	hipEvent_t ev_in = nullptr;            // the caller's stream at sonde_node_submit_on: the ingest buffer is complete there
+	double gather_ms = 0.0;                // host time of the last sonde_node_frames (device -> host copies of every device), and its bytes
+	uint64_t gather_bytes = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool have_scatter = false;
 	uint64_t last_bytes = 0;
@@ -56,11 +65,13 @@ extern "C" void sonde_node_destroy(SondeNode *n)
 		if (d < n->batch.size() && n->batch[d]) sonde_batch_destroy(n->batch[d]);
 		if (d < n->st.size() && n->st[d]) { (void)hipStreamSynchronize(n->st[d]); (void)hipStreamDestroy(n->st[d]); }
 		if (d < n->rows.size() && n->rows[d]) (void)hipFree(n->rows[d]);
+		if (d < n->rows_b.size() && n->rows_b[d]) (void)hipFree(n->rows_b[d]);
 		if (d < n->comm.size() && n->comm[d]) (void)ncclCommDestroy(n->comm[d]);
 	}
 	if (n->nd) (void)hipSetDevice(n->dev[n->ingest]);
 	if (n->ev0) (void)hipEventDestroy(n->ev0);
 	if (n->ev1) (void)hipEventDestroy(n->ev1);
+	if (n->ev_in) (void)hipEventDestroy(n->ev_in);
 	delete n;
 }
 
@@ -79,7 +90,8 @@ extern "C" int sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out)
 	n->kind = cfg->input_kind;
 	n->elem = sonde_sample_bytes(cfg->input_kind);
 	n->dev.resize(n->nd); n->first.resize(n->nd); n->count.resize(n->nd);
-	n->batch.assign(n->nd, nullptr); n->st.assign(n->nd, nullptr); n->rows.assign(n->nd, nullptr); n->comm.assign(n->nd, nullptr);
+	n->batch.assign(n->nd, nullptr); n->st.assign(n->nd, nullptr); n->rows.assign(n->nd, nullptr); n->rows_b.assign(n->nd, nullptr); n->comm.assign(n->nd, nullptr);
+	n->scatter_mode = cfg->scatter_mode;
 	for (uint32_t d = 0; d < n->nd; d++) {
 		n->dev[d] = cfg->devices ? cfg->devices[d] : (int)d;
 		if (n->dev[d] < 0 || n->dev[d] >= ndev) { delete n; return nfail("sonde_node_create: no such HIP device"); }
@@ -91,6 +103,7 @@ extern "C" int sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out)
 		hipError_t e = hipSetDevice(n->dev[d]);
 		if (e == hipSuccess) e = hipStreamCreateWithFlags(&n->st[d], hipStreamNonBlocking);
 		if (e == hipSuccess) e = hipMalloc(&n->rows[d], (size_t)n->count[d] * n->rows_stride_max * n->elem);
+		if (e == hipSuccess) e = hipMalloc(&n->rows_b[d], (size_t)n->count[d] * n->rows_stride_max * n->elem);
 		if (e != hipSuccess) { sonde_node_destroy(n); return nfail("sonde_node_create: stream / rows", hipGetErrorString(e)); }
 		SondeBatchConfig bc;
 		memset(&bc, 0, sizeof(bc));
@@ -99,7 +112,9 @@ extern "C" int sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out)
 		bc.max_samples = cfg->max_samples;
 		bc.input_kind = cfg->input_kind;
 		bc.device = n->dev[d];
-		bc.flags = cfg->flags;
+		// (SONDE_FLAG_PIPELINE never joins a device's stream with its decoders: the node could not tell when a row set may be
+		// rewritten; it runs the per-device batches in the default mode instead -- joined one submit late -- which overlaps the same way)
+		bc.flags = cfg->flags & ~SONDE_FLAG_PIPELINE;
 		if (sonde_batch_create(&bc, &n->batch[d]) != 0) { sonde_node_destroy(n); return nfail("sonde_batch_create", sonde_last_error()); }
 	}
 	if (n->nd > 1) {
@@ -109,6 +124,7 @@ extern "C" int sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out)
 	hipError_t e = hipSetDevice(n->dev[n->ingest]);
 	if (e == hipSuccess) e = hipEventCreate(&n->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&n->ev1);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_in, hipEventDisableTiming);
 	if (e != hipSuccess) { sonde_node_destroy(n); return nfail("sonde_node_create: events", hipGetErrorString(e)); }
 	*out = n;
 	return 0;
@@ -133,36 +149,56 @@ static int check_submit(const SondeNode *n, size_t n_samples, size_t channel_str
 
 extern "C" int sonde_node_submit(SondeNode *n, const void *samples, size_t n_samples, size_t channel_stride)
 {
+	return sonde_node_submit_on(n, samples, n_samples, channel_stride, nullptr);
+}
+
+extern "C" int sonde_node_submit_on(SondeNode *n, const void *samples, size_t n_samples, size_t channel_stride, void *stream)
+{
 	if (!n || !samples) return nfail("sonde_node_submit: null argument");
 	if (check_submit(n, n_samples, channel_stride)) return -1;
-	const size_t rs = sonde_row_stride(n_samples, n->kind);           // destination stride (elements)
+	const size_t rs_reco = sonde_row_stride(n_samples, n->kind);     // the stride the decoders like best (elements)
 	const size_t row_bytes = n_samples * n->elem;
 	const char *src = (const char *)samples;
 	const uint32_t gi = n->ingest;
 	hipStream_t si = n->st[gi];
+	const std::vector<void *> &rows = (n->n_submits & 1) ? n->rows_b : n->rows;
+	n->n_submits++;
 	HCHK(hipSetDevice(n->dev[gi]));
+	// the ingest buffer is produced by work on the CALLER's stream (NULL: the legacy default stream): the scatter, which runs on the
+	// node's own non-blocking streams, starts behind it (it used to start unordered)
+	HCHK(hipEventRecord(n->ev_in, (hipStream_t)stream));
+	HCHK(hipStreamWaitEvent(si, n->ev_in, 0));
 	HCHK(hipEventRecord(n->ev0, si));
 	n->last_bytes = 0; n->last_sends = 0;
+	// Layout of a peer's rows (and so the shape of the transfer), scatter_mode 0 = by the ingest layout:
+	//   ingest rows on the recommended stride  -> ONE send per peer (padding included), rows land on that stride;
+	//   ingest rows back to back               -> ONE send per peer of exactly the shard's bytes, rows land back to back and are decoded
+	//                                             from there (the decoder takes any stride; back-to-back rows cost it ~5 %, a re-stride
+	//                                             copy of the shard on the peer would cost more);
+	//   any other stride (or scatter_mode 1)   -> one send per row, 256 rows of every peer per group, rows land on the recommended stride.
+	const bool same_layout = channel_stride == rs_reco && n->scatter_mode != 1;
+	const bool contiguous = !same_layout && channel_stride == n_samples && n->scatter_mode != 1;
+	const size_t rs = contiguous ? n_samples : rs_reco;               // destination stride (elements) on every device
 	if (n->nd > 1) {
-		const bool same_layout = channel_stride == rs;                  // a peer's shard is one contiguous run, padding included
 		uint32_t done_rows = 0, max_rows = 0;
 		for (uint32_t d = 0; d < n->nd; d++) if (d != gi) max_rows = std::max(max_rows, n->count[d]);
-		const uint32_t per_group = same_layout ? max_rows : 256u;      // rows of every peer per ncclGroup
+		const bool one_send = same_layout || contiguous;
+		const uint32_t per_group = one_send ? max_rows : 256u;        // rows of every peer per ncclGroup
 		while (done_rows < max_rows) {
 			NCHK(ncclGroupStart());
 			for (uint32_t d = 0; d < n->nd; d++) {
 				if (d == gi || done_rows >= n->count[d]) continue;
 				const uint32_t hi = std::min(n->count[d], done_rows + per_group);
-				if (same_layout) {
+				if (one_send) {
 					const size_t bytes = ((size_t)(n->count[d] - 1) * rs + n_samples) * n->elem;
 					ncclResult_t r = ncclSend(src + (size_t)n->first[d] * channel_stride * n->elem, bytes, ncclChar, (int)d, n->comm[gi], si);
-					if (r == ncclSuccess) r = ncclRecv(n->rows[d], bytes, ncclChar, (int)gi, n->comm[d], n->st[d]);
+					if (r == ncclSuccess) r = ncclRecv(rows[d], bytes, ncclChar, (int)gi, n->comm[d], n->st[d]);
 					if (r != ncclSuccess) { (void)ncclGroupEnd(); return nfail("ncclSend/ncclRecv", ncclGetErrorString(r)); }
 					n->last_bytes += bytes; n->last_sends++;
 				} else {
 					for (uint32_t row = done_rows; row < hi; row++) {
 						ncclResult_t r = ncclSend(src + ((size_t)n->first[d] + row) * channel_stride * n->elem, row_bytes, ncclChar, (int)d, n->comm[gi], si);
-						if (r == ncclSuccess) r = ncclRecv((char *)n->rows[d] + (size_t)row * rs * n->elem, row_bytes, ncclChar, (int)gi, n->comm[d], n->st[d]);
+						if (r == ncclSuccess) r = ncclRecv((char *)rows[d] + (size_t)row * rs * n->elem, row_bytes, ncclChar, (int)gi, n->comm[d], n->st[d]);
 						if (r != ncclSuccess) { (void)ncclGroupEnd(); return nfail("ncclSend/ncclRecv", ncclGetErrorString(r)); }
 						n->last_bytes += row_bytes; n->last_sends++;
 					}
@@ -174,13 +210,13 @@ extern "C" int sonde_node_submit(SondeNode *n, const void *samples, size_t n_sam
 		HCHK(hipSetDevice(n->dev[gi]));
 	}
 	// the ingest device's own shard: a strided device copy on its stream (not a send to itself)
-	HCHK(hipMemcpy2DAsync(n->rows[gi], rs * n->elem, src + (size_t)n->first[gi] * channel_stride * n->elem, channel_stride * n->elem,
+	HCHK(hipMemcpy2DAsync(rows[gi], rs * n->elem, src + (size_t)n->first[gi] * channel_stride * n->elem, channel_stride * n->elem,
 	                      row_bytes, n->count[gi], hipMemcpyDeviceToDevice, si));
 	HCHK(hipEventRecord(n->ev1, si));
 	n->have_scatter = true;
 	for (uint32_t d = 0; d < n->nd; d++) {
 		HCHK(hipSetDevice(n->dev[d]));
-		BCHK(sonde_batch_submit(n->batch[d], n->rows[d], n_samples, rs, (void *)n->st[d]));
+		BCHK(sonde_batch_submit(n->batch[d], rows[d], n_samples, rs, (void *)n->st[d]));
 	}
 	return 0;
 }
@@ -224,6 +260,9 @@ extern "C" long sonde_node_frames(SondeNode *n, SondeFrame *out, size_t cap)
 {
 	if (!n) return nfail("sonde_node_frames: null argument");
 	size_t k = 0;
+	for (uint32_t d = 0; d < n->nd; d++)            // every device done first: what is timed below is the gather alone
+		if (sonde_batch_sync(n->batch[d]) < 0) return nfail("sonde_batch_sync", sonde_last_error());
+	const auto t0 = std::chrono::steady_clock::now();
 	for (uint32_t d = 0; d < n->nd; d++) {          // contiguous ascending ranges: device order is node-wide channel order
 		const long m = sonde_batch_sync(n->batch[d]);
 		if (m < 0) return nfail("sonde_batch_sync", sonde_last_error());
@@ -235,7 +274,19 @@ extern "C" long sonde_node_frames(SondeNode *n, SondeFrame *out, size_t cap)
 		for (long i = 0; i < got; i++) out[k + (size_t)i].channel += n->first[d];
 		k += (size_t)got;
 	}
+	if (out && cap) {
+		n->gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		n->gather_bytes = (uint64_t)k * sizeof(SondeFrame);
+	}
 	return (long)k;
+}
+
+extern "C" int sonde_node_gather_stats(SondeNode *n, double *ms, uint64_t *bytes)
+{
+	if (!n) return nfail("sonde_node_gather_stats: null argument");
+	if (ms) *ms = n->gather_ms;
+	if (bytes) *bytes = n->gather_bytes;
+	return 0;
 }
 
 extern "C" long sonde_node_poll(SondeNode *n, SondeData *out, uint32_t *channel, size_t cap)

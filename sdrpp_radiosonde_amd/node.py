@@ -14,10 +14,10 @@ from .shard import NativeShard
 
 class SondeNodeConfig(C.Structure):
     _fields_ = [("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int32)), ("ingest", C.c_uint32), ("n_channels", C.c_uint32),
-                ("types", C.POINTER(C.c_uint8)), ("max_samples", C.c_uint32), ("input_kind", C.c_int32), ("flags", C.c_uint32)]
+                ("types", C.POINTER(C.c_uint8)), ("max_samples", C.c_uint32), ("input_kind", C.c_int32), ("flags", C.c_uint32), ("scatter_mode", C.c_uint32)]
 
 
-NODE_SYMBOLS = ["sonde_node_create", "sonde_node_destroy", "sonde_node_devices", "sonde_node_range", "sonde_node_batch", "sonde_node_submit",
+NODE_SYMBOLS = ["sonde_node_create", "sonde_node_destroy", "sonde_node_devices", "sonde_node_range", "sonde_node_batch", "sonde_node_submit", "sonde_node_submit_on", "sonde_node_gather_stats",
                 "sonde_node_submit_local", "sonde_node_scatter_done", "sonde_node_sync", "sonde_node_frames", "sonde_node_poll",
                 "sonde_node_scatter_stats", "sonde_node_last_error"]
 
@@ -35,6 +35,8 @@ def lib():
         L.sonde_node_batch.argtypes = [vp, C.c_uint32]
         L.sonde_node_batch.restype = vp
         L.sonde_node_submit.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+        L.sonde_node_submit_on.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
+        L.sonde_node_gather_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.sonde_node_submit_local.argtypes = [vp, C.POINTER(vp), C.c_size_t, C.c_size_t]
         L.sonde_node_scatter_done.argtypes = [vp]
         L.sonde_node_sync.argtypes = [vp]
@@ -57,12 +59,13 @@ class SondeNode:
     """All channels of one node: `devices` (HIP ordinals) each decode a contiguous channel range; submit() takes the IQ of ALL
     channels as a device tensor [C, n, 2] on devices[ingest]."""
 
-    def __init__(self, n_channels: int, max_samples: int, devices=(0,), ingest: int = 0, types=None, input_kind: int = INPUT_IQ, flags: int = 0):
+    def __init__(self, n_channels: int, max_samples: int, devices=(0,), ingest: int = 0, types=None, input_kind: int = INPUT_IQ, flags: int = 0, scatter_mode: int = 0):
         self.L = lib()
         self._devs = (C.c_int32 * len(devices))(*devices)
         cfg = SondeNodeConfig()
         cfg.n_devices, cfg.devices, cfg.ingest = len(devices), self._devs, ingest
         cfg.n_channels, cfg.max_samples, cfg.input_kind, cfg.flags = n_channels, max_samples, input_kind, flags
+        cfg.scatter_mode = scatter_mode
         self._types = None
         if types is not None:
             self._types = np.ascontiguousarray(types, dtype=np.uint8)
@@ -83,15 +86,23 @@ class SondeNode:
         self._chk(self.L.sonde_node_range(self.h, d, C.byref(f), C.byref(c)))
         return f.value, f.value + c.value
 
-    def submit(self, iq):
+    def submit(self, iq, stream: int | None = None):
+        """iq: device tensor [C, n, 2] on the ingest device.  The scatter starts behind the work queued on `stream` (a hipStream_t
+        value; default: torch's current stream on the ingest device) -- the stream that produced iq."""
         assert iq.is_cuda and iq.device.index == self.devices[self.ingest] and iq.shape[0] == self.n_channels and iq.stride(1) == 2
-        self._keep = iq
-        self._chk(self.L.sonde_node_submit(self.h, C.c_void_p(iq.data_ptr()), iq.shape[1], iq.stride(0) // 2))
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(iq.device).cuda_stream
+        self._keep = (iq, getattr(self, "_keep", (None, None))[0])
+        self._chk(self.L.sonde_node_submit_on(self.h, C.c_void_p(iq.data_ptr()), iq.shape[1], iq.stride(0) // 2, C.c_void_p(stream)))
 
     def submit_local(self, rows):
         """rows[d]: device tensor [count_d, n, 2] on devices[d] (all with the same channel stride)."""
+        import torch
+        for r in rows:                 # the per-device decoders run on the node's own streams: the rows must be complete (ADVICE r4)
+            torch.cuda.current_stream(r.device).synchronize()
         arr = (C.c_void_p * len(rows))(*[r.data_ptr() for r in rows])
-        self._keep = rows
+        self._keep = (rows, getattr(self, "_keep", (None, None))[0])
         self._chk(self.L.sonde_node_submit_local(self.h, arr, rows[0].shape[1], rows[0].stride(0) // 2))
 
     def scatter_done(self):
@@ -124,6 +135,11 @@ class SondeNode:
         ms, by, ns = C.c_float(), C.c_uint64(), C.c_uint32()
         self._chk(self.L.sonde_node_scatter_stats(self.h, C.byref(ms), C.byref(by), C.byref(ns)))
         return {"ms": ms.value, "bytes_from_ingest": by.value, "sends": ns.value}
+
+    def gather_stats(self):
+        ms, by = C.c_double(), C.c_uint64()
+        self._chk(self.L.sonde_node_gather_stats(self.h, C.byref(ms), C.byref(by)))
+        return {"ms": ms.value, "bytes": by.value}
 
     def close(self):
         if getattr(self, "h", None):

@@ -116,22 +116,27 @@ class NativeShard:
             raise RuntimeError(self.lib().sonde_shard_last_error().decode())
         return out
 
-    def scatter_rows(self, full: torch.Tensor | None, n_rows_total: int, n_samples: int, root: int = 0) -> torch.Tensor:
-        """root holds `full` = [n_rows_total, n, 2] float32 (rows may be strided); every rank gets the rows of its channel range
-        (sonde_shard_range: unequal when the count does not divide) STRAIGHT into rows on the decoder's recommended channel
-        stride: a [count, n, 2] view of a padded allocation, what SondeBatch.submit takes.  No re-stride copy."""
+    def scatter_rows(self, full: torch.Tensor | None, n_rows_total: int, n_samples: int, root: int = 0, src_stride: int | None = None) -> torch.Tensor:
+        """root holds `full` = [n_rows_total, n, 2] float32, rows `src_stride` samples apart (default: back to back); every rank gets
+        the rows of its channel range (sonde_shard_range: unequal when the count does not divide) as a [count, n, 2] view of what
+        SondeBatch.submit takes.  src_stride must be passed ALIKE ON EVERY RANK (only the root can read it off `full`; ADVICE r4: a
+        rank guessing it could pick the other transfer shape and hang): it decides the shape of the transfer as in the node-level host
+        (include/sonde_node.h): rows on the decoder's recommended stride -> one send per peer, rows land on that stride; rows back to
+        back -> one send per peer of exactly the shard's bytes, rows land back to back; any other stride -> one send per row into
+        rows on the recommended stride."""
         import ctypes as C
         from .batch import row_stride
         lo, hi = self.channel_range(n_rows_total, self.rank, self.world)
-        st_ = row_stride(n_samples, iq=True)
-        buf = torch.empty((hi - lo, st_, 2), dtype=torch.float32, device=f"cuda:{self.device}")
-        src_stride = 0
+        reco = row_stride(n_samples, iq=True)
+        src_stride = int(src_stride or n_samples)
+        dst_stride = n_samples if src_stride == n_samples else reco
+        buf = torch.empty((hi - lo, dst_stride, 2), dtype=torch.float32, device=f"cuda:{self.device}")
         if self.rank == root:
             assert full is not None and full.shape[0] == n_rows_total and full.shape[1] == n_samples and full.stride(1) == 2
-            src_stride = full.stride(0) * 4
+            assert full.stride(0) == 2 * src_stride, "src_stride (passed alike on every rank) must be the root tensor's row stride"
         st = torch.cuda.current_stream(buf.device).cuda_stream
-        if self.lib().sonde_shard_scatter_rows(self.h, C.c_void_p(full.data_ptr() if self.rank == root else 0), src_stride or n_samples * 8,
-                                               C.c_void_p(buf.data_ptr()), st_ * 8, n_samples * 8, n_rows_total, root, C.c_void_p(st)) != 0:
+        if self.lib().sonde_shard_scatter_rows(self.h, C.c_void_p(full.data_ptr() if self.rank == root else 0), src_stride * 8,
+                                               C.c_void_p(buf.data_ptr()), dst_stride * 8, n_samples * 8, n_rows_total, root, C.c_void_p(st)) != 0:
             raise RuntimeError(self.lib().sonde_shard_last_error().decode())
         return buf[:, :n_samples]
 

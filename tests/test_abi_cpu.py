@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.SondeFrame) == 560 and _lib.FRAME_DTYPE.itemsize == 560
     assert _lib.SondeFrame.bitpos.offset == 24 and _lib.SondeFrame.data.offset == 32
-    assert C.sizeof(_lib.SondeBatchConfig) == 32
+    assert C.sizeof(_lib.SondeBatchConfig) == 40 and _lib.SondeBatchConfig.launch_units.offset == 32      # (round 5: + launch_units)
 
 
 def test_tap_tables_equal_oracle_bit_for_bit(lib, oracle):
@@ -66,6 +66,22 @@ def test_argument_validation(lib):
     assert lib.rs41_decoder_init(44100) is None        # reference always passes 48000 (main.cpp:16,62-68)
     cfg.n_channels, cfg.max_samples, cfg.input_kind = 4, 2048, 7
     assert lib.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0 and b"input_kind" in lib.sonde_last_error()
+
+
+def test_row_stride_is_monotonic(lib):
+    """buffers sized from sonde_row_stride(max_samples) are written at sonde_row_stride(n_samples), n_samples <= max_samples:
+    the stride must never shrink as the row grows (the round-4 rule gave rows of 80 KiB a 192 KiB stride and rows of 96 KiB 128 KiB),
+    must hold the row, and stay a multiple of 16 bytes."""
+    for kind in (_lib.INPUT_IQ, _lib.INPUT_REAL, _lib.INPUT_IQ16, _lib.INPUT_IQ8):
+        eb = lib.sonde_sample_bytes(kind)
+        prev = 0
+        for tiles in range(1, 400):
+            n = 2048 * tiles
+            st = lib.sonde_row_stride(n, kind)
+            assert st >= n and st >= prev and (st * eb) % 16 == 0, (kind, n, st, prev)
+            assert st * eb <= max(2 * n * eb, 65536), (kind, n, st)          # never more than twice the row
+            prev = st
+    assert lib.sonde_row_stride(10240, _lib.INPUT_IQ) == 16384 and lib.sonde_row_stride(12288, _lib.INPUT_IQ) == 16384
 
 
 def test_input_kinds_sample_bytes_and_row_stride(lib):

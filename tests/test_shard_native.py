@@ -45,14 +45,26 @@ def test_single_rank_scatter_gather_on_device():
 
 
 @pytest.mark.gpu
-def test_single_rank_scatter_rows_into_strided_rows():
-    """sonde_shard_scatter_rows: the rows land on the decoder's recommended channel stride (a view of a padded allocation)."""
+def test_single_rank_scatter_rows_layouts():
+    """sonde_shard_scatter_rows through NativeShard.scatter_rows: the destination layout follows the source layout, passed alike on
+    every rank: rows on the decoder's recommended stride land on that stride (one send per peer), rows back to back
+    land back to back (one send per peer of exactly the shard's bytes), any other stride lands on the recommended stride row by row."""
     import torch
-    from sdrpp_radiosonde_amd.batch import row_stride
+    from sdrpp_radiosonde_amd.batch import row_stride, strided_rows
     ns = shard.NativeShard(0, rank=0, world=1)
     n = 8 * 2048 + 2048                                   # 144 KiB rows -> 256 KiB stride
     x = torch.randn((5, n, 2), device="cuda:0")
-    got = ns.scatter_rows(x, 5, n, root=0)
+    got = ns.scatter_rows(x, 5, n, root=0)                                     # back to back
     torch.cuda.synchronize()
-    assert got.shape == x.shape and got.stride(0) == 2 * row_stride(n) and torch.equal(got, x)
+    assert got.shape == x.shape and got.stride(0) == 2 * n and torch.equal(got, x) and got.data_ptr() != x.data_ptr()
+    xs = strided_rows(x)
+    got = ns.scatter_rows(xs, 5, n, root=0, src_stride=row_stride(n))         # on the recommended stride
+    torch.cuda.synchronize()
+    assert got.stride(0) == 2 * row_stride(n) and torch.equal(got, x)
+    xo = strided_rows(x, n + 4096)
+    got = ns.scatter_rows(xo, 5, n, root=0, src_stride=n + 4096)              # any other stride
+    torch.cuda.synchronize()
+    assert got.stride(0) == 2 * row_stride(n) and torch.equal(got, x)
+    with pytest.raises(AssertionError):
+        ns.scatter_rows(xs, 5, n, root=0)                                      # the root's tensor contradicts the stride every rank was told
     ns.close()
