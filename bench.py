@@ -89,6 +89,7 @@ def parse_args():
     ap.add_argument("--wb-iq16", action="store_true", help="--wideband: the blocks as int16 I, Q pairs (sonde_chan_set_input: what a 10 MS/s receiver delivers)")
     ap.add_argument("--wb-overlap", action="store_true", help="--wideband: filter bank and decoder on two internal streams (consecutive submits may overlap)")
     ap.add_argument("--wb-blocks", type=int, default=1, choices=(1, 2, 4, 8), help="--wideband: blocks of 1 280 000 samples (0.128 s) per submit")
+    ap.add_argument("--wb-occupied", type=int, default=16, help="--wideband: bins of every stream that carry an RS41 transmitter (16: a sparse band; 256: every other bin, the FEC stage busy)")
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
                     "4 for runs of fewer than 16 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
                     "(profiles/r2_notes.md), inside the timed region: every 8th costs 0.6 %% of the step")
@@ -106,6 +107,9 @@ def parse_args():
                          "two in bytes, 2 MiB for the headline's 1.5 MiB rows; measured 2.3-5.5 %% faster, profiles/r3_stride_sweep.txt) or back to back")
     ap.add_argument("--scatter", action="store_true", help="(the default with --gpus > 1) ingest on rank 0 and scatter IQ shards over RCCL before timing")
     ap.add_argument("--scatter-torch", action="store_true", help="scatter through torch.distributed instead of libsonde_rccl.so")
+    ap.add_argument("--multiproc", action="store_true", help="--gpus > 1: one process per GPU (torch.distributed ranks, libsonde_rccl's sonde_shard_* scatter) instead of the default: ONE "
+                    "process driving every GPU through the native node-level host (sonde_node_*, ncclCommInitAll)")
+    ap.add_argument("--node", action="store_true", help="run through the node-level host even with --gpus 1 (a node of one device: test hook)")
     ap.add_argument("--rank-local", action="store_true", help="--gpus > 1: every rank generates its own shard (no scatter): kernel scaling without xGMI time")
     args = ap.parse_args()
     if args.trace_child:      # the headline workload itself, 60 timed steps, no timing events: nothing printed
@@ -176,8 +180,29 @@ def cpu_baseline(iq, C, n, args):
 
 def main():
     args = parse_args()
+    # ---- N > 1 (or --node): ONE process drives every GPU through the product's C++ node-level host (include/sonde_node.h:
+    # ncclCommInitAll, scatter of IQ rows over xGMI, one decoder batch per GPU) -- north_star's "C++ host code ... sharded across the 8
+    # GPUs of one node with an RCCL scatter" (VERDICT r4 item 2).  Under the driver's torchrun launch (one rank per GPU) rank 0 is that
+    # process and the other ranks wait at a host-side barrier; `--multiproc` keeps round 4's one-process-per-GPU path.
+    node_mode = (args.gpus > 1 or args.node) and not args.multiproc and not args.wideband and not args.mix and not args.sonde_type \
+        and os.environ.get("SONDE_BENCH_BACKEND", "nccl") != "gloo"
+    if node_mode and torch.cuda.is_available() and torch.cuda.device_count() >= args.gpus:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        dist = None
+        if world > 1:                              # the driver's launch: the ranks only rendezvous (gloo: no device work on ranks > 0)
+            import torch.distributed as dist
+            import datetime
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=60))
+        if rank == 0:
+            out = run_node(args, launched_ranks=world)
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` as typed: spawn the ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+        # `python bench.py --gpus N --multiproc` as typed: spawn the ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
@@ -271,6 +296,7 @@ def ramp_and_time(submit, sync, args, barrier, reset=None):
 
 
 FLAG_PIPELINE = 4
+FLAG_JOIN = 16
 CLASS_NAMES = ("dec1_nt16", "dec2_nt16", "dec4_nt8 (RS41/DFM/iMS-100/MRZ-N1)", "dec2_nt8 (M10)")
 
 
@@ -327,6 +353,7 @@ def measure(blocks, types, flags, args, local_rank, barrier, stream, input_kind=
     nfr_first = int(fresh.sync())
     fresh.close()
     batch = SondeBatch(C, n, device=local_rank, types=types, flags=flags, input_kind=input_kind)
+    launch = batch.launch_info()                   # launch units per submit and how they are joined (the library's choice at these flags)
     turn = [0]
 
     def submit():
@@ -345,7 +372,7 @@ def measure(blocks, types, flags, args, local_rank, barrier, stream, input_kind=
         nfr_step += batch.sync()
     nfr_step /= len(blocks)
     batch.close()
-    return {"dt": dt, "demod_ms": demod_ms, "framer_ms": framer_ms, "class_ms": class_ms, "nfr_first": nfr_first, "nfr_step": nfr_step}
+    return {"dt": dt, "demod_ms": demod_ms, "framer_ms": framer_ms, "class_ms": class_ms, "nfr_first": nfr_first, "nfr_step": nfr_step, "launch": launch}
 
 
 def alg_bytes_of(C, n, sample_bytes=8):
@@ -377,8 +404,8 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     a = copy.copy(args)
     # (their own step counts, stated in the record: the pipelined class streams need a few steps to fill and one to drain,
     # which a 20-step region would charge at 3-5 %)
-    a.steps = steps or (100 if flags & FLAG_PIPELINE else max(60, min(args.steps, 100)))
-    a.warmup = warmup or (20 if flags & FLAG_PIPELINE else max(10, min(args.warmup, 20)))
+    a.steps = steps or 100
+    a.warmup = warmup or 20
     a.ramp_ms = min(args.ramp_ms, 100.0)
     blocks, types = make_blocks(kind, C, tiles, NB, args.ebn0 if ebn0 is None else ebn0, dev, seed=1000)
     if iq16:
@@ -394,7 +421,9 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     torch.cuda.empty_cache()
     n = tiles * 2048
     ms = m["dt"] / a.steps * 1e3
-    rec = {"channels": C, "samples_per_channel": n, "channel_stride_samples": stride_samples, "blocks_cycled": NB, "flags": flags, "steps": a.steps, "warmup": a.warmup,
+    rec = {"channels": C, "samples_per_channel": n, "channel_stride_samples": stride_samples, "blocks_cycled": NB, "flags": flags, "launch_units": m["launch"]["units"],
+           "join": ("every submit", "one submit late", "never")[m["launch"]["join"]] if m["launch"]["units"] > 1 else "one launch on the caller's stream",
+           "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 4), "value": round(C * n / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s",
            "step_frac": round(alg_bytes_of(C, n, 2 if iq8 else (4 if iq16 else 8)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "frames_per_step_steady": round(m["nfr_step"], 2)}
@@ -404,6 +433,9 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
         rec["input"] = "int8 IQ (SONDE_INPUT_IQ8): 2 bytes per sample; step_frac counts those"
     if m["class_ms"]:
         rec["kernel_ms"] = {CLASS_NAMES[k]: round(v, 4) for k, v in m["class_ms"].items()}
+    elif m["launch"]["units"] > 1:
+        rec["kernel_ms"] = {"fork_to_completion": round(m["demod_ms"], 4),
+                            "note": "launch units on their own streams: HIP events from a submit's fork to its completion, overlapping the neighbouring submits -- not a kernel duration"}
     else:
         rec["kernel_ms"] = {"demod": round(m["demod_ms"], 4), "framer_fec": round(m["framer_ms"], 4)}
     return rec
@@ -535,7 +567,8 @@ def traced_kernel_us(args):
         if len(rows) < 20:
             return None, 0, "too few sd_demod_kernel launches in the trace"
         us = sum(e - b for b, e in rows) / len(rows) / 1e3
-        return us, len(rows), f"rocprofv3 --kernel-trace over a sub-run of this command's shape, last {len(rows)} launches"
+        return us, len(rows), (f"rocprofv3 --kernel-trace over a SEPARATE sub-run of this command's shape (profiler attached, its own clocks: "
+                               f"may read a fraction of a percent above or below this run's ms_per_step), last {len(rows)} launches")
     except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as e:
         return None, 0, f"rocprofv3 --kernel-trace: {e}"
     finally:
@@ -551,7 +584,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
     if args.time_every is None:
         args.time_every = 8 if args.steps >= 16 else 4
     if args.flags is None:
-        args.flags = FLAG_PIPELINE if args.mix else 0
+        args.flags = 0
     C, n = args.channels, args.tiles * 2048
     stream = torch.cuda.current_stream().cuda_stream
     kind = "mix" if args.mix else (args.sonde_type if args.sonde_type else "rs41")
@@ -588,7 +621,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
     # roofline of the dominant kernel (the demodulator): algorithmic bytes = 8 B per complex64 sample read once
     # + bits written (n/sps/8 bytes per channel) -- DESIGN.md section 6
     alg_bytes = alg_bytes_of(C, n)
-    pipelined = bool(args.flags & FLAG_PIPELINE) and kind == "mix"
+    pipelined = m["launch"]["units"] > 1 and m["launch"]["join"] != 0      # launch units that overlap from submit to submit
     if pipelined:
         demod_ms = ms_per_step        # the classes of consecutive submits overlap: there is no per-step kernel interval; see kernel_ms
     step_achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
@@ -654,6 +687,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                                 f"RS41-SG x {C} channels/GPU x {n} samples per step (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)")
                                + (f"; {len(blocks)} consecutive blocks of a continuous signal resident in HBM, cycled" if len(blocks) > 1 else ""),
                    "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{world}", "flags": args.flags,
+                   "launch_units": m["launch"]["units"], "join": ("every submit", "one submit late", "never")[m["launch"]["join"]] if m["launch"]["units"] > 1 else "one launch on the caller's stream",
                    "channel_stride_samples": int(blocks[0].stride(0) // 2),
                    "layout": ("rows back to back" if int(blocks[0].stride(0) // 2) == n else
                               f"rows {int(blocks[0].stride(0) // 2) * 8 // 1024} KiB apart (sonde_row_stride; --row-stride contiguous puts them back to back)"),
@@ -684,17 +718,18 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
         del blocks
         torch.cuda.empty_cache()
         others = {}
-        others["mix4096"] = small_run("mix", 4096, 24, 5, FLAG_PIPELINE, args, local_rank, dev, barrier, stream)
-        others["mix4096"]["workload"] = "BASELINE configs[2]: RS41 / M10 / DFM09 by channel % 3, 4096 channels x 49152 samples per step, pipelined class streams"
-        others["mix4096_joined"] = small_run("mix", 4096, 24, 5, 0, args, local_rank, dev, barrier, stream)
-        others["mix4096_joined"]["workload"] = "the same, every submit joined into the caller's stream (flags 0)"
+        others["mix4096"] = small_run("mix", 4096, 24, 5, 0, args, local_rank, dev, barrier, stream)
+        others["mix4096"]["workload"] = ("BASELINE configs[2]: RS41 / M10 / DFM09 by channel % 3, 4096 channels x 49152 samples per step, DEFAULT flags: one launch unit per "
+                                         "sonde type on its own stream, the caller's stream joined one submit late")
+        others["mix4096_joined"] = small_run("mix", 4096, 24, 5, FLAG_JOIN, args, local_rank, dev, barrier, stream)
+        others["mix4096_joined"]["workload"] = "the same with SONDE_FLAG_JOIN: every submit joined into the caller's stream (rounds 1-4's default)"
         others["shard8192"] = small_run("rs41", 8192, 24, 5, 0, args, local_rank, dev, barrier, stream)
         others["shard8192"]["workload"] = "BASELINE configs[4], one GPU's shard: 8192 RS41 channels x 49152 samples (T = 1 s) per step"
-        others["rt1250"] = small_run("rs41", 1250, 24, 5, FLAG_PIPELINE, args, local_rank, dev, barrier, stream)
+        others["rt1250"] = small_run("rs41", 1250, 24, 5, 0, args, local_rank, dev, barrier, stream)
         others["rt1250"]["workload"] = ("north_star's per-GPU share of 10^4 channels on 8 GPUs: 1250 RS41 channels x 49152 samples (T = 1 s) per step "
-                                        "(1.22 residencies of 4 workgroups x 256 CUs); SONDE_FLAG_PIPELINE: two launch units on their own streams, the tail of one overlaps the next submit of the other")
-        others["ch1280x96"] = small_run("rs41", 1280, 96, 5, FLAG_PIPELINE, args, local_rank, dev, barrier, stream)
-        others["ch1280x96"]["workload"] = "1280 RS41 channels x 196608 samples per step: the headline's rows, 1.25 residencies; SONDE_FLAG_PIPELINE (two launch units)"
+                                        "(1.22 residencies of 4 workgroups x 256 CUs); DEFAULT flags: two launch units on their own streams joined one submit late, the tail of one overlaps the next submit of the other")
+        others["ch1280x96"] = small_run("rs41", 1280, 96, 5, 0, args, local_rank, dev, barrier, stream)
+        others["ch1280x96"]["workload"] = "1280 RS41 channels x 196608 samples per step: the headline's rows, 1.25 residencies; DEFAULT flags (two launch units, joined one submit late)"
         others["cs16_1024x96"] = small_run("rs41", 1024, 96, 5, 0, args, local_rank, dev, barrier, stream, iq16=True)
         others["cs16_1024x96"]["workload"] = ("the headline's signal as 16-bit integer IQ rows (SONDE_INPUT_IQ16, what SDR hardware delivers): 1024 RS41 channels x 196608 "
                                               "samples per step, 4 bytes per sample; frames identical to the float path on the same integers")
@@ -712,10 +747,11 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
             others["rt1250_host_e2e_cs8"]["workload"] = "the same from 8-bit integer IQ in host memory (SONDE_INPUT_IQ8)"
         except Exception as e:                    # (never lets the line fail: the headline above does not depend on it)
             others["rt1250_host_e2e"] = {"error": f"{type(e).__name__}: {e}"}
-        for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8x4", 8, 4), ("wideband4_dual", 4, 1), ("wideband8_cs16", 8, 1)):
+        for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8_dense", 8, 1), ("wideband8x4", 8, 4), ("wideband4_dual", 4, 1), ("wideband8_cs16", 8, 1)):
             import copy
             a = copy.copy(args)
             a.wb_streams, a.wb_blocks = S, B
+            a.wb_occupied = 256 if name.endswith("_dense") else 16
             a.wb_dual = name.endswith("_dual")
             a.wb_iq16 = name.endswith("_cs16")
             a.steps, a.warmup, a.ramp_ms = max(40, min(args.steps, 50)), max(8, min(args.warmup, 10)), min(args.ramp_ms, 100.0)
@@ -723,7 +759,8 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
             others[name] = {
                 "workload": "BASELINE configs[3]: " + w["config"]["workload"], "ms_per_step": w["ms_per_step"], "value": w["value"],
                 "unit": w["unit"], "realtime_streams": w["realtime_streams"], "us_per_stream_block": round(w["ms_per_step"] * 1e3 / (S * B), 2),
-                "step_frac": w["roofline"]["step_frac"], "kernel_ms": w["kernel_ms"], "steps": a.steps, "warmup": a.warmup}
+                "step_frac": w["roofline"]["step_frac"], "kernel_ms": w["kernel_ms"], "frames_per_step": w["frames_per_step"],
+                "occupied_bins_per_stream": w["config"]["occupied_bins_per_stream"], "steps": a.steps, "warmup": a.warmup}
         out["other_configs"] = others
         if getattr(args, "row_stride", "pow2") == "pow2" and not args.stride_pad:
             # the same workload with the rows back to back, measured in this run: what the layout is worth
@@ -776,7 +813,10 @@ def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
         barrier()
         t0 = time.perf_counter()
         if ns is not None and strided:
-            blk = ns.scatter_rows(full, world * C, n, root=0)          # straight into rows on the decoder's channel stride: no re-stride copy
+            from sdrpp_radiosonde_amd.batch import row_stride, strided_rows
+            if rank == 0:
+                full = strided_rows(full)            # the ingest block on the decoder's recommended stride: a peer's shard is ONE send
+            blk = ns.scatter_rows(full, world * C, n, root=0, src_stride=row_stride(n))      # straight into the rows the decoder reads
         else:
             blk = ns.scatter_iq(full, (C, n, 2), root=0) if ns is not None else scatter_iq(full, C, n, dev, src=0)
         torch.cuda.synchronize()
@@ -789,12 +829,135 @@ def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
     bound = 7 * 153.0                                        # GB/s: all seven xGMI links of the root at once
     return blocks, None, {
         "ingest": "scatter from rank 0: torch.distributed" if args.scatter_torch else
-                  ("scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv, one per row, straight into rows on the decoder's channel stride)" if strided
+                  ("scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv, one per peer, ingest block and decoder rows on the recommended channel stride)" if strided
                    else "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)"),
         "rows_delivered_strided": bool(ns is not None and strided),
         "ms": round(ms, 3), "blocks": NB, "bytes_from_root": sent, "gbs": round(gbs, 2),
         "root_egress_bound_gbs": bound, "frac_of_bound": round(gbs / (bound * min(1.0, (world - 1) / 7.0)), 4),
         "note": "root holds one block of all ranks at a time; outside the timed region"}
+
+
+def run_node(args, launched_ranks=1):
+    """--gpus N through the native node-level host, ONE process (include/sonde_node.h, csrc/node.cpp in libsonde_rccl.so).
+    Timed region (the contract's): K steps with every GPU's shard RESIDENT in its HBM (sonde_node_submit_local: one
+    sonde_batch_submit per device on the node's streams), bracketed by a synchronise of every device; value = samples of all GPUs /
+    that time.  Beside it, per step and outside the timed region: the ingest path north_star names -- the IQ of ALL channels on
+    GPU 0, scattered over xGMI by sonde_node_submit (scatter_ms: device time on the ingest GPU's stream; bytes; sends; fraction of
+    the 7-link egress bound) -- and the return path (gather_ms: frame records of every device to host memory)."""
+    from sdrpp_radiosonde_amd.node import SondeNode
+    from sdrpp_radiosonde_amd.batch import row_stride, strided_rows
+    N = args.gpus
+    if args.channels is None:
+        args.channels = 1024
+    if args.time_every is None:
+        args.time_every = 8 if args.steps >= 16 else 4
+    if args.flags is None:
+        args.flags = 0
+    C, n, NB = args.channels, args.tiles * 2048, args.blocks
+    devs = [torch.device("cuda", d) for d in range(N)]
+    shards = []                                    # [device][block]: the device's channels, rows on the stride asked for
+    for d in range(N):
+        torch.cuda.set_device(d)
+        blocks, _ = make_blocks("rs41", C, args.tiles, NB, args.ebn0, devs[d], seed=1000 + d, first_channel=d * C)
+        shards.append(restride(blocks, args))
+    NB = len(shards[0])
+    torch.cuda.set_device(0)
+    node = SondeNode(N * C, n, devices=list(range(N)), ingest=0, flags=args.flags)
+    turn = [0]
+
+    def submit():
+        node.submit_local([shards[d][turn[0] % NB] for d in range(N)])
+        turn[0] += 1
+
+    def sync_all():
+        node.sync()
+        for d in range(N):
+            torch.cuda.synchronize(d)
+
+    for d in range(N):
+        node_batch_timing(node, d, 0)
+    dt = ramp_and_time(submit, sync_all, args, sync_all, reset=lambda: [node_batch_timing(node, d, args.time_every) for d in range(N)])
+    kern = [node_batch_kernel_ms(node, d) for d in range(N)]
+    nfr = 0
+    for _ in range(NB):
+        submit()
+        nfr += node.sync()
+    nfr /= NB
+    samples_per_step = N * C * n
+    msps = samples_per_step * args.steps / dt / 1e6
+    ms_per_step = dt / args.steps * 1e3
+    alg = alg_bytes_of(C, n)                        # per GPU
+    demod_ms = max((k[0] for k in kern if k), default=0.0)
+    demod_ms = min(demod_ms, ms_per_step) if demod_ms > 0 else ms_per_step
+    # ---- the ingest path: all channels on GPU 0 (one block), scattered per step; then the frame gather
+    scatter = None
+    try:
+        st_full = row_stride(n) if getattr(args, "row_stride", "pow2") == "pow2" else n
+        full = torch.empty((N * C, st_full, 2), dtype=torch.float32, device=devs[0])[:, :n]
+        for d in range(N):
+            full[d * C: (d + 1) * C] = shards[d][0].to(devs[0])
+        torch.cuda.synchronize(0)
+        ms, gms, nby, nsend, gby = [], [], 0, 0, 0
+        for k in range(6):
+            node.submit(full)
+            fr = node.frames()
+            sst, gst = node.scatter_stats(), node.gather_stats()
+            if k:                                   # (the first scatter pays RCCL's connection set-up)
+                ms.append(sst["ms"]); gms.append(gst["ms"])
+            nby, nsend, gby = sst["bytes_from_ingest"], sst["sends"], gst["bytes"]
+        bound = 7 * 153.0 * min(1.0, (N - 1) / 7.0)             # GB/s: the ingest GPU's xGMI links towards its N - 1 peers (SURVEY 8e)
+        sms = sum(ms) / len(ms)
+        scatter = {"ingest": "sonde_node_submit: IQ of all channels on GPU 0 -> grouped ncclSend / ncclRecv straight into every peer's decoder rows "
+                             f"({'one send per peer, rows on the recommended stride (padding travels too)' if st_full != n else 'one send per peer of exactly the shard, rows back to back'})",
+                   "ms": round(sms, 3), "bytes_from_ingest": nby, "sends": nsend, "gbs": round(nby / (sms * 1e-3) / 1e9, 2) if sms > 0 else None,
+                   "ingest_egress_bound_gbs": round(bound, 1), "frac_of_bound": round(nby / (sms * 1e-3) / 1e9 / bound, 4) if (sms > 0 and N > 1) else None,
+                   "gather_ms": round(sum(gms) / len(gms), 3), "gather_bytes": gby, "frames_gathered": int(len(fr)),
+                   "note": "outside the timed region (the contract times resident inputs): averages of 5 steps after RCCL's first-call set-up; "
+                           "gather = frame records of every device copied to host memory (one process: nothing travels back over xGMI)"}
+    except Exception as e:                          # (never lets the line fail)
+        scatter = {"error": f"{type(e).__name__}: {e}"}
+    node.close()
+    out = {
+        "metric": "IQ Msamples/s through demod+FEC @ 48 kS/s/ch", "value": round(msps, 3), "unit": "Msamples/s", "n_gpus": N,
+        "steps": args.steps, "warmup": args.warmup, "ramp_ms": args.ramp_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"RS41-SG x {C} channels/GPU x {n} samples per step (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB); {NB} consecutive blocks of a continuous signal resident in every GPU's HBM, cycled",
+                   "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{N} (contiguous ranges, sonde_shard_range)", "flags": args.flags,
+                   "channel_stride_samples": int(shards[0][0].stride(0) // 2),
+                   "host": f"ONE process, sonde_node_* (libsonde_rccl.so: ncclCommInitAll over {N} device(s), one SondeBatch per device); ranks launched by the caller: {launched_ranks}",
+                   "ingest": "resident shards (sonde_node_submit_local) in the timed region; scatter from GPU 0 measured beside it"},
+        "frames_per_s": round(nfr * args.steps / dt, 1), "frames_per_step_steady": round(nfr, 2),
+        "realtime_channels": round(msps * 1e6 / 48000.0, 1),
+        "kernel_ms": {"demod_per_device": [round(k[0], 4) if k else None for k in kern], "framer_fec_per_device": [round(k[1], 4) if k else None for k in kern],
+                      "note": "HIP events around every %dth launch on each device (capped at the step for the roofline)" % args.time_every},
+        "roofline": {"bound": "hbm", "achieved": round(alg / (demod_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (demod_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg,
+                     "kernel": "sd_demod_kernel, per GPU (slowest device's HIP-event time, capped at the step); step_frac = one GPU's bytes / the whole step",
+                     "kernel_time_source": "HIP events (no nested rocprofv3 pass in node mode)"},
+        "nccl_ranks": {"backend": "rccl (ncclCommInitAll, one process)" if N > 1 else "none (one device)", "world": N, "distinct_devices": N},
+        "scatter": scatter,
+    }
+    if scatter and "ms" in scatter:
+        out["scatter_ms"], out["gather_ms"] = scatter["ms"], scatter["gather_ms"]
+    return out
+
+
+def node_batch_timing(node, d, every):
+    import ctypes
+    from sdrpp_radiosonde_amd import _lib
+    L = _lib.load()
+    L.sonde_batch_set_timing(ctypes.c_void_p(node.L.sonde_node_batch(node.h, d)), int(every))
+
+
+def node_batch_kernel_ms(node, d):
+    import ctypes
+    from sdrpp_radiosonde_amd import _lib
+    L = _lib.load()
+    a, b = ctypes.c_float(), ctypes.c_float()
+    if L.sonde_batch_kernel_ms(ctypes.c_void_p(node.L.sonde_node_batch(node.h, d)), ctypes.byref(a), ctypes.byref(b)) != 0:
+        return None
+    return a.value, b.value
 
 
 def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
@@ -809,11 +972,15 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
     chan = SondeChannelizer(blocks_per_submit=args.wb_blocks, device=local_rank, n_streams=S, overlap=getattr(args, "wb_overlap", False), dual=dual,
                             input_kind=2 if iq16 else 0)      # ONE object: every stage is one launch over all S streams
     nwb = chan.samples_per_submit
-    bins_active = list(range(8, 504, 8))
-    # a 1.024 s scene (8 blocks of 0.128 s) with 16 RS41 transmitters, cycled block by block so that the per-bin streams
-    # are continuous (one discontinuity per wrap) and frames really decode; stream s runs s blocks ahead of stream 0
+    occ = int(getattr(args, "wb_occupied", 16))
+    bins_active = list(range(8, 504, 8))[:occ] if occ <= 62 else list(range(1, 512, 2))[:occ]
+    # a 1.024 s scene (8 blocks of 0.128 s) with `occ` RS41 transmitters (16: a sparse band; 256: every other bin, so that the sync
+    # search collects frames and the FEC stage decodes them in half the bins), cycled block by block so that the per-bin streams
+    # are continuous (one discontinuity per wrap) and frames really decode; stream s runs s blocks ahead of stream 0.  Every
+    # transmitter brings its own white noise over the 10 MHz: the per-transmitter Eb/N0 is raised with their number
     NB = 8 // args.wb_blocks
-    scene, _ = synth.make_wideband_rs41(bins_active[:16], NB * nwb, seed=7 + rank, ebn0_db=30.0, device=dev)
+    scene, _ = synth.make_wideband_rs41(bins_active, NB * nwb, seed=7 + rank, ebn0_db=30.0 + 10.0 * np.log10(max(1.0, len(bins_active) / 16.0)), device=dev)
+    scene *= min(1.0, 4.0 / np.sqrt(len(bins_active)))               # (the sum of many carriers stays inside 16 bits for --wb-iq16)
     if iq16:
         scene = torch.clamp(torch.round(scene * 1024.0), -32768, 32767).to(torch.int16)      # (16 carriers of unit amplitude + noise: well inside 16 bits)
     one = [scene[i * nwb: (i + 1) * nwb] for i in range(NB)]
@@ -850,17 +1017,18 @@ def run_wideband(args, rank, local_rank, world, dev, barrier, reduce_max_sum):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{S} x 10 MS/s complex IQ -> 512-bin polyphase channelizer (20 kS/s/bin, one phase sample per step) -> FM discriminator (wrapped phase difference) -> 12/5 resampler "
                                f"-> {S} x {1024 if dual else 512} x 48 kS/s RS41 demod+FEC" + (" (both stackings: bins every 9.77 kHz)" if dual else "") +
-                               f", one launch per stage over all streams; {nwb} wideband samples per stream per step", "streams_per_gpu": S,
-                   "wideband_samples_per_step": nwb},
+                               f", one launch per stage over all streams; {nwb} wideband samples per stream per step; {len(bins_active)} of the 512 bins of every stream carry a transmitter",
+                   "streams_per_gpu": S, "wideband_samples_per_step": nwb, "occupied_bins_per_stream": len(bins_active)},
         "realtime_factor": round(msps * 1e6 / (S * world * 10e6) , 2),
         "realtime_streams": round(msps / 10.0, 1),
         "narrowband_msps": round(512 * (nwb * 12 // 5 // 500) * S * world * args.steps / dt / 1e6, 3),
         "frames_per_step": round(nfr_total, 2),
-        "kernel_ms": {"pfb_fft": round(pfb_ms, 4), "disc_resample": round(rs_ms, 4), "demod": round(dem_ms, 4), "framer_fec": round(fr_ms, 4)},
+        "kernel_ms": dict({"pfb_fft": round(pfb_ms, 4), "demod": round(dem_ms, 4), "framer_fec": round(fr_ms, 4)},
+                          **({} if chan.fused else {"disc_resample": round(rs_ms, 4)})),      # (fused: discriminator + resampler run inside the bins decoder; no such kernel)
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "algorithmic_bytes": alg_bytes, "kernel": "sd_pfb_kernel (8 B per wideband sample read once)", "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "written_bytes": S * (nwb // 500) * 512 * 4,
-                     "note": "algorithmic bytes = the wideband samples read once; the launch also writes 4.1 B per sample (one phase per bin and step, "
+                     "written_bytes": S * (nwb // 500) * 512 * 2,
+                     "note": "algorithmic bytes = the wideband samples read once; the launch also writes 2 B per bin and step (a 16-bit phase, "
                              "re-read once by the decoder) and re-reads its overlapping windows through the L2"},
     }
 

@@ -1,7 +1,7 @@
 """-m gpu: every number of the driver's bench line has a parity test at ITS shape and ITS flags.
 
 bench.py entry                      test here
-other_configs.mix4096               test_mix4096_pipelined_five_blocks_back_to_back   (SONDE_FLAG_PIPELINE, 4096 x 24 tiles x 5 blocks)
+other_configs.mix4096               test_mix4096_five_blocks_back_to_back[0]          (default flags: joined one submit late; [4]: SONDE_FLAG_PIPELINE)
 low_snr                             test_headline_shape_at_9_db                        (1024 x 96 tiles, Eb/N0 9 dB)
 other_configs.rt1250, ch1280x96     test_part_filled_last_generation[1250-24-4 / 1280-96-4]  (not a multiple of one residency; pipelined, two units)
 other_configs.wideband8x4           tests/test_channelizer.py::test_fused_channelizer_frames_equal_oracle[4-8]
@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from sdrpp_radiosonde_amd import synth
-from sdrpp_radiosonde_amd._lib import FLAG_PIPELINE
+from sdrpp_radiosonde_amd._lib import FLAG_JOIN, FLAG_PIPELINE
 from sdrpp_radiosonde_amd.batch import SondeBatch, strided_rows
 
 pytestmark = pytest.mark.gpu
@@ -32,9 +32,11 @@ def _key(a):
     return a[np.lexsort((a["bitpos"], a["channel"]))]
 
 
-def test_mix4096_pipelined_five_blocks_back_to_back(oracle):
+@pytest.mark.parametrize("flags", [0, FLAG_PIPELINE])
+def test_mix4096_five_blocks_back_to_back(oracle, flags):
     """BASELINE configs[2] as bench.py measures it: RS41 / M10 / DFM09 by channel % 3, 4096 channels x 24 tiles per submit,
-    five consecutive blocks, SONDE_FLAG_PIPELINE (every type's kernels keep their own stream and are never joined), rows on
+    five consecutive blocks, at the DEFAULT flags (round 5: every type's kernels keep their own stream, the caller's stream is joined
+    one submit late) and with SONDE_FLAG_PIPELINE (never joined), rows on
     the recommended stride.  (a) two submits in flight, frames per ticket: all frames byte for byte the oracle's over the
     whole 120-tile signal; (b) all five submits queued with NO host interaction in between (the bench's loop): the frames of
     the last two tickets and every channel's loop state and newest bits equal run (a)'s."""
@@ -59,7 +61,8 @@ def test_mix4096_pipelined_five_blocks_back_to_back(oracle):
     st = torch.cuda.current_stream().cuda_stream
 
     # (a) tickets, two submits in flight
-    b = SondeBatch(C, n, types=types, flags=FLAG_PIPELINE)
+    b = SondeBatch(C, n, types=types, flags=flags)
+    assert b.launch_info() == {"units": 3, "join": 2 if flags else 1}
     b.ticket()
     per_ticket = []
     for k in range(NB):
@@ -77,7 +80,7 @@ def test_mix4096_pipelined_five_blocks_back_to_back(oracle):
     b.close()
 
     # (b) the bench's loop: five submits, nothing in between
-    b = SondeBatch(C, n, types=types, flags=FLAG_PIPELINE)
+    b = SondeBatch(C, n, types=types, flags=flags)
     for k in range(NB):
         b.submit(blocks[k], st)
     f5 = b.frames_of(NB)
@@ -109,20 +112,22 @@ def test_headline_shape_at_9_db(oracle):
         assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in sb.frames[f["channel"]])
 
 
-@pytest.mark.parametrize("C,tiles,flags", [(1250, 24, FLAG_PIPELINE), (1280, 96, FLAG_PIPELINE), (1250, 48, 0), (1537, 24, 0)])
+@pytest.mark.parametrize("C,tiles,flags", [(1250, 24, 0), (1280, 96, 0), (1250, 24, FLAG_PIPELINE), (1250, 48, FLAG_JOIN), (1537, 24, 0)])
 def test_part_filled_last_generation(oracle, C, tiles, flags):
     """Channel counts that are not a multiple of one residency (4 workgroups x 256 CUs): 1250 x 24 tiles = bench.py's rt1250 (the
-    north_star's per-GPU share of 10^4 channels, one second per submit), 1280 x 96 = ch1280x96, both as the bench runs them:
-    SONDE_FLAG_PIPELINE, i.e. two launch units on their own streams, submits queued back to back (frames per ticket, two in
-    flight); 1537 = 1.5 residencies + 1 and 1250 x 48 joined (flags 0).  Four consecutive submits; frames, bit counts and loop
-    state against the oracle."""
+    north_star's per-GPU share of 10^4 channels, one second per submit), 1280 x 96 = ch1280x96, both as the bench runs them (round 5):
+    at the DEFAULT flags, i.e. two launch units on their own streams joined into the caller's stream one submit late, submits queued
+    back to back (frames per ticket, two in flight); the same never joined (SONDE_FLAG_PIPELINE); 1250 x 48 joined at every submit
+    (SONDE_FLAG_JOIN: one launch); 1537 = 1.5 residencies + 1.  Four consecutive submits; frames, bit counts and loop state against
+    the oracle."""
     n, NS = tiles * TILE, 4
     sb = synth.make_rs41_batch(C, NS * n, seed=1250 + C, ebn0_db=13.0, device="cuda:0")
     blocks = [strided_rows(sb.iq[:, k * n: (k + 1) * n].contiguous()) for k in range(NS)]
     b = SondeBatch(C, n, flags=flags)
+    assert b.launch_info() == {"units": 1, "join": 0} if flags & FLAG_JOIN else b.launch_info() == {"units": 2, "join": 2 if flags else 1}
     st = torch.cuda.current_stream().cuda_stream
     parts = []
-    if flags & FLAG_PIPELINE:
+    if not flags & FLAG_JOIN:
         b.ticket()
         for k in range(NS):
             b.submit(blocks[k], st)
@@ -144,6 +149,32 @@ def test_part_filled_last_generation(oracle, C, tiles, flags):
         rs, gs = ch.state(), b.state(c)
         assert (gs["t_next"], gs["period"], gs["bias"], gs["amp"]) == (rs["t_next"], rs["period"], rs["bias"], rs["amp"]), c
         assert b.nbits(c) == len(ch.bits())
+
+
+def test_default_join_is_one_submit_late():
+    """include/sonde_abi.h, "how a submit completes on the caller's stream": at the default flags work queued on the caller's stream
+    behind sonde_batch_submit t is ordered behind submit t - 1.  An event recorded on the caller's stream right after submit 2 has
+    completed => submit 1 has completed (its frames are there without any further wait); with SONDE_FLAG_JOIN the same event
+    covers submit 2 itself.  Channel counts that fill whole residencies stay one plain launch (stream order as ever)."""
+    C, n = 1250, 24 * TILE
+    sb = synth.make_rs41_batch(C, 2 * n, seed=77, ebn0_db=16.0, device="cuda:0")
+    blocks = [strided_rows(sb.iq[:, k * n: (k + 1) * n].contiguous()) for k in range(2)]
+    s = torch.cuda.Stream()
+    for flags in (0, FLAG_JOIN):
+        b = SondeBatch(C, n, flags=flags)
+        b.ticket()
+        with torch.cuda.stream(s):
+            b.submit(blocks[0], s.cuda_stream)
+            b.submit(blocks[1], s.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        ev.synchronize()
+        # whatever the join mode, the event behind submit 2 covers submit 1: its counts can be read at once
+        assert len(b.frames_of(1)) >= C // 2
+        assert len(b.frames_of(2)) >= C // 2
+        b.close()
+    assert SondeBatch(1024, n).launch_info() == {"units": 1, "join": 0}
+    assert SondeBatch(2048, n).launch_info() == {"units": 1, "join": 0}
 
 
 def test_host_path_at_the_target_shape(oracle):

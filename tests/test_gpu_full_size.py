@@ -58,7 +58,8 @@ def test_config2_1024_rs41_channels_full_size(oracle):
     assert b2.frames().tobytes() == got.tobytes()
 
 
-def test_config3_4096_mixed_channels_full_size(oracle):
+@pytest.mark.parametrize("flags", [0, 16])       # the default (launch units joined one submit late) and SONDE_FLAG_JOIN (every submit)
+def test_config3_4096_mixed_channels_full_size(oracle, flags):
     C, n = 4096, 32 * TILE
     order = (0, 3, 1)                                     # RS41, M10, DFM09 by channel % 3
     types = np.array([order[c % 3] for c in range(C)], dtype=np.uint8)
@@ -75,7 +76,7 @@ def test_config3_4096_mixed_channels_full_size(oracle):
         del sb
     ref = np.concatenate(refs)
     ref = ref[np.lexsort((ref["bitpos"], ref["channel"]))]
-    b = SondeBatch(C, n, types=types)
+    b = SondeBatch(C, n, types=types, flags=flags)
     b.submit(iq)
     got = b.frames()
     assert len(ref) >= C
