@@ -190,15 +190,15 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 			float y[2], m[2];
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
-				const uint32_t rel = rel0 + __umul24((unsigned)(lane + 64 * (hh + h)), (unsigned)st.period);
+				const uint32_t rel = rel0 + __umul24((unsigned)(sd_hw_symbol(lane) + 64 * (hh + h)), (unsigned)st.period);      // (the half-wave symbol mapping, sd_wave.h)
 				y[h] = interp<BK_NT>(w.A, taps, rel);
 				m[h] = interp<BK_NT>(w.A, taps, rel - ((uint32_t)st.period >> 1));
 			}
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
-				const bool act = lane + 64 * (hh + h) < K;
+				const bool act = sd_hw_symbol(lane) + 64 * (hh + h) < K;
 				const float yy = act ? y[h] : 0.0f;
-				const float yprev = sd_wave_shr1(yy, 0.0f);
+				const float yprev = sd_hw_prev(yy, lane);
 				float e = (yprev - yy) * (m[h] - bias);
 				e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
 				Ei += (act && lane != 0) ? __float2int_rn(e) : 0;           // the first symbol of a 64-group carries no term
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 				const int Y = __float2int_rn(sd_clamp(yy, -8.0f, 8.0f) * 4096.0f);
 				S1i += bit ? Y : 0;
 				S0i += (act && !bit) ? Y : 0;
-				const unsigned long long bal = __ballot(bit);
+				const unsigned long long bal = __ballot(sd_hw_unpermute(bit ? 1 : 0, lane) != 0);      // bits in symbol order
 				C1 += __popcll(bal);
 				if (lane == 0) { w.chunk[1 + 2 * (hh + h)] = (uint32_t)bal; w.chunk[2 + 2 * (hh + h)] = (uint32_t)(bal >> 32); }
 			}

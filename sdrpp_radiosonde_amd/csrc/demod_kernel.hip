@@ -452,9 +452,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	constexpr int SPL = SD_ROUND_SPL(DEC, NT);
 	auto round_front = [&](int K, int b, int par) {
 		int Ei = 0, S1i = 0, S0i = 0, C1 = 0;
+		constexpr bool HW = NT == 8;             // the half-wave symbol mapping (sd_wave.h): 2.5 samples per symbol
 #pragma unroll
 		for (int h = 0; h < SPL; h++) {
-			const int k = t + SD_WG * h;
+			const int k = (HW ? 64 * rwave + sd_hw_symbol(lane) : t) + SD_WG * h;
 			const bool act = k < K;
 			float y = 0.0f, m = 0.0f;
 			if (act) {
@@ -466,16 +467,16 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				if (h == 0) m = interp<NT>(s.A[b], s.taps, rel - ((uint32_t)period >> 1));
 			}
 			if (h == 0) {
-				const float yprev = sd_wave_shr1(y, 0.0f);            // (lane 0's term is not used)
+				const float yprev = HW ? sd_hw_prev(y, lane) : sd_wave_shr1(y, 0.0f);            // (the 64-group's first symbol's term is not used)
 				float e = (yprev - y) * (m - bias);
 				e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
-				Ei += (act && lane != 0) ? __float2int_rn(e) : 0;    // first symbol of a 64-group: no term (SPEC 3.2)
+				Ei += (act && lane != 0) ? __float2int_rn(e) : 0;    // first symbol of a 64-group (lane 0 in either mapping): no term (SPEC 3.2)
 			}
 			const bool bit = act && (y > bias);
 			const int Y = __float2int_rn(sd_clamp(y, -8.0f, 8.0f) * 4096.0f);
 			S1i += bit ? Y : 0;
 			S0i += (act && !bit) ? Y : 0;
-			const unsigned long long bal = __ballot(bit);
+			const unsigned long long bal = HW ? __ballot(sd_hw_unpermute(bit ? 1 : 0, lane) != 0) : __ballot(bit);      // bits in symbol order
 			C1 += __popcll(bal);
 			if (lane == 0) {
 				s.chunk[par][1 + 2 * rwave + 8 * h] = (uint32_t)bal;

@@ -35,6 +35,30 @@ __device__ __forceinline__ float sd_wave_shr1(float v, float first)
 	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
 }
 
+// THE HALF-WAVE SYMBOL MAPPING (round 5) of the classes at 2.5 samples per symbol (8-tap rows).  Lanes <-> consecutive symbols put
+// consecutive lanes 2.5 dwords apart in the tile: of a ds_read_b32's 32 lanes, lanes 13 apart meet on a bank (32.5 dwords), the two tap
+// rows in use (phases 0 and 1/2) lie 576 dwords apart = on the same banks: 23 % (RS41 class) to 38 % (M10 class) of the LDS pipe's
+// cycles were bank conflicts (profiles/r3_class_counters.csv).  Instead lanes 0-31 take the EVEN symbols of the wave's 64 and lanes
+// 32-63 the odd ones: within each half (the unit a ds_read_b32 is served in) the addresses are 5 dwords apart -- co-prime with the 32
+// banks -- and share one tap row.  Nothing arithmetic changes: the Gardner term of symbol k still takes y[k - 1] (now from the other
+// half-wave: a DPP shift and v_permlane32_swap, no LDS), the integer sums do not care, and the bits are put back in symbol order
+// before the ballot (one ds_bpermute_b32).
+__device__ __forceinline__ int sd_hw_symbol(int lane) { return 2 * (lane & 31) + (lane >> 5); }      // the symbol (of the wave's 64) a lane owns
+// y of the symbol before this lane's: lane l < 32 (symbol 2l) <- lane 32 + l - 1 (symbol 2l - 1; l = 0: not used), lane l >= 32 <- lane l - 32
+__device__ __forceinline__ float sd_hw_prev(float y, int lane)
+{
+	const int sh = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x138, 0xF, 0xF, false);      // sh[l] = y[l - 1]
+	const auto r = __builtin_amdgcn_permlane32_swap((unsigned)sh, __builtin_bit_cast(unsigned, y), false, false);
+	// v_permlane32_swap exchanges the first operand's lanes 32-63 with the second's lanes 0-31 (tools/ubench/permlane_probe.hip):
+	// r[0] = (sh[0..31], y[0..31]), r[1] = (sh[32..63], y[32..63])
+	return __builtin_bit_cast(float, lane < 32 ? r[1] : r[0]);
+}
+// a per-lane flag (0 / 1) from the half-wave mapping back into symbol order: lane p receives the flag of the lane that owns symbol p
+__device__ __forceinline__ int sd_hw_unpermute(int flag, int lane)
+{
+	return __builtin_amdgcn_ds_bpermute(4 * ((lane >> 1) + 32 * (lane & 1)), flag);
+}
+
 // y(pos) = (sum_{j even} H[p][j] d[n+16-j]) + (sum_{j odd} H[p][j] d[n+16-j]), each an fmaf chain with j
 // ascending (SPEC 3.2): one v_pk_fma_f32 per tap pair.  The tap rows are stored pair-swapped
 // (T[2i] = H[2i+1], T[2i+1] = H[2i]) so that they line up with the (d[x], d[x+1]) pairs.
