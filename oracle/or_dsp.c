@@ -418,16 +418,27 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 	for (size_t off = 0; off + OR_TILE <= n; off += OR_TILE) {
 		if (is_iq == 1) {
 			const float *x = src + 2 * off;
+			/* SPEC 3.0d (round 5), the carrier-following boxcar: with the carrier f off, consecutive input samples turn by
+			 * w = 2 pi f / 48000, and a plain sum of 4 (2) of them sees the far half of the signal's band through the boxcar's
+			 * droop (-3.6 dB at 5.8 kHz): RS41 at Eb/N0 10 dB and +-1 kHz lost 6 % of the frames a conventional receiver decodes
+			 * (profiles/r4_yardstick.md).  The second half of every group is turned back before it is added,
+			 *   4:1  z = (x0 + x1) + R (x2 + x3),   2:1  z = x0 + R x1,   R = (1 - u^2 / 2, -u),
+			 * u the AFC state of the tile (SPEC 3.0b: 2 atan u per decimated sample, so atan u ~ u is the turn of half a group
+			 * in either class); R's length does not matter.  R p = (fmaf(-p.im, R.im, p.re R.re), fmaf(p.re, R.im, p.im R.re)). */
+			const float u0 = d->afc[0], rr = fmaf(-0.5f * u0, u0, 1.0f), ri = -u0;
 			if (dec == 4) {
 				for (int m = 0; m < it; m++) {
-					z[2 * m] = (x[8 * m] + x[8 * m + 2]) + (x[8 * m + 4] + x[8 * m + 6]);
-					z[2 * m + 1] = (x[8 * m + 1] + x[8 * m + 3]) + (x[8 * m + 5] + x[8 * m + 7]);
+					const float p0r = x[8 * m] + x[8 * m + 2], p0i = x[8 * m + 1] + x[8 * m + 3];
+					const float p1r = x[8 * m + 4] + x[8 * m + 6], p1i = x[8 * m + 5] + x[8 * m + 7];
+					z[2 * m] = p0r + fmaf(-p1i, ri, p1r * rr);
+					z[2 * m + 1] = p0i + fmaf(p1r, ri, p1i * rr);
 				}
 				discriminate_rot(z, (size_t)it, tile, d->iq_last, d->afc[0]);
 			} else if (dec == 2) {
 				for (int m = 0; m < it; m++) {
-					z[2 * m] = x[4 * m] + x[4 * m + 2];
-					z[2 * m + 1] = x[4 * m + 1] + x[4 * m + 3];
+					const float p1r = x[4 * m + 2], p1i = x[4 * m + 3];
+					z[2 * m] = x[4 * m] + fmaf(-p1i, ri, p1r * rr);
+					z[2 * m + 1] = x[4 * m + 1] + fmaf(p1r, ri, p1i * rr);
 				}
 				discriminate_rot(z, (size_t)it, tile, d->iq_last, d->afc[0]);
 			} else {

@@ -36,39 +36,39 @@ static __device__ __forceinline__ float4 sd_cs8_f4(uint32_t q)
 {
 	return make_float4((float)(int8_t)(q & 0xffu), (float)(int8_t)((q >> 8) & 0xffu), (float)(int8_t)((q >> 16) & 0xffu), (float)((int32_t)q >> 24));
 }
-// SD_IN_IQ8, 4:1 class: one 8-byte load = four complex samples = one decimated sample: v_dot4c_i32_i8 against (1, 0, 1, 0) / (0, 1, 0, 1)
-static __device__ __forceinline__ float2 sd_cs8_sum4(uint2 q)
-{
-	int i = 0, j = 0;
-	i = __builtin_amdgcn_sdot4((int)q.x, 0x00010001, i, false); j = __builtin_amdgcn_sdot4((int)q.x, 0x01000100, j, false);
-	i = __builtin_amdgcn_sdot4((int)q.y, 0x00010001, i, false); j = __builtin_amdgcn_sdot4((int)q.y, 0x01000100, j, false);
-	return make_float2((float)i, (float)j);
-}
-static __device__ __forceinline__ float2 sd_cs8_sum4_uniform(uint2 q)      // (wave-uniform operands: scalar unit, as sd_cs16_sum4_uniform)
-{
-	const int i = (int)(int8_t)(q.x & 0xffu) + (int)(int8_t)((q.x >> 16) & 0xffu) + (int)(int8_t)(q.y & 0xffu) + (int)(int8_t)((q.y >> 16) & 0xffu);
-	const int j = (int)(int8_t)((q.x >> 8) & 0xffu) + ((int32_t)q.x >> 24) + (int)(int8_t)((q.y >> 8) & 0xffu) + ((int32_t)q.y >> 24);
-	return make_float2((float)i, (float)j);
-}
-// SD_IN_IQ16, 4:1 class: one 16-byte load = four complex samples = ONE decimated sample: I and Q sums in integers (exact, as the
-// float sums of the float path are: |sum| < 2^17), v_dot2c_i32_i16 against (1, 0) / (0, 1) extracts and adds in one instruction
-static __device__ __forceinline__ float2 sd_cs16_sum4(uint4 q)
+// SPEC 3.0d: the two half-sums of a group of four, (samples 0 + 1, samples 2 + 3), each exact in integers: (P0.re, P0.im, P1.re, P1.im)
+static __device__ __forceinline__ float4 sd_cs16_halves(uint4 q)
 {
 	const sd_i16x2 lo = {1, 0}, hi = {0, 1};
-	int i = 0, j = 0;
-	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.x), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.x), hi, j, false);
-	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.y), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.y), hi, j, false);
-	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.z), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.z), hi, j, false);
-	i = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.w), lo, i, false); j = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.w), hi, j, false);
-	return make_float2((float)i, (float)j);
+	int a = 0, b = 0, c = 0, d = 0;
+	a = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.x), lo, a, false); b = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.x), hi, b, false);
+	a = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.y), lo, a, false); b = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.y), hi, b, false);
+	c = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.z), lo, c, false); d = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.z), hi, d, false);
+	c = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.w), lo, c, false); d = __builtin_amdgcn_sdot2(__builtin_bit_cast(sd_i16x2, q.w), hi, d, false);
+	return make_float4((float)a, (float)b, (float)c, (float)d);
 }
-// the same sums in plain integer arithmetic: for WAVE-UNIFORM operands (the scalar-loaded samples in front of a wave's first one) the
-// compiler keeps this on the scalar unit; v_dot2c has no scalar form and would spend eight vector instructions per tile on one value
-static __device__ __forceinline__ float2 sd_cs16_sum4_uniform(uint4 q)
+static __device__ __forceinline__ float4 sd_cs8_halves(uint2 q)
 {
-	const int i = (int)(int16_t)(q.x & 0xffffu) + (int)(int16_t)(q.y & 0xffffu) + (int)(int16_t)(q.z & 0xffffu) + (int)(int16_t)(q.w & 0xffffu);
-	const int j = ((int32_t)q.x >> 16) + ((int32_t)q.y >> 16) + ((int32_t)q.z >> 16) + ((int32_t)q.w >> 16);
-	return make_float2((float)i, (float)j);
+	int a = 0, b = 0, c = 0, d = 0;
+	a = __builtin_amdgcn_sdot4((int)q.x, 0x00010001, a, false); b = __builtin_amdgcn_sdot4((int)q.x, 0x01000100, b, false);
+	c = __builtin_amdgcn_sdot4((int)q.y, 0x00010001, c, false); d = __builtin_amdgcn_sdot4((int)q.y, 0x01000100, d, false);
+	return make_float4((float)a, (float)b, (float)c, (float)d);
+}
+static __device__ __forceinline__ float4 sd_cs16_halves_uniform(uint4 q)
+{
+	return make_float4((float)((int)(int16_t)(q.x & 0xffffu) + (int)(int16_t)(q.y & 0xffffu)), (float)(((int32_t)q.x >> 16) + ((int32_t)q.y >> 16)),
+	                   (float)((int)(int16_t)(q.z & 0xffffu) + (int)(int16_t)(q.w & 0xffffu)), (float)(((int32_t)q.z >> 16) + ((int32_t)q.w >> 16)));
+}
+static __device__ __forceinline__ float4 sd_cs8_halves_uniform(uint2 q)
+{
+	return make_float4((float)((int)(int8_t)(q.x & 0xffu) + (int)(int8_t)((q.x >> 16) & 0xffu)), (float)((int)(int8_t)((q.x >> 8) & 0xffu) + ((int32_t)q.x >> 24)),
+	                   (float)((int)(int8_t)(q.y & 0xffu) + (int)(int8_t)((q.y >> 16) & 0xffu)), (float)((int)(int8_t)((q.y >> 8) & 0xffu) + ((int32_t)q.y >> 24)));
+}
+// SPEC 3.0d, the carrier-following boxcar: z = P0 + R P1, R = (rr, ri) = (1 - u^2 / 2, -u): the second half of a group turned back by
+// about atan u before it is added (oracle or_demod_feed)
+static __device__ __forceinline__ float2 sd_follow(float p0r, float p0i, float p1r, float p1i, float rr, float ri)
+{
+	return make_float2(p0r + __builtin_fmaf(-p1i, ri, p1r * rr), p0i + __builtin_fmaf(p1r, ri, p1i * rr));
 }
 // SD_IN_IQ16: two complex samples of 16-bit integers (I0 Q0 I1 Q1, little endian) -> the float4 the float path would have loaded
 // (int16 -> float is exact; no scaling: the discriminator's output does not depend on the amplitude)
@@ -327,8 +327,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				pv = src[f4 - 1];
 				if (dec4) pw = src[f4 - 2];
 			} else {
-				pv = (dec2 || dec4) ? make_float4(st.iq_last[0], st.iq_last[1], -0.0f, -0.0f) : make_float4(0.0f, 0.0f, st.iq_last[0], st.iq_last[1]);
-				pw = nz;
+				// (the carried sample is a finished z: it stands for the first half P0, the half behind it, which SPEC 3.0d turns, is empty)
+				pv = dec4 ? nz : (dec2 ? make_float4(st.iq_last[0], st.iq_last[1], -0.0f, -0.0f) : make_float4(0.0f, 0.0f, st.iq_last[0], st.iq_last[1]));
+				pw = dec4 ? make_float4(st.iq_last[0], st.iq_last[1], -0.0f, -0.0f) : nz;
 			}
 		}
 	};
@@ -343,16 +344,23 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	auto k1_tile = [&](int b, int tile, const LoadT (&vraw)[NLD], const LoadT &pvraw, const LoadT &pwraw) {
 		const float afc_u = IS_IQ ? afc_of(tile) : 0.0f;
 		const float rc = __builtin_fmaf(-afc_u, afc_u, 1.0f), rs = afc_u + afc_u;
+		// SPEC 3.0d: the boxcar's second half is turned back by R = (1 - u^2 / 2, -u) of its OWN tile; the sample in front of the tile's
+		// first wave belongs to the tile before
+		const float fr = __builtin_fmaf(-0.5f * afc_u, afc_u, 1.0f), fi_ = -afc_u;
+		const float pu = (IS_IQ && kw == 0 && tile > 0) ? afc_of(tile - 1) : afc_u;
+		const float pfr = __builtin_fmaf(-0.5f * pu, pu, 1.0f), pfi = -pu;
 		if constexpr (IQ16D4) {
 			// 16-bit input, 4:1: load g of lane l IS decimated sample 128 kw + 64 g + l (no exchange between lanes as in the float path)
-			float2 c;
-			if constexpr (IQ8) c = sd_cs8_sum4_uniform(pvraw); else c = sd_cs16_sum4_uniform(pvraw);
+			float4 ch;
+			if constexpr (IQ8) ch = sd_cs8_halves_uniform(pvraw); else ch = sd_cs16_halves_uniform(pvraw);
+			const float2 c = sd_follow(ch.x, ch.y, ch.z, ch.w, pfr, pfi);
 			float cx = c.x, cy = c.y;
 			if (tile == 0 && kw == 0) { cx = st.iq_last[0]; cy = st.iq_last[1]; }       // the carried (decimated) sample
 #pragma unroll
 			for (int g = 0; g < NLD; g++) {
-				float2 z;
-				if constexpr (IQ8) z = sd_cs8_sum4(vraw[g]); else z = sd_cs16_sum4(vraw[g]);
+				float4 hh;
+				if constexpr (IQ8) hh = sd_cs8_halves(vraw[g]); else hh = sd_cs16_halves(vraw[g]);
+				const float2 z = sd_follow(hh.x, hh.y, hh.z, hh.w, fr, fi_);
 				const float px = sd_wave_shr1(z.x, cx), py = sd_wave_shr1(z.y, cy);
 				store_one(s, b, (uint32_t)(128 * kw + 64 * g + lane), sd_disc_rot(z.x, z.y, px, py, rc, rs));
 				cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z.x), 63));
@@ -377,8 +385,11 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			pv = pvraw; pw = pwraw;
 		}
 		// lane 0's predecessor (decimated) sample; after each load: lane 63's last sample
-		float cx = dec4 ? (pw.x + pw.z) + (pv.x + pv.z) : (dec2 ? pv.x + pv.z : pv.z);
-		float cy = dec4 ? (pw.y + pw.w) + (pv.y + pv.w) : (dec2 ? pv.y + pv.w : pv.w);
+		float cx = pv.z, cy = pv.w;
+		if (IS_IQ && (dec4 || dec2)) {
+			const float2 c = dec4 ? sd_follow(pw.x + pw.z, pw.y + pw.w, pv.x + pv.z, pv.y + pv.w, pfr, pfi) : sd_follow(pv.x, pv.y, pv.z, pv.w, pfr, pfi);
+			cx = c.x; cy = c.y;
+		}
 		if (IQ16 && tile == 0 && kw == 0) { cx = st.iq_last[0]; cy = st.iq_last[1]; }       // the carried (decimated) sample
 		if (IS_IQ && dec4) {
 			// 4:1: a decimated sample spans two adjacent float4s, which the coalesced loads put into adjacent LANES.
@@ -395,7 +406,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				const float4 q = *reinterpret_cast<const float4 *>(&scr[2 * lane]);
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 				__builtin_amdgcn_wave_barrier();
-				const float zx = q.x + q.z, zy = q.y + q.w;
+				const float2 z = sd_follow(q.x, q.y, q.z, q.w, fr, fi_);
+				const float zx = z.x, zy = z.y;
 				// (lane l takes lane l - 1's sample, lane 0 the carry: one DPP move each; __shfl_up is a ds_bpermute on the LDS pipe)
 				const float px = sd_wave_shr1(zx, cx), py = sd_wave_shr1(zy, cy);
 				store_one(s, b, (uint32_t)(128 * kw + 64 * g + lane), sd_disc_rot(zx, zy, px, py, rc, rs));
@@ -411,7 +423,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			if (IS_IQ) {
 				if (dec2) {
 					// one float4 = two input samples = one decimated sample z, index fi
-					const float zx = v[r].x + v[r].z, zy = v[r].y + v[r].w;
+					const float2 z = sd_follow(v[r].x, v[r].y, v[r].z, v[r].w, fr, fi_);
+					const float zx = z.x, zy = z.y;
 					const float px = sd_wave_shr1(zx, cx), py = sd_wave_shr1(zy, cy);
 					store_one(s, b, fi, sd_disc_rot(zx, zy, px, py, rc, rs));
 					cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zx), 63));
