@@ -224,7 +224,8 @@ int      sonde_batch_read_bits(SondeBatch *b, uint32_t channel, uint64_t from, s
 int      sonde_batch_test_rs255(SondeBatch *b, uint8_t *cw_pairs, size_t n_pairs, int n, int32_t *status);
 uint64_t sonde_batch_nbits(SondeBatch *b, uint32_t channel);
 int      sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp,
-                                float *yprev /* reserved, reads 0 */);
+                                float *afc_u /* the newest AFC state u of SPEC 3.0b (the carrier offset the channel is following: 2 atan u per
+                                                decimated sample); 0 for real input.  (The parameter was called yprev, reserved, in rounds 1-3.) */);
 int      sonde_get_taps(int type, float *out /* 32*32 floats, [phase][tap] */);
 int      sonde_get_afsk_table(float *out /* 480*2 floats: the iMet tone demodulator's mixer table (cos, -sin) */);
 

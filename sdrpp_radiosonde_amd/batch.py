@@ -168,7 +168,8 @@ class SondeBatch:
         t, p = C.c_int64(), C.c_int32()
         b, a, y = C.c_float(), C.c_float(), C.c_float()
         self._chk(self.L.sonde_batch_read_state(self.h, channel, C.byref(t), C.byref(p), C.byref(b), C.byref(a), C.byref(y)))
-        return dict(t_next=t.value, period=p.value, bias=b.value, amp=a.value, yprev=y.value)
+        # afc_u: the newest AFC state (SPEC 3.0b); `yprev` is the key's name of rounds 1-3 (the same value), kept for the oracle binding's sake
+        return dict(t_next=t.value, period=p.value, bias=b.value, amp=a.value, afc_u=y.value, yprev=y.value)
 
 
 def row_stride(n_samples: int, iq: bool = True, kind: int | None = None) -> int:

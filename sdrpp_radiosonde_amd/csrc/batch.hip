@@ -972,7 +972,7 @@ extern "C" int sonde_batch_read_bits(SondeBatch *b, uint32_t channel, uint64_t f
 	return 0;
 }
 
-extern "C" int sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp, float *yprev)
+extern "C" int sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *t_next, int32_t *period, float *bias, float *amp, float *afc_u)
 {
 	if (!b || channel >= b->n_channels) return fail("sonde_batch_read_state: bad argument");
 	if (sonde_batch_sync(b) < 0) return -1;
@@ -982,7 +982,7 @@ extern "C" int sonde_batch_read_state(SondeBatch *b, uint32_t channel, int64_t *
 	if (period) *period = st.period;
 	if (bias) *bias = st.bias;
 	if (amp) *amp = st.amp;
-	if (yprev) *yprev = st.afc[2];          // (round 4: the newest AFC state u, SPEC 3.0b; 0 for real input)
+	if (afc_u) *afc_u = st.afc[2];          // the newest AFC state u (SPEC 3.0b); 0 for real input
 	return 0;
 }
 

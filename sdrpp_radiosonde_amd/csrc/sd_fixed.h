@@ -65,7 +65,7 @@ __device__ __forceinline__ bool sync_match(uint32_t w0, uint32_t w1, uint32_t w2
 
 // K4 for one fixed-length sonde type: the state machine of sd_sync_fixed_kernel (framer2_kernel.hip), advanced over
 // the bits [.., wp) with one candidate position per lane; `mirror` as in sd_rs41_sync_step.
-template <int T, bool REG = false>      // REG: as sd_rs41_sync_step
+template <int T, bool REG = false, int NCHUNK = (REG ? 4 : 1)>      // REG, NCHUNK: as sd_rs41_sync_step
 __device__ __forceinline__ void sd_fixed_sync_step(SdSyncRun &lds_state, uint64_t wp, const uint32_t *mirror, int lane,
 	SdFrameDesc *__restrict__ descs_ch, uint32_t max_frames, SdFrameDesc *list = nullptr)
 {
@@ -81,7 +81,7 @@ __device__ __forceinline__ void sd_fixed_sync_step(SdSyncRun &lds_state, uint64_
 		if (!fs.collecting) {
 			bool found = false;
 			while (fs.rpos + Tr::WIN <= wp) {
-				constexpr int NCH = REG ? 4 : 1;          // chunks of 64 candidate positions per trip (as sd_rs41_sync_step)
+				constexpr int NCH = NCHUNK;               // chunks of 64 candidate positions per trip (as sd_rs41_sync_step)
 				unsigned long long hm[NCH];
 				int invv[NCH];
 #pragma unroll

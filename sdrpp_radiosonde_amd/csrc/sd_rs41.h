@@ -44,7 +44,7 @@ __device__ __forceinline__ uint64_t sd_uniform64(unsigned long long v)    // a v
 // all control flow wave-uniform.
 // REG: `lds_state` is a register-resident copy owned by the calling wave alone (bins_kernel.hip: one wave per channel), its list of
 // the first frames lives at `list` (LDS); else the state sits in LDS between steps (kernel A) and list = lds_state.list.
-template <bool REG = false>
+template <bool REG = false, int NCHUNK = (REG ? 4 : 1)>
 __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t wp, const uint32_t *mirror, int lane,
 	SdFrameDesc *__restrict__ descs_ch, uint32_t max_frames, SdFrameDesc *list = nullptr)
 {
@@ -63,7 +63,7 @@ __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t
 			while (fs.rpos + 64 <= wp) {
 				// NCH chunks of 64 candidate positions per trip (REG: a wave that sees a whole tile's bits at once: one LDS round trip
 				// instead of four); positions are still tried in ascending order: the earliest hit of the earliest chunk wins
-				constexpr int NCH = REG ? 4 : 1;
+				constexpr int NCH = NCHUNK;
 				unsigned long long hm[NCH];
 				int hdv[NCH];
 #pragma unroll

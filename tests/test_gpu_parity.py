@@ -449,3 +449,27 @@ def test_rows_on_the_recommended_stride_and_host_staging(oracle):
     assert len(outs[0][0]) > 0 and outs[0] == outs[1] == outs[2]
     ref = np.concatenate([ch.frames() for ch in _oracle_channels(oracle, sb.iq.numpy())])
     assert np.frombuffer(outs[0][0], dtype=ref.dtype).tobytes() == ref.tobytes()
+
+
+def test_host_staging_with_fewer_samples_than_max(oracle):
+    """sonde_batch_submit_host sizes its staging buffer from sonde_row_stride(max_samples) and writes at
+    sonde_row_stride(n_samples); with the round-4 rule rows of 80 KiB (n = 10240) got a LARGER stride (192 KiB) than rows of 96-128 KiB
+    (128 KiB) and ran past the allocation.  A batch created for 6 tiles is fed 5-tile and 6-tile submits through the host path,
+    several channels: frames and bits equal the oracle's over the whole signal."""
+    from sdrpp_radiosonde_amd.batch import row_stride
+    assert row_stride(10240) <= row_stride(12288)
+    C = 6
+    plan = [5, 6, 5, 6, 6, 5, 6, 5, 6, 6]                    # tiles per submit
+    n = TILE * sum(plan)
+    sb = synth.make_rs41_batch(C, n, seed=81, ebn0_db=16.0)
+    b = SondeBatch(C, TILE * 6)
+    parts, off = [], 0
+    for t in plan:
+        b.submit_host(np.ascontiguousarray(sb.iq.numpy()[:, off: off + TILE * t]))
+        parts.append(b.frames())
+        off += TILE * t
+    got = np.concatenate(parts)
+    ref = np.concatenate([ch.frames() for ch in _oracle_channels(oracle, sb.iq.numpy())])
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    assert len(ref) >= C and key(got).tobytes() == key(ref).tobytes()
+    b.close()
