@@ -49,6 +49,9 @@
 #define P_NSTG 2
 #endif                                                 // staging rounds (halves of the prototype's taps).  Quarters (48.5 KB: three workgroups per
                                                        // CU) need <= 85 VGPRs and spill 224 B per lane; the halves take 112 and none (r4_notes.md)
+#ifndef P_DMA_ALL
+#define P_DMA_ALL 0
+#endif
 #ifndef P_WGCU
 #define P_WGCU (P_NSTG == 2 ? 2 : 3)                   // workgroups per CU the staging form aims at
 #endif
@@ -203,12 +206,12 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
 			}
 		}
 	};
-	PT tb[NQ];
-	// Round 0 (taps 0-7): complex64 input goes global -> LDS directly (global_load_lds_dwordx4: a wave moves 64 x 16 bytes to
-	// consecutive LDS addresses; no staging registers, no ds_write pass -- the window stores were a fifth of the kernel's LDS time);
-	// integer input is converted on the way and keeps the register path.
-	if constexpr (IK == 0) {
-		const long base = p0;
+	// complex64 input goes global -> LDS directly (global_load_lds_dwordx4: a wave moves 64 x 16 bytes to consecutive LDS addresses; no
+	// staging registers, no ds_write pass -- the window stores were a fifth of the kernel's LDS time); integer input is converted on
+	// the way and keeps the register path.  P_DMA_ALL: every round that way (no staging registers at all: the form that fits three
+	// workgroups per CU); else round 0 only, the later rounds through registers that are loaded while the round before is folded.
+	auto dma_round = [&](int c) {
+		const long base = p0 + (long)c * P_TC * CH_M;
 #pragma unroll
 		for (int q = 0; q < NQ; q++) {
 			const int piece = wave + 8 * q;                          // 1 KB piece of the window (wave-uniform)
@@ -221,6 +224,11 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
 				                                 (__attribute__((address_space(3))) void *)(s_x + 128 * piece), 16, 0, 0);
 			}
 		}
+	};
+	constexpr bool DMA_ALL = IK == 0 && P_DMA_ALL;
+	PT tb[DMA_ALL ? 1 : NQ];
+	if constexpr (IK == 0) {
+		dma_round(0);
 	} else {
 		PT ta[NQ];
 		load_round(0, ta);
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
 		PT *ho = reinterpret_cast<PT *>(hist_out_all + (size_t)phys * CH_H);
 		for (int i = tid; i < CH_H / 2; i += P_NT) ho[i] = tail[i];
 	}
-	load_round(1, tb);                                         // in flight while the first half is folded
+	if constexpr (!DMA_ALL) load_round(1, tb);                 // in flight while the first part is folded
 	__syncthreads();
 	// 2. fold (SPEC 3.5: v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc), t ascending)
 	float2 v[P_S];
@@ -262,9 +270,14 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
 		fold_round(c);
 		__syncthreads();                   // this part of the window is consumed (the last one: the window is dead from here on)
 		if (c + 1 < P_NSTG) {
-			store_round(tb);
-			if (c + 2 < P_NSTG) load_round(c + 2, tb);
-			else { w64 = tw[64]; w128 = tw[128]; w192 = tw[192]; twr = pfb_load_tw(tw, lane); }
+			if constexpr (DMA_ALL) {
+				dma_round(c + 1);
+				if (c + 2 == P_NSTG) { w64 = tw[64]; w128 = tw[128]; w192 = tw[192]; twr = pfb_load_tw(tw, lane); }
+			} else {
+				store_round(tb);
+				if (c + 2 < P_NSTG) load_round(c + 2, tb);
+				else { w64 = tw[64]; w128 = tw[128]; w192 = tw[192]; twr = pfb_load_tw(tw, lane); }
+			}
 			__syncthreads();
 		}
 	}
