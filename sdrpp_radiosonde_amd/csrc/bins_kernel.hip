@@ -96,7 +96,10 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 	// the channel's state and K4's state come through VECTOR loads (a dword per lane, fields by v_readlane): 4096 waves asking the
 	// scalar data cache for 64 private bytes each at the same moment waited 5 800 cycles for them (tools/bk_ts.py); a vector load 500
 	const uint32_t sv = lane < 16 ? reinterpret_cast<const uint32_t *>(states + ch)[lane] : (lane < 24 ? reinterpret_cast<const uint32_t *>(P.fo.fstates + ch)[lane - 16] : 0u);
-	const float hv = hist[(size_t)ch * SD_HIST + lane];
+	// (of the 64 carried samples the filters of a tile's first symbols reach back 13 at most -- t_next lies behind the previous tile's
+	// limit, 8 samples before its end, the 8-tap rows and the mid-symbol instant take 5 more: only the newest 16 travel, 1.5 MB less HBM
+	// traffic per 8-stream step)
+	const float hv = lane >= SD_HIST - 16 ? hist[(size_t)ch * SD_HIST + lane] : 0.0f;
 	auto svw = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)sv, i); };
 	auto sv64 = [&](int i) { return (uint64_t)svw(i) | ((uint64_t)svw(i + 1) << 32); };
 	SdChanState st;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 	}
 
 	// ---- epilogue: history, state, the carried phases, K4's state; RS41: the frames listed in this submit
-	hist[(size_t)ch * SD_HIST + lane] = w.A[lane];
+	if (lane >= SD_HIST - 16) hist[(size_t)ch * SD_HIST + lane] = w.A[lane];
 	if (lane < 8) {
 		const size_t n_ph = 2560 * (size_t)n_blocks;
 		reinterpret_cast<uint32_t *>(carry_rows + (size_t)ch * carry_stride)[lane] = row32[n_ph / 2 + lane];      // row elements [n_ph, n_ph + 16) = the last 16 phases
