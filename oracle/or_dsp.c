@@ -252,7 +252,7 @@ static void run_rounds(OrDemod *d)
 
 	while (K_total > 0) {
 		const int K = K_total > rmax ? rmax : (int)K_total;
-		int32_t E = 0, S1 = 0, S0 = 0, C1 = 0;
+		int32_t E = 0, S1 = 0, S0 = 0, C1 = 0, SY = 0, SM = 0;
 		K_total -= K;
 
 		for (int k = 0; k < K; k++) {
@@ -268,6 +268,10 @@ static void run_rounds(OrDemod *d)
 			 * 256 terms per 42.7 ms are plenty for a clock that drifts by ppm, and the second symbol of a lane then needs no
 			 * mid-symbol FIR at all (round 3: a quarter of the M10 class's FIR work) */
 			if ((k & 63) && k < OR_ROUND_MAX) {
+				if (d->m->pre == 8) {       /* SPEC 3.6b: how open the eye is at the on-time and at the mid-symbol instants */
+					SY += (int32_t)lrintf(clampf(fabsf(y[k] - d->bias), 0.0f, 8.0f) * 4096.0f);
+					SM += (int32_t)lrintf(clampf(fabsf(m[k] - d->bias), 0.0f, 8.0f) * 4096.0f);
+				}
 				const float a = y[k - 1] - y[k];
 				const float b = m[k] - d->bias;
 				float e = a * b;
@@ -307,6 +311,12 @@ static void run_rounds(OrDemod *d)
 		const int32_t dphase = (int32_t)lrintf(err * kp);
 		const int32_t dper = (int32_t)lrintf(err * ki);
 		d->t_next += (int64_t)K * d->period + dphase;
+		/* SPEC 3.6b (round 5), acquisition aid of the AFSK streams: a Gardner loop that starts half a symbol off sits on the detector's
+		 * unstable zero, and a loop that is closed three (iMet) or six (C50) times a second takes many seconds to drift off it (9 % of random
+		 * iMet channels decoded nothing in their first two seconds).  There the mid-symbol samples show the open eye and the on-time ones the
+		 * transitions: when the mid-symbol samples lie further from the threshold (by 17/16) than the on-time ones, the instants move by half
+		 * a symbol, once the slicer has seen both levels. */
+		if (d->m->pre == 8 && d->nstat && 16 * (int64_t)SM > 17 * (int64_t)SY) d->t_next += d->period >> 1;
 		d->period += dper;
 		const int32_t pmin = d->m->period0 - (d->m->period0 >> 8);
 		const int32_t pmax = d->m->period0 + (d->m->period0 >> 8);

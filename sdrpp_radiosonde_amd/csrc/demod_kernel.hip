@@ -94,6 +94,7 @@ struct DemodLds {
 	float X[2][SD_BUF];
 	float taps[SD_NPHASE * SD_TAPS_LD];     // rows padded to 36 floats: 16-byte aligned ds_read_b128
 	int4 red[2][4];                         // [round parity][wave]: (E, S1, S0, C1)
+	int2 red2[2][4];                        // AFSK streams (SPEC 3.6b): (SY, SM), the eye opening at the on-time / the mid-symbol instants
 	uint32_t chunk[2][18];                  // [round parity]: the round's bits, one ballot per wave (and half), zero-padded
 	uint32_t partial[2];                    // bits already in the ring word that wpos points into (ping-pong)
 	float iq_last[2];
@@ -206,6 +207,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	if (utype >= 0) stype = utype;
 	else stype = __builtin_amdgcn_readfirstlane(st.type);
 	const SdModem md = modems[stype];
+	constexpr bool AF = IN == SD_IN_REAL && DEC == 1;                  // the instantiation the 6 kS/s AFSK streams run through
+	const bool afsk = AF && (stype == SONDE_IMET4 || stype == SONDE_C50);
 	const int rounds = md.rounds;          // sub-phases (= barriers) per tile: 1, or 2 for the SRS-C50 6 kS/s stream
 	constexpr int IT = SD_TILE / DEC;      // internal samples per input tile (= md.itile)
 	constexpr bool dec2 = DEC == 2, dec4 = DEC == 4;
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// SPL symbols per lane: symbol k = 256 h + t of the round, h < SPL (the undecimated streams hold up to 410 / 822 symbols per tile)
 	constexpr int SPL = SD_ROUND_SPL(DEC, NT);
 	auto round_front = [&](int K, int b, int par) {
-		int Ei = 0, S1i = 0, S0i = 0, C1 = 0;
+		int Ei = 0, S1i = 0, S0i = 0, C1 = 0, SYi = 0, SMi = 0;
 		constexpr bool HW = NT == 8;             // the half-wave symbol mapping (sd_wave.h): 2.5 samples per symbol
 #pragma unroll
 		for (int h = 0; h < SPL; h++) {
@@ -484,6 +487,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				float e = (yprev - y) * (m - bias);
 				e = sd_clamp(e * 1024.0f, -1.0e6f, 1.0e6f);
 				Ei += (act && lane != 0) ? __float2int_rn(e) : 0;    // first symbol of a 64-group (lane 0 in either mapping): no term (SPEC 3.2)
+				if (AF) {                                            // SPEC 3.6b: same symbols as the detector's
+					SYi += (act && lane != 0) ? __float2int_rn(sd_clamp(fabsf(y - bias), 0.0f, 8.0f) * 4096.0f) : 0;
+					SMi += (act && lane != 0) ? __float2int_rn(sd_clamp(fabsf(m - bias), 0.0f, 8.0f) * 4096.0f) : 0;
+				}
 			}
 			const bool bit = act && (y > bias);
 			const int Y = __float2int_rn(sd_clamp(y, -8.0f, 8.0f) * 4096.0f);
@@ -500,6 +507,11 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		S1i = wave_sum(S1i);
 		S0i = wave_sum(S0i);
 		if (lane == 0) s.red[par][rwave] = make_int4(Ei, S1i, S0i, C1);
+		if (AF) {
+			SYi = wave_sum(SYi);
+			SMi = wave_sum(SMi);
+			if (lane == 0) s.red2[par][rwave] = make_int2(SYi, SMi);
+		}
 	};
 	// round wave 1, after the barrier: append the previous round's bits to the bit ring (HBM) and its LDS mirror, beside the lead wave's
 	// loop filter (round 4: it was the first quarter of the lead wave's chain) and tell K4 how far the mirror is valid
@@ -569,6 +581,13 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		const int dphase = __float2int_rn(err * md.kp);
 		const int dper = __float2int_rn(err * md.ki);
 		st.t_next += (int64_t)K * st.period + dphase;
+		if (AF && afsk && st.nstat) {
+			// SPEC 3.6b, acquisition aid of the AFSK streams: half a symbol off, the Gardner detector sits on its unstable zero and a loop
+			// closed 3-6 times a second takes seconds to leave it; there the mid-symbol samples show the open eye.  Jump half a symbol.
+			const int2 q0 = s.red2[par][0], q1 = s.red2[par][1], q2 = s.red2[par][2], q3 = s.red2[par][3];
+			const int64_t SY = (int64_t)q0.x + q1.x + q2.x + q3.x, SM = (int64_t)q0.y + q1.y + q2.y + q3.y;
+			if (16 * SM > 17 * SY) st.t_next += st.period >> 1;
+		}
 		st.period += dper;
 		if (st.period < md.pmin) st.period = md.pmin;
 		if (st.period > md.pmax) st.period = md.pmax;
