@@ -157,7 +157,7 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
                                                            uint32_t dual, const float *__restrict__ h_odd, const float2 *__restrict__ twist)
 {
 	__shared__ __attribute__((aligned(16))) float2 s_x[P_LDS];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	// Workgroups go to the 8 XCDs round robin (linear id mod 8; gridDim.x is a multiple of 8): XCD x takes the x-th eighth of the
 	// block's step groups, so that the workgroups resident on one XCD are neighbours in time and the overlap of their windows is
 	// served by that XCD's L2 (round 3: 8 streams 104 -> 97 us; one stream x one block loses: the host asks for it from two
@@ -184,6 +184,18 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
 		const long base = p0 + (long)c * P_TC * CH_M;           // even: a pair never straddles the block's first sample
 		const PT *src_iq = reinterpret_cast<const PT *>(iq);
 		const PT *src_h = reinterpret_cast<const PT *>(hist_in);
+		if (base >= 0) {                                        // (workgroup-uniform) all but the first two groups of a block: the window lies inside
+			const PT *src = src_iq + base / 2;                  // the block, one base address and constant offsets (round 5: the per-element select between
+#pragma unroll                                                  // history and block cost ~150 of the wave's 970 VALU instructions)
+			for (int q = 0; q < NQ; q++) {
+				const int i = tid + P_NT * q;
+				if (i < P_CHW / 2) tmp[q] = src[i];
+				else if constexpr (I8) tmp[q] = 0u;
+				else if constexpr (I16) tmp[q] = make_uint2(0u, 0u);
+				else tmp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+			return;
+		}
 #pragma unroll
 		for (int q = 0; q < NQ; q++) {
 			const int i = tid + P_NT * q;
@@ -212,6 +224,20 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
 	// workgroups per CU); else round 0 only, the later rounds through registers that are loaded while the round before is folded.
 	auto dma_round = [&](int c) {
 		const long base = p0 + (long)c * P_TC * CH_M;
+		if (base >= 0) {
+			const float4 *src0 = reinterpret_cast<const float4 *>(iq) + base / 2;
+#pragma unroll
+			for (int q = 0; q < NQ; q++) {
+				const int piece = wave + 8 * q;
+				if (64 * piece < P_CHW / 2) {
+					int i = 64 * piece + lane;
+					i = i < P_CHW / 2 ? i : P_CHW / 2 - 1;
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + i),
+					                                 (__attribute__((address_space(3))) void *)(s_x + 128 * piece), 16, 0, 0);
+				}
+			}
+			return;
+		}
 #pragma unroll
 		for (int q = 0; q < NQ; q++) {
 			const int piece = wave + 8 * q;                          // 1 KB piece of the window (wave-uniform)

@@ -194,7 +194,7 @@ class Channel:
         t, p = C.c_int64(), C.c_int32()
         b, a, y = C.c_float(), C.c_float(), C.c_float()
         self.L.or_demod_state(d, C.byref(t), C.byref(p), C.byref(b), C.byref(a), C.byref(y))
-        return dict(t_next=t.value, period=p.value, bias=b.value, amp=a.value, yprev=y.value)
+        return dict(t_next=t.value, period=p.value, bias=b.value, amp=a.value, afc_u=y.value, yprev=y.value)
 
     def __del__(self):
         try:
