@@ -305,6 +305,38 @@ def test_fused_channelizer_frames_equal_oracle(oracle, bps, streams):
 
 
 @pytest.mark.gpu
+def test_dense_scene_frames_equal_oracle(oracle):
+    """bench.py's other_configs.wideband8_dense scene (the sparse scene decodes 2 frames per step, the FEC stage is
+    idle): an RS41 transmitter in every other bin (256 of 512), built exactly as bench.py builds it (per-transmitter Eb/N0 raised with
+    their number, the sum scaled into 16 bits' range), one stream, the 1.024 s scene block by block.  Every bin's frames == the
+    oracle's (187 frames: a bin's 1.024 s hold one whole frame or none), none in the empty bins."""
+    import torch
+    from sdrpp_radiosonde_amd.batch import SondeChannelizer
+    bins_active = list(range(1, 512, 2))
+    nblk = 8
+    scene = synth.make_wideband_rs41(bins_active, nblk * BLOCK, seed=7, ebn0_db=30.0 + 10.0 * np.log10(len(bins_active) / 16.0), device="cuda:0")[0]
+    scene *= min(1.0, 4.0 / np.sqrt(len(bins_active)))
+    chz = SondeChannelizer(blocks_per_submit=1)
+    assert chz.fused
+    got = []
+    for b in range(nblk):
+        chz.submit(scene[b * BLOCK: (b + 1) * BLOCK].contiguous())
+        got.append(chz.frames())
+    got = np.concatenate(got)
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    dec, _ = _oracle_decode_wideband(oracle, scene.cpu().numpy(), bins_active, composite=True)
+    refs = []
+    for k in bins_active:
+        r = dec[k].frames().copy()
+        r["channel"] = k
+        refs.append(r)
+    ref = np.concatenate(refs)
+    assert key(got).tobytes() == key(ref).tobytes()
+    per_bin = np.bincount(ref["channel"], minlength=512)
+    assert len(ref) >= 150 and per_bin[0::2].sum() == 0, len(ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fused,bits", [(True, 16), (False, 16), (True, 8), (False, 8)])
 def test_channelizer_takes_16_bit_wideband_blocks(oracle, fused, bits):
     """sonde_chan_set_input(SONDE_INPUT_IQ16): the wideband block as int16 I, Q pairs (what a 10 MS/s receiver delivers).  Converted
