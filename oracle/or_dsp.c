@@ -97,6 +97,16 @@ void or_discriminate(const float *iq, size_t n, float *d, float *last)
 	last[1] = y0;
 }
 
+/* SPEC 3.0e: (4 / pi) atan(u), |u| <= OR_AFC_MAX = 0.8: odd polynomial, max error 2.3e-5 quadrant */
+static float afc_rot(float u)
+{
+	const float t = u * u;
+	float p = fmaf(t, -0.073257752f, 0.21412420f);
+	p = fmaf(t, p, -0.41814741f);
+	p = fmaf(t, p, 1.2729679f);
+	return u * p;
+}
+
 /* The same with the product x[n] conj(x[n-1]) turned back by the AFC phasor (c, s) = (1 - u^2, 2u) before the arctangent
  * (SPEC 3.0b): d[n] = arg(x[n] conj(x[n-1]) (c - j s)).  The phasor's length (1 + u^2) does not matter to an arctangent. */
 static void discriminate_rot(const float *iq, size_t n, float *d, float *last, float u)
@@ -481,6 +491,13 @@ void or_demod_feed(OrDemod *d, const float *src, size_t n, int is_iq)
 			u = fmaf(-OR_AFC_LEAK, u, u);
 			u = fmaf(OR_AFC_GAIN, d->bias, u);
 			u = clampf(u, -OR_AFC_MAX, OR_AFC_MAX);
+			/* SPEC 3.0e (round 5), the threshold follows the rotation: the next tile's discriminator turns the signal back by
+			 * rot(afc[1]) instead of rot(afc[0]) quadrants per sample, rot(u) = (4 / pi) atan(u) (the phasor (1 - u^2, 2u) of
+			 * discriminate_rot turns by 2 atan u) as an odd polynomial (afc_rot): its output drops by the difference, and so does
+			 * the slicer's threshold, now, instead of following through its smoothing a few tiles later (MRZ-N1 at -2 kHz and
+			 * Eb/N0 14 dB lost the first frame of 9 channels of 32 to that; profiles/r5_notes.md section 7).  The AFC's input stays
+			 * the threshold: what is left of the offset behind the rotation the next tile will see. */
+			d->bias -= afc_rot(d->afc[1]) - afc_rot(d->afc[0]);
 			d->afc[0] = d->afc[1];
 			d->afc[1] = d->afc[2];
 			d->afc[2] = u;

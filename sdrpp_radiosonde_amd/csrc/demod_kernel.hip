@@ -99,6 +99,7 @@ struct DemodLds {
 	uint32_t partial[2];                    // bits already in the ring word that wpos points into (ping-pong)
 	float iq_last[2];
 	float afc_u[4];                         // SPEC 3.0b: AFC state for the discriminator of tile T at [T & 3] (written by the lead wave three tiles earlier)
+	float afc_dq[4];                        // SPEC 3.0e: by how much tile T's rotation exceeds tile T - 1's, quadrants per sample: sd_afc_rot(u[T]) - sd_afc_rot(u[T - 1])
 	// what the lead round wave (wave 0) computes once per round and the other round waves pick up:
 	// the PI loop filter runs on one wave instead of four (it is ~35 % of a round wave's VALU work)
 	struct { long long t_next; int period; float bias; int K; unsigned flag; unsigned long long wpos; } pub;
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 					s.pub.flag = 0;
 					s.pub.wpos = st.wpos;
 					s.afc_u[0] = st.afc[0]; s.afc_u[1] = st.afc[1]; s.afc_u[2] = st.afc[2];
+					if (IS_IQ) { const float q1 = sd_afc_rot(st.afc[1]); s.afc_dq[1] = q1 - sd_afc_rot(st.afc[0]); s.afc_dq[2] = sd_afc_rot(st.afc[2]) - q1; }
 				}
 			}
 		} else {
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				s.pub.flag = 0;
 				s.pub.wpos = st.wpos;
 				s.afc_u[0] = st.afc[0]; s.afc_u[1] = st.afc[1]; s.afc_u[2] = st.afc[2];
+					if (IS_IQ) { const float q1 = sd_afc_rot(st.afc[1]); s.afc_dq[1] = q1 - sd_afc_rot(st.afc[0]); s.afc_dq[2] = sd_afc_rot(st.afc[2]) - q1; }
 			}
 		}
 	}
@@ -597,12 +600,20 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// AFC (SPEC 3.0b), lead wave, after the rounds of tile j: the slicer threshold is what is left of the carrier offset behind the
 	// rotation; a leaky integrator moves the state, which the discriminator of tile j + 3 will use
 	float afc_last = st.afc[2];
+	// SPEC 3.0e (round 5): the next tile's discriminator turns the signal back by rot(u[j + 1]) instead of rot(u[j]) quadrants per sample:
+	// the slicer threshold drops by the difference now, instead of following through its smoothing some tiles later.  The difference
+	// was formed when u[j + 1] was (two tiles ago): one LDS read and one subtraction on the lead wave's chain.
+	float afc_rq_last = IS_IQ ? sd_afc_rot(afc_last) : 0.0f;
 	auto afc_step = [&](int j) {
+		const float dq = s.afc_dq[(j + 1) & 3];
 		float u = __builtin_fmaf(-SD_AFC_LEAK, afc_last, afc_last);
 		u = __builtin_fmaf(SD_AFC_GAIN, st.bias, u);
 		u = sd_clamp(u, -SD_AFC_MAX, SD_AFC_MAX);
 		afc_last = u;
-		if (lane == 0) s.afc_u[(j + 3) & 3] = u;
+		st.bias -= dq;
+		const float rq = sd_afc_rot(u);
+		if (lane == 0) { s.afc_u[(j + 3) & 3] = u; s.afc_dq[(j + 3) & 3] = rq - afc_rq_last; }
+		afc_rq_last = rq;
 	};
 
 	// ---- the two roles run separate loops (so that neither carries the other's live registers) with the
