@@ -313,6 +313,14 @@ static void run_rounds(OrDemod *d)
 			 * threshold): no level estimate; move the threshold to the mean so that the next round sees both levels */
 			d->bias = ((float)(S1 + S0) * or_recip((float)K)) * (1.0f / 4096.0f);
 		}
+		/* SPEC 3.2b (round 5), acquisition: during the first three tiles of a stream the threshold is the MEAN of the round.  With the
+		 * carrier 2 kHz off, the first rounds slice most symbols to one side, the level estimate above is built from wrong decisions
+		 * and creeps towards the offset over several tiles (0.20, 0.25, 0.36 ... of 0.67 quadrants): every frame the SPEC missed and a
+		 * conventional receiver decoded at +-2 kHz lay in the first 700 chips (profiles/r5_notes.md section 7).  The sondes' line codes
+		 * are balanced (Manchester, biphase, whitened NRZ): the mean of a round IS the offset.  Amplitude and `nstat` as above; the
+		 * AFSK streams (threshold 0 by construction) keep the level estimate. */
+		if (d->m->pre == 1 && d->n0 <= 3 * (int64_t)(OR_TILE / d->m->decim))
+			d->bias = ((float)(S1 + S0) * or_recip((float)K)) * (1.0f / 4096.0f);
 		float err = ((float)E * or_recip((float)(K > OR_ROUND_MAX ? OR_ROUND_MAX : K))) * (1.0f / 1024.0f);   /* the symbols that fed the detector */
 		err = err * or_recip(d->amp * d->amp);
 		err = clampf(err, -1.0f, 1.0f);

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		} else {
 			st.bias = ((float)(S1 + S0) * sd_recip((float)K)) * (1.0f / 4096.0f);
 		}
+		if (n0 <= 3 * (int64_t)BK_IT) st.bias = ((float)(S1 + S0) * sd_recip((float)K)) * (1.0f / 4096.0f);      // SPEC 3.2b: acquisition, the mean of the round
 		const f32x2 den = {(float)K, st.amp * st.amp};
 		const f32x2 rd = sd_recip2(den);
 		float err = ((float)E * rd.x) * (1.0f / 1024.0f);

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (lane == 0) __hip_atomic_store(&s.pub.wpos, (unsigned long long)wpos_w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 	};
 	// lead wave, after the barrier: update slicer levels and the PI loop filter
-	auto round_back = [&](int K, int par) {
+	auto round_back = [&](int K, int par, int64_t n_done /* samples consumed up to and including that round's tile */) {
 		if (K <= 0) return;
 		const int4 r0 = s.red[par][0], r1 = s.red[par][1], r2 = s.red[par][2], r3 = s.red[par][3];
 		const int E = r0.x + r1.x + r2.x + r3.x;
@@ -576,6 +576,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			// mean of the round so that the next one sees both levels (SPEC 3.2)
 			st.bias = ((float)(S1 + S0) * sd_recip((float)K)) * (1.0f / 4096.0f);
 		}
+		// SPEC 3.2b (round 5), acquisition: during a stream's first three tiles the threshold is the mean of the round (the level estimate
+		// above is built from the slicer's own decisions: with the carrier 2 kHz off it needs several tiles to find the offset)
+		if (!afsk && n_done <= 3 * (int64_t)IT) st.bias = ((float)(S1 + S0) * sd_recip((float)K)) * (1.0f / 4096.0f);
 		const f32x2 den = {(float)(K > SD_ROUND_MAX ? SD_ROUND_MAX : K), st.amp * st.amp};      // the symbols that fed the detector
 		const f32x2 rd = sd_recip2(den);
 		float err = ((float)E * rd.x) * (1.0f / 1024.0f);
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				if (r == 0) n0 += IT;                                 // the tile in buffer b is now counted
 				if (lead) {
 					if (pendK >= 0) {
-						round_back(pendK, par ^ 1);                   // the previous round's update
+						round_back(pendK, par ^ 1, r == 0 ? n0 - IT : n0);      // the previous round's update (n0 already counts this round's tile)
 						if (IS_IQ) afc_step(tile - 1);                // (IQ classes run one round per tile)
 					}
 					if (r == 0) {
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		}
 		// ---- epilogue of the round role: the last round's update ...
 		if (lead && pendK >= 0) {
-			round_back(pendK, (int)((seq & 1u) ^ 1u));
+			round_back(pendK, (int)((seq & 1u) ^ 1u), n0);
 			if (IS_IQ) afc_step(n_tiles - 1);
 		}
 		if (rwave == 1 && pendK >= 0) ring_append(pendK, (int)((seq & 1u) ^ 1u));
