@@ -32,38 +32,47 @@
 #define PH_HEAD 16                  // phases of the previous block kept at the head of every bin's row (bins_kernel.hip)
 
 // ---- the filter bank: 8 output steps per 512-thread workgroup, blockIdx.y = wideband stream.
-//   1. the window of the 8 steps (8192 + 7*500 samples) is staged in LDS in TWO halves of the prototype's 16 taps (taps 0-7, then
-//      8-15: 4096 + 3500 + 512 samples = 60.8 KB each time, so that two workgroups share a CU and their phases overlap); the
-//      second half's global loads are in flight while the first half is folded;
-//   2. fold: thread = bin residue r, the 16 taps in registers, t ascending across both halves (SPEC 3.5:
-//      v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc));
-//   3. circular shift by (m*D mod 512) into the step's FFT buffer (aliasing the dead window), natural order;
+// Round 5, the commutator form.  Step m0 + q, bin residue r, tap t reads window sample 500 q + r + 512 t (window sample 0 = stream
+// position 500 m0 - CH_H).  Rounds 2-4 staged the window (11 692 samples, in two halves of 60.8 KB) in LDS and let thread = r read its
+// 16 x 8 operands back: 128 8-byte LDS reads per thread, every window sample read 5.6 times -- the LDS pipe was busy for 29 of the
+// kernel's 56 us (and without any global load the kernel still took 48 us: profiles/r5_notes.md).  But 500 = 512 - 12: a thread that owns
+// window COLUMN c (the samples c + 512 s, s = 0 .. 22) and, at step q, works for bin r = (c + 12 q) mod 512 needs
+//     500 q + r + 512 t  =  c + 512 (q + t)            [ - 512 where c + 12 q >= 512 ]
+// i.e. only ITS OWN 23 samples, each used for up to 8 (q, t) pairs: they come from global memory straight into registers, each
+// sample of the window once per workgroup, coalesced (consecutive columns, consecutive addresses); no window in LDS, no staging
+// rounds, no barrier before the fold.  What varies per (q, t) now is the TAP h[r + 512 t]: the prototype (32 KB) sits in LDS and is read
+// as 4-byte operands (half the bytes, and ds_read2st64 pairs).  The sums are the same products added in the same order (t ascending per
+// (q, r)): bit for bit SPEC 3.5.
+//   1. 23 global loads per thread (all in flight at once), the prototype into LDS meanwhile;
+//   2. fold: columns 0 .. 383 (waves 0-5) never wrap (c + 84 < 512): sample s = q + t, straight-line code; waves 6-7 hold the columns
+//      that wrap for some q (there the operand is s = q + t - 1): they walk s = q - 1 .. q + 15 with the tap index u = c + 12 q +
+//      512 (s - q) and skip u outside [0, 8192) by predication;
+//   3. the step's vector goes to its FFT buffer at (r + 500 (m0 + q)) mod 512 = (c + 500 m0) mod 512: the same rotation for all q;
 //   4. 512-point radix-2 DIT FFT, one WAVE per time step, 8 points per lane, two transposes through LDS (pfb_fft512n);
-//   5. phase = atan2q(bin) of the 8 points a lane holds, transposed through LDS into [bin][step], stored as one aligned 32-byte
-//      run per bin (two lanes of 16 bytes).
+//   5. phase = atan2q(bin) of the 8 points a lane holds, transposed through LDS into [bin][step], one aligned 16-byte store per bin.
 // The stream in front of the block (the last CH_H samples of the previous submit) comes from hist_in; the last workgroup of a
 // stream copies this block's tail to hist_out (the other buffer of a ping-pong pair: the first workgroups still read hist_in).
 #define P_S    8
 #define P_NT   (64 * P_S)
-#ifndef P_NSTG
-#define P_NSTG 2
-#endif                                                 // staging rounds (halves of the prototype's taps).  Quarters (48.5 KB: three workgroups per
-                                                       // CU) need <= 85 VGPRs and spill 224 B per lane; the halves take 112 and none (r4_notes.md)
-#ifndef P_DMA_ALL
-#define P_DMA_ALL 0
-#endif
-#ifndef P_WGCU
-#define P_WGCU (P_NSTG == 2 ? 2 : 3)                   // workgroups per CU the staging form aims at
-#endif
-#define P_TC   (CH_T / P_NSTG)                         // taps per round
-#define P_CHW  (P_TC * CH_M + (P_S - 1) * CH_D)       // samples staged per round: 7596
+#define P_NS   (CH_T + P_S - 1)                        // samples per column: 23
+#define P_WIN  (CH_L + (P_S - 1) * CH_D)              // window samples of a workgroup: 11 692
+#define P_NOWRAP ((CH_M - (P_S - 1) * (CH_M - CH_D)) / 64)   // waves whose columns never wrap: 6
 #define PFB_FB (CH_M + CH_M / 8)                      // FFT buffer per step: one pad element per 8 (bank spread)
 #define P_OT   (P_S + 1)                               // phase tile row stride (floats)
-#define P_LDS  (((P_CHW / 2 + 63) / 64) * 128)          // the window in whole 1 KB pieces (64 lanes x 16 bytes: the LDS-DMA unit): 7680 samples
-static_assert(P_NT == CH_M, "fold: one thread per bin residue; FFT: one wave per step");
-static_assert(P_S * PFB_FB <= P_CHW && CH_M * P_OT <= 2 * P_S * PFB_FB, "FFT buffers / phase tile alias the window");
-static_assert(P_WGCU * P_LDS * sizeof(float2) <= 160 * 1024, "workgroups per CU");
-static_assert(P_CHW % 2 == 0 && (P_S * CH_D) % 2 == 0 && CH_H % 2 == 0 && (P_TC * CH_M) % 2 == 0, "16-byte staging loads");
+static_assert(P_NT == CH_M, "fold: one thread per window column; FFT: one wave per step");
+static_assert(CH_M * P_OT <= 2 * P_S * PFB_FB, "the phase tile aliases the FFT buffers");
+static_assert(2 * ((CH_L + 256) * sizeof(float) + P_S * PFB_FB * sizeof(float2)) <= 160 * 1024, "two workgroups per CU");
+
+#ifdef P_TS       // experiment: cycle stamps of one wave's phases (make EXTRA=-DP_TS; tools/pfb_ts.py reads them)
+__device__ unsigned long long g_pfb_ts[128];
+extern "C" int sonde_debug_pfb_ts(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfb_ts), sizeof(g_pfb_ts)) == hipSuccess ? 0 : -1; }
+#define P_STAMP(i) do { if (blockIdx.x == P_TS_WG && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_pfb_ts[8 * (i) + (threadIdx.x >> 6)] = __builtin_readcyclecounter(); } while (0)
+#ifndef P_TS_WG
+#define P_TS_WG 100
+#endif
+#else
+#define P_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
 {
@@ -150,13 +159,15 @@ __device__ __forceinline__ void pfb_fft512n(float2 *fb, const float2 w64 /* tw[6
 // the way into LDS (exactly, no scaling: a phase does not see the amplitude); everything behind the window is the float path
 // (IK: 0 complex64, 1 int16 pairs, 2 int8 pairs -- a 10 MS/s 8-bit receiver's format)
 template <int IK>
-__global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
+__global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
                                                            const void *__restrict__ hist_in_all_, void *__restrict__ hist_out_all_,
                                                            const float *__restrict__ h_even, const float2 *__restrict__ tw,
                                                            int16_t *__restrict__ phi_all, uint32_t n_steps, uint32_t xcd_map,
                                                            uint32_t dual, const float *__restrict__ h_odd, const float2 *__restrict__ twist)
 {
-	__shared__ __attribute__((aligned(16))) float2 s_x[P_LDS];
+	__shared__ __attribute__((aligned(16))) float s_h_[CH_L + 256];        // the prototype (even or odd bank's) between two pads of 128: the
+	float *const s_h = s_h_ + 128;                                        // wrapping columns' edge taps are read unconditionally and used under a predicate
+	__shared__ __attribute__((aligned(16))) float2 s_x[P_S * PFB_FB];     // the steps' FFT buffers; later the phase tile
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	// Workgroups go to the 8 XCDs round robin (linear id mod 8; gridDim.x is a multiple of 8): XCD x takes the x-th eighth of the
 	// block's step groups, so that the workgroups resident on one XCD are neighbours in time and the overlap of their windows is
@@ -172,168 +183,146 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
 	const float *h = odd ? h_odd : h_even;
 	constexpr bool I16 = IK == 1, I8 = IK == 2;
 	using ET = typename std::conditional<I8, uint16_t, typename std::conditional<I16, uint32_t, float2>::type>::type;       // one complex sample
-	using PT = typename std::conditional<I8, uint32_t, typename std::conditional<I16, uint2, float4>::type>::type;          // a pair of them: what a staging load moves
+	using PT = typename std::conditional<I8, uint32_t, typename std::conditional<I16, uint2, float4>::type>::type;          // a pair of them (the history copy)
 	const ET *iq = reinterpret_cast<const ET *>(iq_all_) + (size_t)phys * stream_stride;
 	const ET *hist_in = reinterpret_cast<const ET *>(hist_in_all_) + (size_t)phys * CH_H;
 	ET *hist_out_all = reinterpret_cast<ET *>(hist_out_all_);
 	const size_t prow = (size_t)n_steps + PH_HEAD;                     // a bin's row: [16 carried phases | n_steps]
 	int16_t *phi = phi_all + (size_t)sidx * CH_M * prow + PH_HEAD;
-	const long p0 = (long)m0 * CH_D - CH_H;                   // stream position of window sample 0 (even)
-	constexpr int NQ = (P_CHW / 2 + P_NT - 1) / P_NT;
-	auto load_round = [&](int c, PT (&tmp)[NQ]) {              // taps c*P_TC ..: window samples [c * P_TC * 512, + P_CHW)
-		const long base = p0 + (long)c * P_TC * CH_M;           // even: a pair never straddles the block's first sample
-		const PT *src_iq = reinterpret_cast<const PT *>(iq);
-		const PT *src_h = reinterpret_cast<const PT *>(hist_in);
-		if (base >= 0) {                                        // (workgroup-uniform) all but the first two groups of a block: the window lies inside
-			const PT *src = src_iq + base / 2;                  // the block, one base address and constant offsets (round 5: the per-element select between
-#pragma unroll                                                  // history and block cost ~150 of the wave's 970 VALU instructions)
-			for (int q = 0; q < NQ; q++) {
-				const int i = tid + P_NT * q;
-				if (i < P_CHW / 2) tmp[q] = src[i];
-				else if constexpr (I8) tmp[q] = 0u;
-				else if constexpr (I16) tmp[q] = make_uint2(0u, 0u);
-				else tmp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-			}
-			return;
-		}
+	const long p0 = (long)m0 * CH_D - CH_H;                   // stream position of window sample 0
+	const int c = tid;                                        // this thread's window column
+	P_STAMP(0);
+	// 1. the column's 23 samples (window sample c + 512 s exists for c + 512 s < P_WIN: s = 22 only for the columns that do not wrap,
+	// the only ones that use it; positions in front of the block come from the carried history) and the prototype, which goes to LDS.
+	// Loads return in order: the first 8 samples, then the 16 taps (L2 hits), then the other 15 samples -- the taps are in LDS and the
+	// fold starts on the first samples while the rest of the window is still on its way
+	ET xr[P_NS];
+	auto stage = [&](auto get) {
 #pragma unroll
-		for (int q = 0; q < NQ; q++) {
-			const int i = tid + P_NT * q;
-			const long pos = base + 2 * (long)i;
-			if (i < P_CHW / 2) tmp[q] = pos < 0 ? src_h[(CH_H + pos) / 2] : src_iq[pos / 2];
-			else if constexpr (I8) tmp[q] = 0u;
-			else if constexpr (I16) tmp[q] = make_uint2(0u, 0u);
-			else tmp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-		}
+		for (int k = 0; k < 8; k++) { xr[k] = get(k); __builtin_amdgcn_sched_barrier(0); }       // (issued in k order: they return in that order)
+		float hreg[CH_T];
+#pragma unroll
+		for (int t = 0; t < CH_T; t++) hreg[t] = h[c + t * CH_M];
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int k = 8; k < P_NS; k++) { xr[k] = get(k); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+		for (int t = 0; t < CH_T; t++) s_h[c + t * CH_M] = hreg[t];      // (coalesced, conflict-free)
 	};
-	auto store_round = [&](const PT (&tmp)[NQ]) {
-		float4 *dst = reinterpret_cast<float4 *>(s_x);
-#pragma unroll
-		for (int q = 0; q < NQ; q++) {
-			const int i = tid + P_NT * q;
-			if (i < P_CHW / 2) {
-				if constexpr (I8) dst[i] = make_float4((float)(int8_t)(tmp[q] & 0xffu), (float)(int8_t)((tmp[q] >> 8) & 0xffu), (float)(int8_t)((tmp[q] >> 16) & 0xffu), (float)((int32_t)tmp[q] >> 24));
-				else if constexpr (I16) dst[i] = make_float4((float)(int16_t)(tmp[q].x & 0xffffu), (float)((int32_t)tmp[q].x >> 16), (float)(int16_t)(tmp[q].y & 0xffffu), (float)((int32_t)tmp[q].y >> 16));
-				else dst[i] = tmp[q];
-			}
-		}
-	};
-	// complex64 input goes global -> LDS directly (global_load_lds_dwordx4: a wave moves 64 x 16 bytes to consecutive LDS addresses; no
-	// staging registers, no ds_write pass -- the window stores were a fifth of the kernel's LDS time); integer input is converted on
-	// the way and keeps the register path.  P_DMA_ALL: every round that way (no staging registers at all: the form that fits three
-	// workgroups per CU); else round 0 only, the later rounds through registers that are loaded while the round before is folded.
-	auto dma_round = [&](int c) {
-		const long base = p0 + (long)c * P_TC * CH_M;
-		if (base >= 0) {
-			const float4 *src0 = reinterpret_cast<const float4 *>(iq) + base / 2;
-#pragma unroll
-			for (int q = 0; q < NQ; q++) {
-				const int piece = wave + 8 * q;
-				if (64 * piece < P_CHW / 2) {
-					int i = 64 * piece + lane;
-					i = i < P_CHW / 2 ? i : P_CHW / 2 - 1;
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + i),
-					                                 (__attribute__((address_space(3))) void *)(s_x + 128 * piece), 16, 0, 0);
-				}
-			}
-			return;
-		}
-#pragma unroll
-		for (int q = 0; q < NQ; q++) {
-			const int piece = wave + 8 * q;                          // 1 KB piece of the window (wave-uniform)
-			if (64 * piece < P_CHW / 2) {
-				int i = 64 * piece + lane;
-				i = i < P_CHW / 2 ? i : P_CHW / 2 - 1;               // (the last piece's spare lanes: any valid address)
-				const long pos = base + 2 * (long)i;
-				const float4 *src = pos < 0 ? reinterpret_cast<const float4 *>(hist_in) + (CH_H + pos) / 2 : reinterpret_cast<const float4 *>(iq) + pos / 2;
-				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-				                                 (__attribute__((address_space(3))) void *)(s_x + 128 * piece), 16, 0, 0);
-			}
-		}
-	};
-	constexpr bool DMA_ALL = IK == 0 && P_DMA_ALL;
-	PT tb[DMA_ALL ? 1 : NQ];
-	if constexpr (IK == 0) {
-		dma_round(0);
+	if (p0 >= 0) {                                            // (workgroup-uniform) all but the first two groups of a block
+		const ET *src = iq + p0 + c;
+		stage([&](int k) -> ET { return (k < P_NS - 1 || c + CH_M * k < P_WIN) ? src[CH_M * k] : ET{}; });
 	} else {
-		PT ta[NQ];
-		load_round(0, ta);
-		store_round(ta);
+		stage([&](int k) -> ET {
+			const long pos = p0 + c + CH_M * k;
+			return (k < P_NS - 1 || c + CH_M * k < P_WIN) ? (pos < 0 ? hist_in[CH_H + pos] : iq[pos]) : ET{};
+		});
 	}
-	const int r = tid;
-	float hr[CH_T];
-#pragma unroll
-	for (int t = 0; t < CH_T; t++) hr[t] = h[r + t * CH_M];
+	P_STAMP(1);
 	if (grp == gridDim.x - 1 && !odd) {     // the last CH_H samples of the block are the next submit's history (n_steps * 500 >= CH_H)
 		const PT *tail = reinterpret_cast<const PT *>(iq + (size_t)n_steps * CH_D - CH_H);
 		PT *ho = reinterpret_cast<PT *>(hist_out_all + (size_t)phys * CH_H);
 		for (int i = tid; i < CH_H / 2; i += P_NT) ho[i] = tail[i];
 	}
-	if constexpr (!DMA_ALL) load_round(1, tb);                 // in flight while the first part is folded
 	__syncthreads();
+	P_STAMP(2);
 	// 2. fold (SPEC 3.5: v[r] = sum_t fmaf(h[r+512t], x[r+512t], acc), t ascending)
+	auto sample = [&](int k) -> float2 {
+		if constexpr (I8) return make_float2((float)(int8_t)(xr[k] & 0xffu), (float)(int8_t)(xr[k] >> 8));
+		else if constexpr (I16) return make_float2((float)(int16_t)(xr[k] & 0xffffu), (float)((int32_t)xr[k] >> 16));
+		else return xr[k];
+	};
 	float2 v[P_S];
 #pragma unroll
 	for (int q = 0; q < P_S; q++) v[q] = make_float2(0.0f, 0.0f);
-	auto fold_round = [&](int c) {
+	// The samples are consumed in the order they arrive (k ascending; a scheduling barrier per sample keeps the compiler from starting with
+	// the last ones, which would wait for the whole window); the taps of sample k + 1 are read from LDS before the products of sample k.
+	// Tap index of (q, k): u = c + 12 q + 512 d, d = k - q.  d = 0 .. 14: inside [0, 8192) for every column; d = 15 only where
+	// c + 12 q < 512, d = -1 only where it is not.  Columns 0 .. 383 (waves 0-5) never wrap: d = 0 .. 15, no predicate; waves 6-7 carry
+	// the two edge terms of every q under a per-lane predicate.
+	auto fold = [&](auto edge_c) {
+		constexpr bool edge = decltype(edge_c)::value;
+		const float *hq = s_h + c;
+		float hk[P_S], hn[P_S], he = 0.0f, hen = 0.0f;          // he: the d = -1 tap (q = k + 1) of the wrapping columns
+		auto taps_of = [&](int k, float (&hh)[P_S], float &hm1) {
 #pragma unroll
-		for (int q = 0; q < P_S; q++) {
-			const float2 *xs = s_x + q * CH_D + r;
-#pragma unroll
-			for (int t = 0; t < P_TC; t++) {
-				const float2 xv = xs[t * CH_M];
-				v[q].x = __builtin_fmaf(hr[c * P_TC + t], xv.x, v[q].x);
-				v[q].y = __builtin_fmaf(hr[c * P_TC + t], xv.y, v[q].y);
+			for (int q = 0; q < P_S; q++) {
+				const int d = k - q;
+				if (d >= 0 && d < CH_T - 1) hh[q] = hq[(CH_M - CH_D) * q + CH_M * d];
+				else if (d == CH_T - 1) hh[q] = hq[(CH_M - CH_D) * q + CH_M * d];       // (beyond the table for a wrapping column: the pad)
+				else hh[q] = 0.0f;
 			}
+			hm1 = 0.0f;
+			if (edge && k + 1 < P_S) hm1 = hq[(CH_M - CH_D) * (k + 1) - CH_M];      // q = k + 1, d = -1 (in front of the table for a column that does not wrap: the pad)
+		};
+		taps_of(0, hk, he);
+#pragma unroll
+		for (int k = 0; k < P_NS; k++) {
+			if (k + 1 < P_NS) taps_of(k + 1, hn, hen);
+			const float2 xv = sample(k);
+			if (edge && k + 1 < P_S) {                           // d = -1 comes first in q = k + 1's sum
+				const int q = k + 1;
+				const bool ok = c + (CH_M - CH_D) * q >= CH_M;
+				const float nx = __builtin_fmaf(he, xv.x, v[q].x), ny = __builtin_fmaf(he, xv.y, v[q].y);
+				v[q].x = ok ? nx : v[q].x;
+				v[q].y = ok ? ny : v[q].y;
+			}
+#pragma unroll
+			for (int q = 0; q < P_S; q++) {
+				const int d = k - q;
+				if (d >= 0 && d < CH_T - 1) {
+					v[q].x = __builtin_fmaf(hk[q], xv.x, v[q].x);
+					v[q].y = __builtin_fmaf(hk[q], xv.y, v[q].y);
+				} else if (d == CH_T - 1) {
+					const float nx = __builtin_fmaf(hk[q], xv.x, v[q].x), ny = __builtin_fmaf(hk[q], xv.y, v[q].y);
+					const bool ok = !edge || c + (CH_M - CH_D) * q < CH_M;
+					v[q].x = ok ? nx : v[q].x;
+					v[q].y = ok ? ny : v[q].y;
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int q = 0; q < P_S; q++) hk[q] = hn[q];
+			he = hen;
 		}
 	};
-	// the FFT's twiddles: pass 1's three are wave-uniform; passes 2 and 3 per lane, requested once the last staged part has left its
-	// registers, in flight during the last part's fold
-	float2 w64, w128, w192;
-	PfbTw twr;
-#pragma unroll
-	for (int c = 0; c < P_NSTG; c++) {
-		fold_round(c);
-		__syncthreads();                   // this part of the window is consumed (the last one: the window is dead from here on)
-		if (c + 1 < P_NSTG) {
-			if constexpr (DMA_ALL) {
-				dma_round(c + 1);
-				if (c + 2 == P_NSTG) { w64 = tw[64]; w128 = tw[128]; w192 = tw[192]; twr = pfb_load_tw(tw, lane); }
-			} else {
-				store_round(tb);
-				if (c + 2 < P_NSTG) load_round(c + 2, tb);
-				else { w64 = tw[64]; w128 = tw[128]; w192 = tw[192]; twr = pfb_load_tw(tw, lane); }
-			}
-			__syncthreads();
-		}
-	}
-	if (odd) {                              // the twist W[r] = exp(-j pi r / 512) (wave-uniform branch)
-		const float2 w = twist[r];
+	if (wave < P_NOWRAP) fold(std::false_type{});
+	else fold(std::true_type{});
+	P_STAMP(3);
+	// the FFT's twiddles: pass 1's three are wave-uniform; passes 2 and 3 per lane (requested now, in flight during the rotation)
+	const float2 w64 = tw[64], w128 = tw[128], w192 = tw[192];
+	const PfbTw twr = pfb_load_tw(tw, lane);
+	if (odd) {                              // the twist W[r] = exp(-j pi r / 512), r = (c + 12 q) mod 512 (wave-uniform branch)
 #pragma unroll
 		for (int q = 0; q < P_S; q++) {
+			const float2 w = twist[(c + (CH_M - CH_D) * q) & (CH_M - 1)];
 			const float tr = __builtin_fmaf(-v[q].y, w.y, v[q].x * w.x), ti = __builtin_fmaf(v[q].x, w.y, v[q].y * w.x);
 			v[q] = make_float2(tr, ti);
 		}
 	}
-	// 3. rotate into the buffer of the step
+	// 3. rotate into the buffer of the step: (r + 500 (m0 + q)) mod 512 = (c + 500 m0) mod 512 for every q
+	{
+		const uint32_t pos = ((uint32_t)c + m0 * (uint32_t)CH_D) & (CH_M - 1);
 #pragma unroll
-	for (int q = 0; q < P_S; q++) {
-		const uint32_t shift = ((m0 + (uint32_t)q) * CH_D) & (CH_M - 1);
-		const uint32_t pos = ((uint32_t)r + shift) & (CH_M - 1);
-		s_x[q * PFB_FB + pos] = v[q];                          // natural order: consecutive lanes, consecutive addresses
+		for (int q = 0; q < P_S; q++) s_x[q * PFB_FB + pos] = v[q];      // natural order: consecutive lanes, consecutive addresses
 	}
 	__syncthreads();
+	P_STAMP(4);
 	// 4. FFT of step m0 + wave by this wave alone; 5. the phases of the 8 bins this lane holds
 	float2 e0[8];
 	pfb_fft512n(s_x + wave * PFB_FB, w64, w128, w192, twr, lane, e0);
+	P_STAMP(5);
 	float ph[8];
 #pragma unroll
 	for (int j = 0; j < 8; j++) ph[j] = sd_atan2q(e0[j].y, e0[j].x);
+	P_STAMP(6);
 	__syncthreads();                       // every wave has left its FFT buffer: the phase tile aliases them
+	P_STAMP(7);
 	float *const s_t = reinterpret_cast<float *>(s_x);
 #pragma unroll
 	for (int j = 0; j < 8; j++) s_t[(lane + 64 * j) * P_OT + wave] = ph[j];
 	__syncthreads();
+	P_STAMP(8);
 	// SPEC 3.5 (round 5): a phase leaves the bank as a 16-bit fraction of a turn, q = rint(16384 atan2q) mod 2^16; the odd bank takes
 	// the step's common phase -(125 / 64) m quadrants = -32000 m (mod 2^16) off in integers (exact; 256 steps = whole turns).
 	// Thread = bin: its 8 steps are one aligned 16-byte store.
@@ -348,6 +337,7 @@ __global__ __launch_bounds__(P_NT, 2 * P_WGCU) void sd_pfb_kernel(const void *__
 		}
 		*reinterpret_cast<uint4 *>(phi + (size_t)tid * prow + m0) = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16));
 	}
+	P_STAMP(9);
 }
 
 // ---- per bin: discriminator (wrapped difference of consecutive phases) at 20 kS/s + 12/5 polyphase resampler to 48 kS/s, as a
