@@ -61,7 +61,7 @@
 #define P_OT   (P_S + 1)                               // phase tile row stride (floats)
 static_assert(P_NT == CH_M, "fold: one thread per window column; FFT: one wave per step");
 static_assert(CH_M * P_OT <= 2 * P_S * PFB_FB, "the phase tile aliases the FFT buffers");
-static_assert(2 * ((CH_L + 256) * sizeof(float) + P_S * PFB_FB * sizeof(float2)) <= 160 * 1024, "two workgroups per CU");
+static_assert(3 * ((CH_L / 2 + 128) * sizeof(float) + P_S * PFB_FB * sizeof(float2)) <= 160 * 1024, "three workgroups per CU");
 
 #ifdef P_TS       // experiment: cycle stamps of one wave's phases (make EXTRA=-DP_TS; tools/pfb_ts.py reads them)
 __device__ unsigned long long g_pfb_ts[128];
@@ -159,14 +159,18 @@ __device__ __forceinline__ void pfb_fft512n(float2 *fb, const float2 w64 /* tw[6
 // the way into LDS (exactly, no scaling: a phase does not see the amplitude); everything behind the window is the float path
 // (IK: 0 complex64, 1 int16 pairs, 2 int8 pairs -- a 10 MS/s 8-bit receiver's format)
 template <int IK>
-__global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
+__global__ __launch_bounds__(P_NT, 6) void sd_pfb_kernel(const void *__restrict__ iq_all_, size_t stream_stride,
                                                            const void *__restrict__ hist_in_all_, void *__restrict__ hist_out_all_,
                                                            const float *__restrict__ h_even, const float2 *__restrict__ tw,
                                                            int16_t *__restrict__ phi_all, uint32_t n_steps, uint32_t xcd_map,
                                                            uint32_t dual, const float *__restrict__ h_odd, const float2 *__restrict__ twist)
 {
-	__shared__ __attribute__((aligned(16))) float s_h_[CH_L + 256];        // the prototype (even or odd bank's) between two pads of 128: the
-	float *const s_h = s_h_ + 128;                                        // wrapping columns' edge taps are read unconditionally and used under a predicate
+	// The prototype is symmetric, h[n] = h[8191 - n] bit for bit (the odd bank's, taps of odd t negated, antisymmetric): its FIRST HALF sits in
+	// LDS behind a pad of 128 (the wrapping columns' edge taps are read unconditionally -- a negative index lands in the pad -- and used
+	// under a predicate); tap u >= 4096 is read at 8191 - u (descending lanes: conflict-free) and negated for the odd bank.  16.5 KB instead
+	// of 32: with the FFT buffers 52.5 KB per workgroup, THREE workgroups per CU (six waves per SIMD).
+	__shared__ __attribute__((aligned(16))) float s_h_[CH_L / 2 + 128];
+	float *const s_h = s_h_ + 128;
 	__shared__ __attribute__((aligned(16))) float2 s_x[P_S * PFB_FB];     // the steps' FFT buffers; later the phase tile
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	// Workgroups go to the 8 XCDs round robin (linear id mod 8; gridDim.x is a multiple of 8): XCD x takes the x-th eighth of the
@@ -200,14 +204,14 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 	auto stage = [&](auto get) {
 #pragma unroll
 		for (int k = 0; k < 8; k++) { xr[k] = get(k); __builtin_amdgcn_sched_barrier(0); }       // (issued in k order: they return in that order)
-		float hreg[CH_T];
+		float hreg[CH_T / 2];
 #pragma unroll
-		for (int t = 0; t < CH_T; t++) hreg[t] = h[c + t * CH_M];
+		for (int t = 0; t < CH_T / 2; t++) hreg[t] = h[c + t * CH_M];
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int k = 8; k < P_NS; k++) { xr[k] = get(k); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-		for (int t = 0; t < CH_T; t++) s_h[c + t * CH_M] = hreg[t];      // (coalesced, conflict-free)
+		for (int t = 0; t < CH_T / 2; t++) s_h[c + t * CH_M] = hreg[t];      // (coalesced, conflict-free)
 	};
 	if (p0 >= 0) {                                            // (workgroup-uniform) all but the first two groups of a block
 		const ET *src = iq + p0 + c;
@@ -240,16 +244,21 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 	// Tap index of (q, k): u = c + 12 q + 512 d, d = k - q.  d = 0 .. 14: inside [0, 8192) for every column; d = 15 only where
 	// c + 12 q < 512, d = -1 only where it is not.  Columns 0 .. 383 (waves 0-5) never wrap: d = 0 .. 15, no predicate; waves 6-7 carry
 	// the two edge terms of every q under a per-lane predicate.
-	auto fold = [&](auto edge_c) {
-		constexpr bool edge = decltype(edge_c)::value;
-		const float *hq = s_h + c;
+	auto fold = [&](auto edge_c, auto odd_c) {
+		constexpr bool edge = decltype(edge_c)::value, ODD = decltype(odd_c)::value;
+		const float *hq = s_h + c;                              // tap u = c + 12 q + 512 d < 4096 at hq[12 q + 512 d]
+		const float *hm = s_h + (CH_L - 1) - c;                 // tap u >= 4096 at s_h[8191 - u] = hm[-(12 q + 512 d)]
 		float hk[P_S], hn[P_S], he = 0.0f, hen = 0.0f;          // he: the d = -1 tap (q = k + 1) of the wrapping columns
+		auto mir = [&](int off) -> float { const float m = hm[-off]; return ODD ? -m : m; };
 		auto taps_of = [&](int k, float (&hh)[P_S], float &hm1) {
 #pragma unroll
 			for (int q = 0; q < P_S; q++) {
-				const int d = k - q;
-				if (d >= 0 && d < CH_T - 1) hh[q] = hq[(CH_M - CH_D) * q + CH_M * d];
-				else if (d == CH_T - 1) hh[q] = hq[(CH_M - CH_D) * q + CH_M * d];       // (beyond the table for a wrapping column: the pad)
+				const int d = k - q, off = (CH_M - CH_D) * q + CH_M * d;
+				if (d >= 0 && d < CH_T / 2 - 1) hh[q] = hq[off];
+				else if (d == CH_T / 2 - 1) {                       // u = c + 12 q + 3584: the second half for a column that has wrapped
+					if (edge) { const float a = hq[off], b = mir(off); hh[q] = c + (CH_M - CH_D) * q < CH_M ? a : b; }
+					else hh[q] = hq[off];
+				} else if (d >= CH_T / 2 && d < CH_T) hh[q] = mir(off);      // (d = 15 of a wrapping column: index < 0, the pad)
 				else hh[q] = 0.0f;
 			}
 			hm1 = 0.0f;
@@ -286,8 +295,8 @@ __global__ __launch_bounds__(P_NT, 4) void sd_pfb_kernel(const void *__restrict_
 			he = hen;
 		}
 	};
-	if (wave < P_NOWRAP) fold(std::false_type{});
-	else fold(std::true_type{});
+	if (wave < P_NOWRAP) { if (odd) fold(std::false_type{}, std::true_type{}); else fold(std::false_type{}, std::false_type{}); }
+	else { if (odd) fold(std::true_type{}, std::true_type{}); else fold(std::true_type{}, std::false_type{}); }
 	P_STAMP(3);
 	// the FFT's twiddles: pass 1's three are wave-uniform; passes 2 and 3 per lane (requested now, in flight during the rotation)
 	const float2 w64 = tw[64], w128 = tw[128], w192 = tw[192];
@@ -534,6 +543,7 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 	          hipMalloc((void **)&c->d_dhist, nb * RS_TAPS * sizeof(float)) == hipSuccess;
 	ok = ok && hipMemset(c->d_hist[0], 0, hist_bytes) == hipSuccess && hipMemset(c->d_hist[1], 0, hist_bytes) == hipSuccess && hipMemset(c->d_philast, 0, nb * sizeof(int32_t)) == hipSuccess && hipMemset(c->d_bins, 0, nb * ((size_t)c->n_steps + PH_HEAD) * sizeof(int16_t)) == hipSuccess &&
 	     hipMemset(c->d_dhist, 0, nb * RS_TAPS * sizeof(float)) == hipSuccess &&
+	     [&] { for (int i = 0; i < CH_L / 2; i++) if (memcmp(&h[i], &h[CH_L - 1 - i], sizeof(float))) return false; return true; }() &&      // the kernel keeps half of it
 	     hipMemcpy(c->d_h, h.data(), CH_L * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_tw, tw.data(), CH_M * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(c->d_g, g.data(), RS_UP * RS_TAPS * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
