@@ -248,7 +248,7 @@ __global__ __launch_bounds__(P_NT, 6) void sd_pfb_kernel(const void *__restrict_
 		constexpr bool edge = decltype(edge_c)::value, ODD = decltype(odd_c)::value;
 		const float *hq = s_h + c;                              // tap u = c + 12 q + 512 d < 4096 at hq[12 q + 512 d]
 		const float *hm = s_h + (CH_L - 1) - c;                 // tap u >= 4096 at s_h[8191 - u] = hm[-(12 q + 512 d)]
-		float hk[P_S], hn[P_S], he = 0.0f, hen = 0.0f;          // he: the d = -1 tap (q = k + 1) of the wrapping columns
+		float hk[P_S], he = 0.0f;                               // he: the d = -1 tap (q = k + 1) of the wrapping columns
 		auto mir = [&](int off) -> float { const float m = hm[-off]; return ODD ? -m : m; };
 		auto taps_of = [&](int k, float (&hh)[P_S], float &hm1) {
 #pragma unroll
@@ -264,11 +264,10 @@ __global__ __launch_bounds__(P_NT, 6) void sd_pfb_kernel(const void *__restrict_
 			hm1 = 0.0f;
 			if (edge && k + 1 < P_S) hm1 = hq[(CH_M - CH_D) * (k + 1) - CH_M];      // q = k + 1, d = -1 (in front of the table for a column that does not wrap: the pad)
 		};
-		taps_of(0, hk, he);
 #pragma unroll
 		for (int k = 0; k < P_NS; k++) {
-			if (k + 1 < P_NS) taps_of(k + 1, hn, hen);
-			const float2 xv = sample(k);
+			taps_of(k, hk, he);                                  // (no software prefetch of the next sample's taps: at six waves per SIMD the
+			const float2 xv = sample(k);                          // other waves cover the LDS latency, and the 9 registers are the difference to spilling)
 			if (edge && k + 1 < P_S) {                           // d = -1 comes first in q = k + 1's sum
 				const int q = k + 1;
 				const bool ok = c + (CH_M - CH_D) * q >= CH_M;
@@ -290,9 +289,6 @@ __global__ __launch_bounds__(P_NT, 6) void sd_pfb_kernel(const void *__restrict_
 				}
 			}
 			__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-			for (int q = 0; q < P_S; q++) hk[q] = hn[q];
-			he = hen;
 		}
 	};
 	if (wave < P_NOWRAP) { if (odd) fold(std::false_type{}, std::true_type{}); else fold(std::false_type{}, std::false_type{}); }
