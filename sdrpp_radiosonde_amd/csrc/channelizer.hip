@@ -43,10 +43,10 @@
 // rounds, no barrier before the fold.  What varies per (q, t) now is the TAP h[r + 512 t]: the prototype (32 KB) sits in LDS and is read
 // as 4-byte operands (half the bytes, and ds_read2st64 pairs).  The sums are the same products added in the same order (t ascending per
 // (q, r)): bit for bit SPEC 3.5.
-//   1. 23 global loads per thread (all in flight at once), the prototype into LDS meanwhile;
-//   2. fold: columns 0 .. 383 (waves 0-5) never wrap (c + 84 < 512): sample s = q + t, straight-line code; waves 6-7 hold the columns
-//      that wrap for some q (there the operand is s = q + t - 1): they walk s = q - 1 .. q + 15 with the tap index u = c + 12 q +
-//      512 (s - q) and skip u outside [0, 8192) by predication;
+//   1. 23 global loads per thread (all in flight at once, issued and consumed in stream order), the first half of the (symmetric)
+//      prototype into LDS meanwhile: 16.5 KB + the FFT buffers = 52.5 KB per workgroup, THREE workgroups per CU, 80 VGPRs;
+//   2. fold: columns 0 .. 383 (waves 0-5) never wrap (c + 84 < 512): sample s = q + t; waves 6-7 hold the columns that wrap for some q
+//      (there the operand is s = q + t - 1): the same walk plus the two edge terms of every q under a per-lane predicate;
 //   3. the step's vector goes to its FFT buffer at (r + 500 (m0 + q)) mod 512 = (c + 500 m0) mod 512: the same rotation for all q;
 //   4. 512-point radix-2 DIT FFT, one WAVE per time step, 8 points per lane, two transposes through LDS (pfb_fft512n);
 //   5. phase = atan2q(bin) of the 8 points a lane holds, transposed through LDS into [bin][step], one aligned 16-byte store per bin.
@@ -288,7 +288,9 @@ __global__ __launch_bounds__(P_NT, 6) void sd_pfb_kernel(const void *__restrict_
 					v[q].y = ok ? ny : v[q].y;
 				}
 			}
+#ifndef P_NOSB
 			__builtin_amdgcn_sched_barrier(0);
+#endif
 		}
 	};
 	if (wave < P_NOWRAP) { if (odd) fold(std::false_type{}, std::true_type{}); else fold(std::false_type{}, std::false_type{}); }
