@@ -116,6 +116,10 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 	const bool fec_here = is_rs41 && fuse;
 	uint32_t *ring_g = bitring + (size_t)ch * ring_words;
 	const uint32_t ring_mask = ring_words - 1;
+	// the ring's newest words (K4's window into the past): the address needs the state, which has arrived; requested now, used before tile 0
+	// (round 5: requested there it cost a full memory latency, 1 200 of the wave's 34 600 ticks: tools/bk_ts.py)
+	const uint32_t wi = (uint32_t)(st.wpos >> 5) - (uint32_t)(63 - lane);
+	const uint32_t xw = __hip_atomic_load(ring_g + (wi & ring_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	float *const taps = s.taps[bk_slot(stype)];
 	{
 		// the type's tap table into its slot, pair-swapped rows as interp() wants them (bins of one type write identical values)
@@ -287,8 +291,6 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		if (b == 0) {
 			// what the timing loop needs from the head of the wave's life has arrived by now: history, the ring's newest words, K4's state
 			w.A[lane] = hv;
-			const uint32_t wi = (uint32_t)(st.wpos >> 5) - (uint32_t)(63 - lane);
-			const uint32_t xw = __hip_atomic_load(ring_g + (wi & ring_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			w.mirror[wi & (SD_MIRROR_WORDS - 1)] = xw;
 			partial = ((uint32_t)st.wpos & 31u) ? (uint32_t)__builtin_amdgcn_readlane((int)xw, 63) : 0u;
 			k4.rpos = f0.rpos; k4.fstart = f0.fstart; k4.collecting = f0.collecting; k4.inv = f0.inv; k4.flen = f0.flen; k4.nout = 0; k4.wp_seen = 0;
