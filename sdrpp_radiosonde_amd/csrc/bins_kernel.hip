@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 	__shared__ __attribute__((aligned(16))) BinsLds s;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t ch = blockIdx.x * BK_WAVES + (uint32_t)wave;
+	const uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;      // (the launcher picks the waves per workgroup: sd_launch_bins)
 	if (ch >= n_channels) return;
 	BinsWaveLds &w = s.w[wave];
 	BK_STAMP(0);
@@ -366,7 +366,16 @@ void sd_launch_bins(uint32_t n_channels, hipStream_t stream, const int16_t *phas
 	int16_t *carry_rows, size_t carry_stride, SdChanState *states, float *hist, uint32_t *bitring, uint32_t ring_words,
 	const float *taps_all, const SdModem *modems_host, const SdFramerOut *fo_host, const float *g_comp, int utype)
 {
-	const dim3 g((n_channels + BK_WAVES - 1) / BK_WAVES), blk(64 * BK_WAVES);
+	// Waves (= bins) per workgroup: 8 for launches that fill the GPU anyway; small launches (one stream = 512 bins) spread over all CUs -- a
+	// tile's rounds are bound by the VALU share a wave gets on its SIMD (tools/bk_ts.py): 512 waves as 64 workgroups sit two to a SIMD
+	// on a quarter of the CUs, as 256 workgroups of two waves each has a SIMD to itself
+	int wpw = BK_WAVES;
+	{
+		int dev = 0, cus = 256;
+		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+		while (wpw > 1 && (n_channels + wpw - 1) / wpw < (uint32_t)cus) wpw >>= 1;
+	}
+	const dim3 g((n_channels + wpw - 1) / wpw), blk(64 * wpw);
 	SdBinsParams P;
 	P.fo = *fo_host;
 	for (int t = 0; t < SONDE_NTYPES; t++) P.modems[t] = modems_host[t];
