@@ -177,11 +177,21 @@ __global__ __launch_bounds__(P_NT, 6) void sd_pfb_kernel(const void *__restrict_
 	// block's step groups, so that the workgroups resident on one XCD are neighbours in time and the overlap of their windows is
 	// served by that XCD's L2 (round 3: 8 streams 104 -> 97 us; one stream x one block loses: the host asks for it from two
 	// generations of workgroups on, xcd_map)
-	const uint32_t grp = xcd_map ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+	// xcd_map 2 (round 5; streams a multiple of 8, one bank): XCD x takes STREAMS x, x + 8, ... whole, their step groups in order -- no
+	// window straddles two L2s any more (the eighths' 8 x 8 seams cost 3.9 MB of HBM fetches per 8-stream step: 86.3 -> 82.4 MB)
+	uint32_t grp, sidx;
+	if (xcd_map == 2u) {
+		const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, j = lin >> 3;
+		sidx = (lin & 7u) + 8u * (j / gridDim.x);
+		grp = j % gridDim.x;
+	} else {
+		grp = xcd_map ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+		sidx = blockIdx.y;
+	}
 	// blockIdx.y = LOGICAL stream.  dual (SPEC 3.5c): logical streams 2p and 2p + 1 are the even and the odd-stacked bank (bins centred
 	// at k and k + 1/2 bin spacings) of physical stream p: the same samples, taps of odd t negated, a twist behind the fold, the
 	// step's common phase taken off the phase samples
-	const uint32_t m0 = grp * P_S, sidx = blockIdx.y;
+	const uint32_t m0 = grp * P_S;
 	const bool odd = dual && (sidx & 1u);
 	const uint32_t phys = dual ? sidx >> 1 : sidx;
 	const float *h = odd ? h_odd : h_even;
@@ -517,6 +527,7 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 	c->dual = dual;
 	c->n_steps = 2560u * blocks_per_submit;                  // 2560 steps = 1.28 M wideband samples = 6144 samples at 48 kS/s
 	c->xcd_map = (c->n_steps / P_S) % 8 == 0 && (size_t)(c->n_steps / P_S) * n_streams > 1024;
+	if (c->xcd_map && !dual && n_streams % 8 == 0) c->xcd_map = 2;      // a stream per XCD (the two banks of a dual object share their samples: they stay together)
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
 	const size_t nb = (size_t)n_streams * CH_M;              // bins of all streams: the decoder batch's channels, stream-major
 	SondeBatchConfig cfg;
