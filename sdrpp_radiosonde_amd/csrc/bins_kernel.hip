@@ -157,6 +157,13 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		WAVE_SYNC();
 		// lane <-> group u = 64 gp + lane: the three decimated samples that d[5u .. 5u + 4] complete read d[5u - 15 .. 5u + 4] =
 		// elements 5 lane + 1 .. 5 lane + 20 (lanes 20 bytes apart: conflict-free), statically indexed; tap rows broadcast
+		// (the table's address through an opaque copy per pass: left to itself the compiler loads the 51 taps ONCE and keeps them in scalar
+		// registers for the whole kernel -- half of the wave's 102 -- and spills 118 other scalars into VGPR lanes: 530 v_readlane /
+		// v_writelane in the tile code; reloaded per pass they are scalar-cache hits)
+		typedef const __attribute__((address_space(4))) float *CTab;      // (constant address space: scalar loads)
+		unsigned long long g_addr = (unsigned long long)g_comp;
+		asm volatile("" : "+s"(g_addr));
+		const CTab g_pass = (CTab)g_addr;
 		float dv[20];
 		const float *dp = &w.d[5 * lane + 1];
 #pragma unroll
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 			const int bo = BO[c] + 15;
 			// the composite tap row: wave-uniform addresses of a read-only table = scalar loads, the taps SGPR operands of the multiply-adds
 			// (as broadcast LDS reads they were 15 of a pass's 31 LDS instructions, and the LDS pipe is this kernel's busiest unit)
-			const float *gt = g_comp + SD_RS_KT_LD * c;
+			const CTab gt = g_pass + SD_RS_KT_LD * c;
 			float acc = 0.0f;
 #pragma unroll
 			for (int t = 0; t < SD_RS_KT; t++) acc = __builtin_fmaf(gt[t], dv[bo - t], acc);

@@ -57,6 +57,30 @@ __device__ __forceinline__ void sd_rs41_sync_step(SdSyncRun &lds_state, uint64_t
 	fs.nout = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_state.nout);
 	// nothing to do in the common case: a frame is being collected and its end has not arrived
 	if (fs.collecting && fs.flen && wp < fs.fstart + 8 * (uint64_t)fs.flen) return;
+	if (REG && !fs.collecting) {
+		// The other common case, as straight-line code (round 5; tools/bk_ts.py: the general loop below costs a wave of the bins decoder
+		// 2 000 of a tile's 6 000 ticks on a bin without a transmitter -- 1 100 for four chunks behind 64-bit position compares, 700 for
+		// the scalar tail of hit tests and loop exits): searching, and ONE trip of NCHUNK chunks covers every candidate whose window is
+		// complete.  Without a hit the loop would leave rpos = wp - 63 and nothing else changed: exactly that, behind one branch.
+		const uint32_t avail = (uint32_t)(wp - fs.rpos);               // (the search never trails by more than the mirror: < 2^11)
+		if (wp >= fs.rpos && avail < 64u) return;                          // no candidate with a complete window yet
+		if (wp >= fs.rpos && avail <= 64u * NCHUNK + 63u) {
+			const uint32_t b0 = (uint32_t)fs.rpos;
+			unsigned long long any = 0;
+#pragma unroll
+			for (int j = 0; j < NCHUNK; j++) {
+				const uint32_t pb = b0 + (uint32_t)(64 * j + lane);           // the position's low 32 bits: word index and shift are all it gives
+				const uint32_t wi = (uint32_t)((fs.rpos + (uint64_t)(64 * j)) >> 5) + ((((uint32_t)fs.rpos & 31u) + (uint32_t)lane) >> 5), sh = pb & 31u;
+				const uint32_t w0 = mirror[wi & (SD_MIRROR_WORDS - 1)], w1 = mirror[(wi + 1) & (SD_MIRROR_WORDS - 1)],
+				               w2 = mirror[(wi + 2) & (SD_MIRROR_WORDS - 1)];
+				const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+				const int hd = __popc(lo ^ RS41_SYNC_LO) + __popc(hi ^ RS41_SYNC_HI);
+				const bool hit = (uint32_t)(64 * j + lane) + 64u <= avail && (hd <= RS41_SYNC_THR || hd >= 64 - RS41_SYNC_THR);
+				any |= __ballot(hit);
+			}
+			if (!any) { lds_state.rpos = wp - 63; return; }
+		}
+	}
 	for (;;) {
 		if (!fs.collecting) {
 			bool found = false;
