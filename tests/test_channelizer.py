@@ -31,6 +31,15 @@ def test_fft512_and_tables(oracle):
     assert np.allclose(g.reshape(12, 16).sum(axis=1), 1.0, atol=1e-6)
 
 
+def test_prototype_is_symmetric_bit_for_bit(oracle):
+    """The filter-bank kernel keeps only the first half of the prototype in LDS and reads tap u >= 4096 at 8191 - u (round 5:
+    three workgroups per CU); sonde_chan_create refuses a prototype that is not symmetric bit for bit.  The SPEC's is."""
+    L = oracle.lib()
+    h = np.zeros(16 * 512, dtype=np.float32)
+    L.or_chan_proto(oracle.fptr(h))
+    assert h.tobytes() == h[::-1].tobytes()
+
+
 def test_channelizer_isolates_a_tone(oracle):
     """A tone 1.2 kHz above the centre of bin 77 comes out of bin 77 as a phase ramp of that slope at 20 kS/s; the resampled
     discriminator reads its frequency."""
