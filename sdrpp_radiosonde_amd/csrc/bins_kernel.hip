@@ -378,8 +378,12 @@ void sd_launch_bins(uint32_t n_channels, hipStream_t stream, const int16_t *phas
 	// on a quarter of the CUs, as 256 workgroups of two waves each has a SIMD to itself
 	int wpw = BK_WAVES;
 	{
+		static int cus_of[64];                                   // (per device, asked once: 0 = not asked yet)
 		int dev = 0, cus = 256;
-		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+		if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+			if (!cus_of[dev] && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cus_of[dev] = cus;
+			if (cus_of[dev]) cus = cus_of[dev];
+		}
 		while (wpw > 1 && (n_channels + wpw - 1) / wpw < (uint32_t)cus) wpw >>= 1;
 	}
 	const dim3 g((n_channels + wpw - 1) / wpw), blk(64 * wpw);
