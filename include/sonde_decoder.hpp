@@ -206,7 +206,7 @@ public:
 		if (flags == kFlagsAuto) flags = default_flags(sonde_type);
 		const uint8_t t = (uint8_t)sonde_type;
 		const bool afsk = sonde_type == SONDE_IMET4 || sonde_type == SONDE_C50;
-		SondeBatchConfig cfg = {};
+		SondeBatchConfig cfg = SONDE_BATCH_CONFIG_INIT;
 		cfg.n_channels = 1;
 		cfg.types = &t;
 		cfg.device = device;

@@ -41,21 +41,27 @@ class SondeData(C.Structure):
 
 class SondeBatchConfig(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("types", C.POINTER(C.c_uint8)), ("max_samples", C.c_uint32),
-                ("input_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32), ("launch_units", C.c_uint32)]
+                ("input_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32), ("launch_units", C.c_uint32),
+                ("struct_size", C.c_uint32)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(SondeBatchConfig)      # SONDE_BATCH_CONFIG_INIT: sonde_batch_create refuses any other value
 
 
 FLAG_WIDE = 1            # one decimation step less for every GFSK sonde (SONDE_FLAG_WIDE)
 FLAG_RS41_WIDE = FLAG_WIDE
 FLAG_SPLIT_FEC = 2
-FLAG_PIPELINE = 4        # mixed batches: class streams are not joined into the caller's stream (SONDE_FLAG_PIPELINE)
-FLAG_JOIN = 16           # launch units joined into the caller's stream at every submit (SONDE_FLAG_JOIN; rounds 1-4's default)
+FLAG_PIPELINE = 4        # launch units never joined into the caller's stream (SONDE_FLAG_PIPELINE; opt-in)
+FLAG_JOIN = 16           # accepted and ignored: joining at every submit is the default since round 6 (SONDE_FLAG_JOIN)
+FLAG_LATE_JOIN = 32      # launch units joined into the caller's stream ONE SUBMIT LATE (SONDE_FLAG_LATE_JOIN; opt-in: round 5's default)
 FLAG_WIDE_AUTO = 8       # SONDE_FLAG_WIDE for the types whose reference channel is >= 20 kHz only (iMS-100, MRZ-N1, M10)
 
 
 # every symbol include/sonde_abi.h declares; tests check the .so exports all of them
 ABI_SYMBOLS = [
     "sonde_batch_create", "sonde_batch_destroy", "sonde_batch_submit", "sonde_batch_submit_host",
-    "sonde_row_stride", "sonde_sample_bytes", "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_class_ms", "sonde_batch_read_bits",
+    "sonde_row_stride", "sonde_sample_bytes", "sonde_batch_wait_input", "sonde_batch_sync", "sonde_batch_frames", "sonde_batch_frames_of", "sonde_batch_ticket", "sonde_batch_overflow", "sonde_batch_kernel_ms", "sonde_batch_set_timing", "sonde_batch_class_ms", "sonde_batch_read_bits",
     "sonde_batch_launch_info", "sonde_batch_nbits", "sonde_batch_read_state", "sonde_batch_test_rs255", "sonde_batch_poll", "sonde_get_taps", "sonde_get_afsk_table", "sonde_parse_frame",
     "sonde_parser_create", "sonde_parser_feed", "sonde_parser_destroy", "sonde_rs41_temp", "sonde_rs41_rh", "sonde_dfm_temp", "sonde_rs41_pressure", "sonde_ozone_mpa",
     "sonde_m10_temp", "sonde_m10_rh", "sonde_m20_temp", "sonde_ims100_temp",
@@ -98,6 +104,7 @@ def load() -> C.CDLL:
     L.sonde_batch_submit_host.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
     L.sonde_batch_sync.argtypes = [vp]
     L.sonde_batch_sync.restype = C.c_long
+    L.sonde_batch_wait_input.argtypes = [vp, vp]
     L.sonde_batch_frames.argtypes = [vp, vp, C.c_size_t]
     L.sonde_batch_frames.restype = C.c_long
     if hasattr(L, "sonde_batch_frames_of"):

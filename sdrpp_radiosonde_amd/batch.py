@@ -79,8 +79,8 @@ class SondeBatch:
         if (is_iq and st[1:] != (2, 1)) or (not is_iq and st[1] != 1):
             raise SondeError("samples must be contiguous inside a channel (only the channel stride may be padded)")
         stride = samples.stride(0) // (2 if is_iq else 1)
-        # keep the device buffers of the last two submits alive: by default a submit of several launch units is joined into the
-        # caller's stream one submit late (include/sonde_abi.h), so the buffer of submit t may be read until submit t + 1 is queued
+        # keep the device buffers of the last two submits alive (Python-side lifetime only): with SONDE_FLAG_LATE_JOIN / _PIPELINE the
+        # buffer of submit t may be read until submit t + 1 is queued (include/sonde_abi.h); with default flags stream order covers it
         self._keep = (samples, getattr(self, "_keep", (None, None))[0])
         self._chk(self.L.sonde_batch_submit(self.h, C.c_void_p(samples.data_ptr()), n, stride, C.c_void_p(stream or 0)))
 
@@ -91,6 +91,10 @@ class SondeBatch:
         samples = np.ascontiguousarray(samples, dtype=want)
         n = samples.shape[1]
         self._chk(self.L.sonde_batch_submit_host(self.h, samples.ctypes.data_as(C.c_void_p), n, n))
+
+    def wait_input(self, stream: int | None = None):
+        """Device-side: work queued on `stream` after this call may overwrite the last submit's sample buffer (sonde_batch_wait_input)."""
+        self._chk(self.L.sonde_batch_wait_input(self.h, C.c_void_p(stream or 0)))
 
     def sync(self) -> int:
         return self._chk(self.L.sonde_batch_sync(self.h))
@@ -146,7 +150,7 @@ class SondeBatch:
         return {k: float(v[k]) for k in range(4) if n > 0 and v[k] >= 0.0}
 
     def launch_info(self) -> dict:
-        """{'units': launch units per submit, 'join': 0 at every submit / 1 one submit late (default) / 2 never} (sonde_batch_launch_info)"""
+        """{'units': launch units per submit, 'join': 0 at every submit (default) / 1 one submit late (FLAG_LATE_JOIN) / 2 never (FLAG_PIPELINE)} (sonde_batch_launch_info)"""
         u, j = C.c_uint32(), C.c_int32()
         self.L.sonde_batch_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
         self._chk(self.L.sonde_batch_launch_info(self.h, C.byref(u), C.byref(j)))

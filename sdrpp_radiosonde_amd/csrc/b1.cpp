@@ -35,8 +35,7 @@ static SondeB1Decoder *b1_init(int type, int samplerate, bool implemented)
 	if (samplerate != 48000) return nullptr;   // reference always passes OUT_SAMPLE_RATE, main.cpp:16,62-68
 	SondeB1Decoder *d = new SondeB1Decoder(type);
 	if (implemented) {
-		SondeBatchConfig cfg;
-		memset(&cfg, 0, sizeof(cfg));
+		SondeBatchConfig cfg = SONDE_BATCH_CONFIG_INIT;
 		const uint8_t t = (uint8_t)type;
 		cfg.n_channels = 1;
 		cfg.types = &t;

@@ -169,8 +169,8 @@ struct SondeBatch {
 	uint32_t *d_cls[4] = {};               // joined batches: the channel list of each class
 	int n_chunks = 1;
 	hipEvent_t ev_fork = nullptr;
-	// How a submit of several launch units completes (include/sonde_abi.h): 0 SONDE_FLAG_JOIN: the unit streams are joined into the
-	// caller's stream before sonde_batch_submit returns; 1 (default, round 5): one submit late -- submit t joins the units of submit
+	// How a submit of several launch units completes (include/sonde_abi.h): 0 (default): the unit streams are joined into the
+	// caller's stream before sonde_batch_submit returns; 1 SONDE_FLAG_LATE_JOIN: one submit late -- submit t joins the units of submit
 	// t - 1 into the caller's stream, so that a unit's submit t + 1 may start beside the other units' submit t; 2 SONDE_FLAG_PIPELINE:
 	// never.  In modes 1 and 2 done_stream collects the unit streams for completion (sonde_batch_sync, tickets).
 	int join_mode = 0;
@@ -228,6 +228,11 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 {
 	if (!cfg || !out) return fail("sonde_batch_create: null argument");
 	*out = nullptr;
+	//  a caller compiled against an older, shorter SondeBatchConfig, or one that did not zero the struct, must not hand
+	// over garbage in the members it does not know about: the size it was compiled with is part of the struct
+	if (cfg->struct_size != sizeof(SondeBatchConfig))
+		return fail("sonde_batch_create: SondeBatchConfig.struct_size != sizeof(SondeBatchConfig) -- initialise with SONDE_BATCH_CONFIG_INIT (a host built against an older sonde_abi.h must be recompiled)");
+	if (cfg->launch_units > 16) return fail("sonde_batch_create: launch_units must be 0 (the library's choice) or 1..16");
 	if (cfg->n_channels == 0) return fail("sonde_batch_create: n_channels == 0");
 	if (cfg->max_samples == 0 || cfg->max_samples % SONDE_TILE) return fail("sonde_batch_create: max_samples must be a positive multiple of SONDE_TILE");
 	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL && cfg->input_kind != SONDE_INPUT_IQ16 && cfg->input_kind != SONDE_INPUT_IQ8)
@@ -321,7 +326,8 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	// 0.565 -> 0.756, 8192 x 24 0.765 -> 0.782, 1024 x 96 (exactly one residency) 0.779 -> 0.789; three units: equal or worse
 	// (1250 x 24: 0.626); four and more: 0.38-0.63 (more streams than the hardware runs side by side).  SondeBatchConfig.launch_units
 	// overrides.  Round 5: also the DEFAULT (join_mode 1), with the caller's stream joined one submit late.
-	b->join_mode = (cfg->flags & SONDE_FLAG_PIPELINE) ? 2 : ((cfg->flags & SONDE_FLAG_JOIN) ? 0 : 1);
+	// Round 6: ordinary stream semantics are the default again (join_mode 0); the lagging join is SONDE_FLAG_LATE_JOIN
+	b->join_mode = (cfg->flags & SONDE_FLAG_PIPELINE) ? 2 : ((cfg->flags & SONDE_FLAG_LATE_JOIN) ? 1 : 0);
 	int one_class_units = 1;
 	if (b->join_mode != 0 && n_afsk == 0 && b->n_classes == 1) {
 		int n_types = 0;
@@ -548,9 +554,14 @@ int sd_batch_bins_capable(const SondeBatch *b)
 int sd_batch_submit_bins(SondeBatch *b, const SdBinsArgs *ba, size_t n_steps, void *stream_)
 {
 	if (!b || !ba || !ba->phases || !ba->carry_rows || !ba->g_comp || !sd_batch_bins_capable(b)) return fail("sd_batch_submit_bins: bad argument");
+	//  the launch-unit path knows nothing of phase rows: it would read them as float rows without an error
+	if (!b->units.empty()) return fail("sd_batch_submit_bins: the decoder batch behind a channelizer must be one plain launch (no launch units)");
 	const size_t n_out = n_steps / 5 * 12;
-	if (n_steps == 0 || n_steps % 2560 || n_out > b->max_samples || ba->row_stride < n_steps + 16 || (ba->row_stride & 1) || ((uintptr_t)ba->phases & 3u))
+	if (n_steps == 0 || n_steps % 2560 || n_out > b->max_samples || ba->row_stride < n_steps + 16)
 		return fail("sd_batch_submit_bins: n_steps must be a multiple of 2560 within max_samples");
+	//  sd_bins_kernel reads the rows as uint4 (eight phases) and writes the carry as dwords
+	if ((ba->row_stride & 7) || (ba->carry_stride & 7) || ((uintptr_t)ba->phases & 15u) || ((uintptr_t)ba->carry_rows & 15u))
+		return fail("sd_batch_submit_bins: phase rows and carry rows must be 16-byte aligned with strides that are multiples of 8 phases");
 	return submit_impl(b, ba->phases, n_out, ba->row_stride, stream_, ba);
 }
 
@@ -675,13 +686,33 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	return 0;
 }
 
+// Device-side release of the last submit's sample buffer on `stream_` (include/sonde_abi.h).  Unit batches: the units' join events of
+// the last submit (recorded behind each unit's last kernel: a superset of its readers); a plain launch: stream order on the submit's
+// own stream, an event recorded there now for any other stream.
+extern "C" int sonde_batch_wait_input(SondeBatch *b, void *stream_)
+{
+	if (!b) return fail("sonde_batch_wait_input: null argument");
+	if (b->tickets == 0) return 0;
+	HIPCHK(hipSetDevice(b->device));
+	hipStream_t stream = (hipStream_t)stream_;
+	if (!b->units.empty()) {
+		const int slot = (int)((b->tickets - 1) & 1);
+		for (const SondeBatch::Unit &u : b->units) HIPCHK(hipStreamWaitEvent(stream, u.ev_join[slot], 0));
+		return 0;
+	}
+	if (stream == b->last_stream) return 0;
+	HIPCHK(hipEventRecord(b->ev_xs, b->last_stream));
+	HIPCHK(hipStreamWaitEvent(stream, b->ev_xs, 0));
+	return 0;
+}
+
 // How the batch launches and joins (bench / tests label their figures with it): launch units per submit (1: one plain launch on the
 // caller's stream) and the join mode (0 at every submit, 1 one submit late, 2 never; only meaningful with more than one unit)
 extern "C" int sonde_batch_launch_info(const SondeBatch *b, uint32_t *n_units, int32_t *join_mode)
 {
 	if (!b) return fail("sonde_batch_launch_info: null argument");
 	if (n_units) *n_units = b->units.empty() ? 1u : (uint32_t)b->units.size();
-	if (join_mode) *join_mode = b->units.empty() ? 0 : b->join_mode;
+	if (join_mode) *join_mode = b->join_mode;      // what the FLAGS ask for, whatever the unit count (the contract does not depend on the device)
 	return 0;
 }
 

@@ -13,6 +13,7 @@
 // this submit (K5 / K6).  The arithmetic is SPEC 3.2 / 3.3 / 3.5b to the bit: same fmaf chains, same integer statistics; frames,
 // bits and loop state equal the oracle's (tests/test_channelizer.py).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "sonde_dev.h"
 #include "sd_math.h"
 #include "sd_wave.h"
@@ -378,11 +379,12 @@ void sd_launch_bins(uint32_t n_channels, hipStream_t stream, const int16_t *phas
 	// on a quarter of the CUs, as 256 workgroups of two waves each has a SIMD to itself
 	int wpw = BK_WAVES;
 	{
-		static int cus_of[64];                                   // (per device, asked once: 0 = not asked yet)
+		static std::atomic<int> cus_of[64];                      // (per device, asked once: 0 = not asked yet; atomics: hosts submit from several threads)
 		int dev = 0, cus = 256;
 		if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-			if (!cus_of[dev] && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cus_of[dev] = cus;
-			if (cus_of[dev]) cus = cus_of[dev];
+			int known = cus_of[dev].load(std::memory_order_relaxed);
+			if (!known && hipDeviceGetAttribute(&known, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && known > 0) cus_of[dev].store(known, std::memory_order_relaxed);
+			if (known > 0) cus = known;
 		}
 		while (wpw > 1 && (n_channels + wpw - 1) / wpw < (uint32_t)cus) wpw >>= 1;
 	}

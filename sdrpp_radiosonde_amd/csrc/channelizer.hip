@@ -530,14 +530,13 @@ static int chan_create(const uint8_t *types, uint32_t blocks_per_submit, uint32_
 	if (c->xcd_map && !dual && n_streams % 8 == 0) c->xcd_map = 2;      // a stream per XCD (the two banks of a dual object share their samples: they stay together)
 	const uint32_t n_out = c->n_steps * RS_UP / RS_DN;
 	const size_t nb = (size_t)n_streams * CH_M;              // bins of all streams: the decoder batch's channels, stream-major
-	SondeBatchConfig cfg;
-	memset(&cfg, 0, sizeof(cfg));
+	SondeBatchConfig cfg = SONDE_BATCH_CONFIG_INIT;
 	cfg.n_channels = (uint32_t)nb;
 	cfg.types = types;
 	cfg.max_samples = n_out;
 	cfg.input_kind = SONDE_INPUT_REAL;
 	cfg.device = device;
-	cfg.flags = SONDE_FLAG_JOIN;                             // the bins decoder is one launch behind the filter bank, in the caller's stream
+	cfg.flags = 0;                                           // default completion: the bins decoder is one launch behind the filter bank, in the caller's stream
 	if (sonde_batch_create(&cfg, &c->batch) != 0) { delete c; return -1; }
 	std::vector<float> h, tw, g;
 	make_tables(h, tw, g);
@@ -614,7 +613,8 @@ static bool chan_overlap_setup(SondeChannelizer *c)
 	const size_t nb = (size_t)c->n_streams * CH_M;
 	bool ok = hipStreamCreateWithFlags(&c->s_pfb, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->s_dec, hipStreamNonBlocking) == hipSuccess &&
 	          hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess &&
-	          hipMalloc((void **)&c->d_bins_b, nb * c->n_steps * sizeof(float)) == hipSuccess;
+	          hipMalloc((void **)&c->d_bins_b, nb * ((size_t)c->n_steps + PH_HEAD) * sizeof(int16_t)) == hipSuccess &&      // the layout of d_bins: [PH_HEAD carried | n_steps] 16-bit phases
+	          hipMemset(c->d_bins_b, 0, nb * ((size_t)c->n_steps + PH_HEAD) * sizeof(int16_t)) == hipSuccess;
 	for (int i = 0; i < 2 && ok; i++)
 		ok = hipEventCreateWithFlags(&c->ev_pfb[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess &&
 		     hipEventCreateWithFlags(&c->ev_dec[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;

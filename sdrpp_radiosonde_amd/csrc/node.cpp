@@ -105,8 +105,7 @@ extern "C" int sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out)
 		if (e == hipSuccess) e = hipMalloc(&n->rows[d], (size_t)n->count[d] * n->rows_stride_max * n->elem);
 		if (e == hipSuccess) e = hipMalloc(&n->rows_b[d], (size_t)n->count[d] * n->rows_stride_max * n->elem);
 		if (e != hipSuccess) { sonde_node_destroy(n); return nfail("sonde_node_create: stream / rows", hipGetErrorString(e)); }
-		SondeBatchConfig bc;
-		memset(&bc, 0, sizeof(bc));
+		SondeBatchConfig bc = SONDE_BATCH_CONFIG_INIT;
 		bc.n_channels = n->count[d];
 		bc.types = cfg->types ? cfg->types + n->first[d] : nullptr;
 		bc.max_samples = cfg->max_samples;

@@ -29,7 +29,7 @@ int main(int argc, char **argv)
 	float *d_iq = nullptr;
 	if (hipMalloc((void **)&d_iq, iq.size() * sizeof(float)) != hipSuccess) { printf("ERROR hipMalloc\n"); return 1; }
 	hipMemcpy(d_iq, iq.data(), iq.size() * sizeof(float), hipMemcpyHostToDevice);
-	SondeBatchConfig cfg = {};
+	SondeBatchConfig cfg = SONDE_BATCH_CONFIG_INIT;
 	cfg.n_channels = C;
 	cfg.max_samples = (uint32_t)(n / parts);
 	cfg.input_kind = SONDE_INPUT_IQ;

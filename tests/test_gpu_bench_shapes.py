@@ -1,9 +1,9 @@
 """-m gpu: every number of the driver's bench line has a parity test at ITS shape and ITS flags.
 
 bench.py entry                      test here
-other_configs.mix4096               test_mix4096_five_blocks_back_to_back[0]          (default flags: joined one submit late; [4]: SONDE_FLAG_PIPELINE)
+other_configs.mix4096 / _late_join  test_mix4096_five_blocks_back_to_back[0 / 32]     (default flags: joined at every submit; [32]: SONDE_FLAG_LATE_JOIN; [4]: SONDE_FLAG_PIPELINE)
 low_snr                             test_headline_shape_at_9_db                        (1024 x 96 tiles, Eb/N0 9 dB)
-other_configs.rt1250, ch1280x96     test_part_filled_last_generation[1250-24-4 / 1280-96-4]  (not a multiple of one residency; pipelined, two units)
+other_configs.rt1250, ch1280x96     test_part_filled_last_generation[1250-24-0 / 1280-96-0] and [..-32] (not a multiple of one residency; default and late-joined)
 other_configs.wideband8x4           tests/test_channelizer.py::test_fused_channelizer_frames_equal_oracle[4-8]
 other_configs.rt1250_host_e2e       test_host_path_at_the_target_shape                 (1250 channels x 1 s from host memory to SondeData fragments)
 other_configs.cs16_1024x96, cs16_8192x24   test_16_bit_rows_at_the_bench_shapes[1024-96 / 8192-24]  (SONDE_INPUT_IQ16 rows on the recommended stride)
@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from sdrpp_radiosonde_amd import synth
-from sdrpp_radiosonde_amd._lib import FLAG_JOIN, FLAG_PIPELINE
+from sdrpp_radiosonde_amd._lib import FLAG_JOIN, FLAG_LATE_JOIN, FLAG_PIPELINE
 from sdrpp_radiosonde_amd.batch import SondeBatch, strided_rows
 
 pytestmark = pytest.mark.gpu
@@ -32,10 +32,15 @@ def _key(a):
     return a[np.lexsort((a["bitpos"], a["channel"]))]
 
 
-@pytest.mark.parametrize("flags", [0, FLAG_PIPELINE])
+def _join_of(flags):
+    return 2 if flags & FLAG_PIPELINE else (1 if flags & FLAG_LATE_JOIN else 0)
+
+
+@pytest.mark.parametrize("flags", [0, FLAG_LATE_JOIN, FLAG_PIPELINE])
 def test_mix4096_five_blocks_back_to_back(oracle, flags):
     """BASELINE configs[2] as bench.py measures it: RS41 / M10 / DFM09 by channel % 3, 4096 channels x 24 tiles per submit,
-    five consecutive blocks, at the DEFAULT flags (round 5: every type's kernels keep their own stream, the caller's stream is joined
+    five consecutive blocks, at the DEFAULT flags (round 6: ordinary stream semantics, every submit joined into the caller's stream),
+    with SONDE_FLAG_LATE_JOIN (every type's kernels keep their own stream, the caller's stream is joined
     one submit late) and with SONDE_FLAG_PIPELINE (never joined), rows on
     the recommended stride.  (a) two submits in flight, frames per ticket: all frames byte for byte the oracle's over the
     whole 120-tile signal; (b) all five submits queued with NO host interaction in between (the bench's loop): the frames of
@@ -62,7 +67,8 @@ def test_mix4096_five_blocks_back_to_back(oracle, flags):
 
     # (a) tickets, two submits in flight
     b = SondeBatch(C, n, types=types, flags=flags)
-    assert b.launch_info() == {"units": 3, "join": 2 if flags else 1}
+    info = b.launch_info()
+    assert info["join"] == _join_of(flags) and info["units"] >= 2
     b.ticket()
     per_ticket = []
     for k in range(NB):
@@ -112,19 +118,21 @@ def test_headline_shape_at_9_db(oracle):
         assert any(np.array_equal(tx[8:], f["data"][8: f["len"]]) for _, tx in sb.frames[f["channel"]])
 
 
-@pytest.mark.parametrize("C,tiles,flags", [(1250, 24, 0), (1280, 96, 0), (1250, 24, FLAG_PIPELINE), (1250, 48, FLAG_JOIN), (1537, 24, 0)])
+@pytest.mark.parametrize("C,tiles,flags", [(1250, 24, 0), (1280, 96, 0), (1250, 24, FLAG_LATE_JOIN), (1280, 96, FLAG_LATE_JOIN), (1250, 24, FLAG_PIPELINE),
+                                           (1250, 48, FLAG_JOIN), (1537, 24, 0), (1537, 24, FLAG_LATE_JOIN)])
 def test_part_filled_last_generation(oracle, C, tiles, flags):
     """Channel counts that are not a multiple of one residency (4 workgroups x 256 CUs): 1250 x 24 tiles = bench.py's rt1250 (the
-    north_star's per-GPU share of 10^4 channels, one second per submit), 1280 x 96 = ch1280x96, both as the bench runs them (round 5):
-    at the DEFAULT flags, i.e. two launch units on their own streams joined into the caller's stream one submit late, submits queued
-    back to back (frames per ticket, two in flight); the same never joined (SONDE_FLAG_PIPELINE); 1250 x 48 joined at every submit
-    (SONDE_FLAG_JOIN: one launch); 1537 = 1.5 residencies + 1.  Four consecutive submits; frames, bit counts and loop state against
-    the oracle."""
+    north_star's per-GPU share of 10^4 channels, one second per submit), 1280 x 96 = ch1280x96, both as the bench runs them (round 6):
+    at the DEFAULT flags (ordinary stream semantics) and with SONDE_FLAG_LATE_JOIN (two launch units on their own streams joined into
+    the caller's stream one submit late), submits queued back to back (frames per ticket, two in flight); the same never joined
+    (SONDE_FLAG_PIPELINE); SONDE_FLAG_JOIN (round 5's opt-out) is the default spelled out; 1537 = 1.5 residencies + 1.  Four
+    consecutive submits; frames, bit counts and loop state against the oracle."""
     n, NS = tiles * TILE, 4
     sb = synth.make_rs41_batch(C, NS * n, seed=1250 + C, ebn0_db=13.0, device="cuda:0")
     blocks = [strided_rows(sb.iq[:, k * n: (k + 1) * n].contiguous()) for k in range(NS)]
     b = SondeBatch(C, n, flags=flags)
-    assert b.launch_info() == {"units": 1, "join": 0} if flags & FLAG_JOIN else b.launch_info() == {"units": 2, "join": 2 if flags else 1}
+    info = b.launch_info()
+    assert info["join"] == _join_of(flags) and (info["units"] == 2 if _join_of(flags) else info["units"] >= 1)
     st = torch.cuda.current_stream().cuda_stream
     parts = []
     if not flags & FLAG_JOIN:
@@ -151,30 +159,93 @@ def test_part_filled_last_generation(oracle, C, tiles, flags):
         assert b.nbits(c) == len(ch.bits())
 
 
-def test_default_join_is_one_submit_late():
-    """include/sonde_abi.h, "how a submit completes on the caller's stream": at the default flags work queued on the caller's stream
-    behind sonde_batch_submit t is ordered behind submit t - 1.  An event recorded on the caller's stream right after submit 2 has
-    completed => submit 1 has completed (its frames are there without any further wait); with SONDE_FLAG_JOIN the same event
-    covers submit 2 itself.  Channel counts that fill whole residencies stay one plain launch (stream order as ever)."""
-    C, n = 1250, 24 * TILE
-    sb = synth.make_rs41_batch(C, 2 * n, seed=77, ebn0_db=16.0, device="cuda:0")
-    blocks = [strided_rows(sb.iq[:, k * n: (k + 1) * n].contiguous()) for k in range(2)]
+def test_completion_contract_depends_on_the_flags_only():
+    """include/sonde_abi.h, "how a submit completes on the caller's stream" (ADVICE r5): flags 0 = ordinary stream
+    semantics WHATEVER the channel count, the mix of types or the device's CU count; the lagging join and the never-joined mode are
+    opt-in flags.  sonde_batch_launch_info reports the mode the flags ask for."""
+    n = 24 * TILE
+    mixed = np.array([(0, 3, 1)[c % 3] for c in range(96)], dtype=np.uint8)
+    for flags in (0, FLAG_JOIN, FLAG_LATE_JOIN, FLAG_PIPELINE):
+        for C, types in ((4, None), (1024, None), (1250, None), (2048, None), (96, mixed)):
+            b = SondeBatch(C, n, types=types, flags=flags)
+            assert b.launch_info()["join"] == _join_of(flags), (flags, C)
+            b.close()
+
+
+@pytest.mark.parametrize("flags", [0, FLAG_LATE_JOIN, FLAG_PIPELINE])
+@pytest.mark.parametrize("shape", ["rs41_1250", "mixed_1536"])
+def test_sample_buffer_may_be_rewritten_on_the_callers_stream(oracle, flags, shape):
+    """VERDICT r5 item 3's acceptance test.  ONE sample buffer, refilled on the caller's stream right behind every submit (an
+    asynchronous device copy -- what a streaming host's DMA does; /root/reference/src/decode/decoder.hpp:59-117 flushes the stream
+    buffer right after X_decode returns).  Default flags: nothing else to do (stream order).  SONDE_FLAG_LATE_JOIN /
+    SONDE_FLAG_PIPELINE: sonde_batch_wait_input on that stream before the copy.  Shapes that are cut into launch units (1250 RS41
+    channels: a part-filled generation; a mixed batch: one unit per type).  Frames of all submits: the oracle's, byte for byte."""
+    tiles, NS = 12, 6
+    n = tiles * TILE
+    if shape == "rs41_1250":
+        C, types, order = 1250, None, (0,)
+    else:
+        C, order = 1536, (0, 3, 1)
+        types = np.array([order[c % 3] for c in range(C)], dtype=np.uint8)
+    iq = torch.empty((C, NS * n, 2), dtype=torch.float32, device="cuda:0")
+    refs = []
+    for t in order:
+        idx = np.arange(C) if types is None else np.nonzero(types == t)[0]
+        sb = synth.make_batch(int(t), len(idx), NS * n, seed=3300 + int(t), ebn0_db=15.0, device="cuda:0")
+        iq[torch.from_numpy(idx).to("cuda:0")] = sb.iq
+        r = oracle.batch_run(int(t), sb.iq.cpu().numpy(), nthreads=CORES)
+        r["channel"] = idx[r["channel"]]
+        refs.append(r)
+        del sb
+    ref = _key(np.concatenate(refs))
+    blocks = [iq[:, k * n: (k + 1) * n].contiguous() for k in range(NS)]
+    del iq
+    buf = strided_rows(blocks[0].clone())                 # THE buffer: every submit reads it, every copy overwrites it
+    torch.cuda.synchronize()
     s = torch.cuda.Stream()
-    for flags in (0, FLAG_JOIN):
-        b = SondeBatch(C, n, flags=flags)
-        b.ticket()
-        with torch.cuda.stream(s):
-            b.submit(blocks[0], s.cuda_stream)
-            b.submit(blocks[1], s.cuda_stream)
-            ev = torch.cuda.Event()
-            ev.record(s)
-        ev.synchronize()
-        # whatever the join mode, the event behind submit 2 covers submit 1: its counts can be read at once
-        assert len(b.frames_of(1)) >= C // 2
-        assert len(b.frames_of(2)) >= C // 2
-        b.close()
-    assert SondeBatch(1024, n).launch_info() == {"units": 1, "join": 0}
-    assert SondeBatch(2048, n).launch_info() == {"units": 1, "join": 0}
+    b = SondeBatch(C, n, types=types, flags=flags)
+    assert b.launch_info()["join"] == _join_of(flags)
+    b.ticket()
+    parts = []
+    with torch.cuda.stream(s):
+        for k in range(NS):
+            b.submit(buf, s.cuda_stream)
+            if flags:
+                b.wait_input(s.cuda_stream)               # device-side; the host does not wait
+            if k + 1 < NS:
+                buf.copy_(blocks[k + 1], non_blocking=True)      # queued on s right behind the submit
+            if k >= 1:
+                parts.append(b.frames_of(k))
+        parts.append(b.frames_of(NS))
+    got = _key(np.concatenate(parts))
+    b.close()
+    assert len(ref) >= C and got.tobytes() == ref.tobytes()
+
+
+def test_wait_input_releases_the_buffer_on_another_stream(oracle):
+    """sonde_batch_wait_input with a stream that is NOT the submit's: a copy engine's stream may refill the buffer behind it (one
+    plain launch, 1024 channels: the event is recorded on the submit's stream at the call)."""
+    C, tiles, NS = 1024, 12, 4
+    n = tiles * TILE
+    sb = synth.make_rs41_batch(C, NS * n, seed=515, ebn0_db=15.0, device="cuda:0")
+    ref = _key(oracle.batch_run(0, sb.iq.cpu().numpy(), nthreads=CORES))
+    blocks = [sb.iq[:, k * n: (k + 1) * n].contiguous() for k in range(NS)]
+    buf = strided_rows(blocks[0].clone())
+    torch.cuda.synchronize()
+    s, cp = torch.cuda.Stream(), torch.cuda.Stream()
+    b = SondeBatch(C, n)
+    parts = []
+    for k in range(NS):
+        s.wait_stream(cp)                                  # the submit reads what the copy stream wrote
+        b.submit(buf, s.cuda_stream)
+        b.wait_input(cp.cuda_stream)
+        if k + 1 < NS:
+            with torch.cuda.stream(cp):
+                buf.copy_(blocks[k + 1], non_blocking=True)
+        parts.append(b.frames().copy())
+    got = _key(np.concatenate(parts))
+    b.close()
+    assert got.tobytes() == ref.tobytes()
 
 
 def test_host_path_at_the_target_shape(oracle):

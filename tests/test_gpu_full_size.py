@@ -58,7 +58,7 @@ def test_config2_1024_rs41_channels_full_size(oracle):
     assert b2.frames().tobytes() == got.tobytes()
 
 
-@pytest.mark.parametrize("flags", [0, 16])       # the default (launch units joined one submit late) and SONDE_FLAG_JOIN (every submit)
+@pytest.mark.parametrize("flags", [0, 32])       # the default (every submit joined into the caller's stream) and SONDE_FLAG_LATE_JOIN (launch units joined one submit late)
 def test_config3_4096_mixed_channels_full_size(oracle, flags):
     C, n = 4096, 32 * TILE
     order = (0, 3, 1)                                     # RS41, M10, DFM09 by channel % 3

@@ -14,18 +14,18 @@ pytestmark = pytest.mark.gpu
 TILE = 2048
 
 
-@pytest.mark.parametrize("ebn0,seed,flags,cfo", [(5.0, 1, 0, 500.0), (7.5, 2, 4, 500.0), (10.0, 3, 0, 2500.0), (12.5, 4, 4, 2000.0)])
+@pytest.mark.parametrize("ebn0,seed,flags,cfo", [(5.0, 1, 0, 500.0), (7.5, 2, 4, 500.0), (10.0, 3, 0, 2500.0), (12.5, 4, 32, 2000.0)])
 def test_mixed_batch_low_snr_bit_exact(ebn0, seed, flags, cfo):
     run_mixed(ebn0, seed, check_coverage=True, flags=flags, cfo_max_hz=cfo)
 
 
-@pytest.mark.parametrize("ebn0,seed,flags,bits", [(7.5, 5, 0, 16), (11.0, 6, 4, 16), (9.0, 7, 4, 8), (12.0, 8, 0, 8)])
+@pytest.mark.parametrize("ebn0,seed,flags,bits", [(7.5, 5, 0, 16), (11.0, 6, 4, 16), (9.0, 7, 32, 8), (12.0, 8, 0, 8)])
 def test_mixed_batch_as_16_bit_iq_bit_exact(ebn0, seed, flags, bits):
     run_mixed(ebn0, seed, check_coverage=False, flags=flags, cfo_max_hz=1500.0, iq16=bits if bits == 8 else True)
 
 
 def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0, iq16=False):
-    """(also driven by tools/fuzz_campaign.py over many seeds)  flags & 4 (SONDE_FLAG_PIPELINE): the submits are queued with two
+    """(also driven by tools/fuzz_campaign.py over many seeds)  flags & 4 (SONDE_FLAG_PIPELINE) or 32 (SONDE_FLAG_LATE_JOIN): the submits are queued with two
     in flight and the frames fetched per ticket; the state is compared at the end.  cfo_max_hz: carrier offsets up to this
     (the AFC of SPEC 3.0b at work; beyond +-2 kHz frames are lost on both sides alike).  iq16: the rows go to the GPU as 16-bit
     integers (SONDE_INPUT_IQ16, full scale 4096 per unit amplitude: the quantisation is part of the signal), the oracle gets the same
@@ -55,7 +55,7 @@ def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0, iq16=False)
     chs = [oracle_lib.Channel(int(types[c]), c) for c in range(C)]
     x = iq.numpy()
     total = 0
-    if flags & 4:
+    if flags & (4 | 32):
         st_ = torch.cuda.current_stream().cuda_stream
         b.ticket()
         parts = []

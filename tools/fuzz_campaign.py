@@ -18,7 +18,7 @@ t0 = time.time()
 for i in range(n):
     ebn0 = float(rng.uniform(4.0, 16.0))
     seed = int(rng.integers(10, 10_000))
-    flags = int(rng.choice([0, 0, 4, 16]))                              # the default (joined one submit late), SONDE_FLAG_PIPELINE, SONDE_FLAG_JOIN
+    flags = int(rng.choice([0, 0, 4, 32]))                              # the default (joined at every submit), SONDE_FLAG_PIPELINE, SONDE_FLAG_LATE_JOIN
     cfo = float(rng.choice([500.0, 1500.0, 2500.0]))                    # carrier offsets: the AFC of SPEC 3.0b
     iq16 = (False, False, True, 8)[int(rng.integers(0, 4))]              # a quarter of the batches as 16-bit integer IQ rows (SONDE_INPUT_IQ16), a quarter as 8-bit (IQ8)
     total = fz.run_mixed(ebn0, seed, check_coverage=False, flags=flags, cfo_max_hz=cfo, iq16=iq16)      # raises on the first differing bit, state or frame
