@@ -106,8 +106,8 @@ def parse_args():
                     help="layout of the resident IQ blocks: rows on the library's recommended channel stride (sonde_row_stride: the next power of "
                          "two in bytes, 2 MiB for the headline's 1.5 MiB rows; measured 2.3-5.5 %% faster, profiles/r3_stride_sweep.txt) or back to back")
     ap.add_argument("--scatter", action="store_true", help="(the default with --gpus > 1) ingest on rank 0 and scatter IQ shards over RCCL before timing")
-    ap.add_argument("--scatter-torch", action="store_true", help="scatter through torch.distributed instead of libsonde_rccl.so")
-    ap.add_argument("--multiproc", action="store_true", help="--gpus > 1: one process per GPU (torch.distributed ranks, libsonde_rccl's sonde_shard_* scatter) instead of the default: ONE "
+    ap.add_argument("--scatter-torch", action="store_true", help="(kept for old command lines: --multiproc always scatters through torch.distributed now)")
+    ap.add_argument("--multiproc", action="store_true", help="--gpus > 1: one process per GPU (torch.distributed ranks, torch.distributed.scatter of the ingest blocks) instead of the default: ONE "
                     "process driving every GPU through the native node-level host (sonde_node_*, ncclCommInitAll)")
     ap.add_argument("--node", action="store_true", help="run through the node-level host even with --gpus 1 (a node of one device: test hook)")
     ap.add_argument("--rank-local", action="store_true", help="--gpus > 1: every rank generates its own shard (no scatter): kernel scaling without xGMI time")
@@ -789,30 +789,17 @@ def run_channels(args, rank, local_rank, world, dev, dist, barrier, reduce_max_s
 
 
 def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
-    """Multi-GPU ingest as north_star names it: rank 0 holds the IQ of ALL channels of one block at a time (generated block by
-    block: synth.make_rs41_cyclic_block), scatters it with the native grouped ncclSend / ncclRecv (csrc/shard_rccl.cpp,
-    SURVEY 8e) -- or --scatter-torch: dist.scatter -- and frees it.  The scatters are outside the timed region (inputs are
-    resident when timing starts); their time and rate are reported beside the 7-link xGMI egress bound."""
+    """--multiproc (one process per GPU): rank 0 holds the IQ of ALL channels of one block at a time (generated block by block:
+    synth.make_rs41_cyclic_block), scatters it with torch.distributed.scatter (RCCL over xGMI with backend nccl) and frees it.  The
+    scatters are outside the timed region (inputs are resident when timing starts); their time and rate are reported beside the 7-link
+    xGMI egress bound.  (The native scatter lives in the ONE-process node host, run_node below: round 6 retired the second, rank-per-GPU
+    native stack.)"""
     from sdrpp_radiosonde_amd import synth
     from sdrpp_radiosonde_amd.shard import scatter_iq
     C, n, NB = args.channels, args.tiles * 2048, args.blocks
     cyc = NB > 1 and cyclic_ok(n, NB)
-    strided = getattr(args, "row_stride", "pow2") == "pow2" and not args.stride_pad
     if not cyc:
         NB = 1                                   # no seamless cycle of this shape: one block, re-submitted
-    ns, fallback = None, ""
-    if not args.scatter_torch:
-        from sdrpp_radiosonde_amd.shard import NativeShard
-        try:
-            ns = NativeShard(local_rank)
-        except Exception as e:                     # (library missing / communicator refused: the same on every rank)
-            fallback = f"{type(e).__name__}: {e}"
-        ok = torch.tensor([1 if ns is not None else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:                    # every rank takes the same path: torch.distributed's scatter (RCCL as well)
-            ns, args.scatter_torch = None, True
-            if rank == 0:
-                print(f"bench: native scatter unavailable ({fallback or 'another rank failed'}); using torch.distributed scatter", file=sys.stderr)
     blocks, ms = [], 0.0
     for k in range(NB):
         full = None
@@ -822,13 +809,7 @@ def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
         torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
-        if ns is not None and strided:
-            from sdrpp_radiosonde_amd.batch import row_stride, strided_rows
-            if rank == 0:
-                full = strided_rows(full)            # the ingest block on the decoder's recommended stride: a peer's shard is ONE send
-            blk = ns.scatter_rows(full, world * C, n, root=0, src_stride=row_stride(n))      # straight into the rows the decoder reads
-        else:
-            blk = ns.scatter_iq(full, (C, n, 2), root=0) if ns is not None else scatter_iq(full, C, n, dev, src=0)
+        blk = scatter_iq(full, C, n, dev, src=0)
         torch.cuda.synchronize()
         ms += (time.perf_counter() - t0) * 1e3
         blocks.append(blk)
@@ -838,10 +819,8 @@ def scattered_blocks(args, rank, local_rank, world, dev, dist, barrier):
     gbs = sent / (ms * 1e-3) / 1e9
     bound = 7 * 153.0                                        # GB/s: all seven xGMI links of the root at once
     return blocks, None, {
-        "ingest": "scatter from rank 0: torch.distributed" if args.scatter_torch else
-                  ("scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv, one per peer, ingest block and decoder rows on the recommended channel stride)" if strided
-                   else "scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv)"),
-        "rows_delivered_strided": bool(ns is not None and strided),
+        "ingest": "scatter from rank 0: torch.distributed.scatter",
+        "rows_delivered_strided": False,
         "ms": round(ms, 3), "blocks": NB, "bytes_from_root": sent, "gbs": round(gbs, 2),
         "root_egress_bound_gbs": bound, "frac_of_bound": round(gbs / (bound * min(1.0, (world - 1) / 7.0)), 4),
         "note": "root holds one block of all ranks at a time; outside the timed region"}
@@ -899,14 +878,21 @@ def run_node(args, launched_ranks=1):
     alg = alg_bytes_of(C, n)                        # per GPU
     demod_ms = max((k[0] for k in kern if k), default=0.0)
     demod_ms = min(demod_ms, ms_per_step) if demod_ms > 0 else ms_per_step
-    # ---- the ingest path: all channels on GPU 0 (one block), scattered per step; then the frame gather
-    scatter = None
+    # ---- the ingest path: all channels on GPU 0 (one block), scattered per step; then the frame gather.  The ingest block lies BACK TO
+    # BACK (include/sonde_node.h's recommendation: one send per peer straight from the buffer, exactly the shard's bytes, no packing pass)
+    scatter, with_scatter = None, None
     try:
-        st_full = row_stride(n) if getattr(args, "row_stride", "pow2") == "pow2" else n
+        st_full = n
         full = torch.empty((N * C, st_full, 2), dtype=torch.float32, device=devs[0])[:, :n]
         for d in range(N):
             full[d * C: (d + 1) * C] = shards[d][0].to(devs[0])
         torch.cuda.synchronize(0)
+        # (a) the SAME K steps with the scatter INSIDE the timed region: every step = sonde_node_submit of the ingest block (scatter over
+        # xGMI + the ingest GPU's own strided copy + every device's decode), bracketed like the headline
+        def submit_ingest():
+            node.submit(full)
+        dt_s = ramp_and_time(submit_ingest, sync_all, args, sync_all)
+        with_scatter = {"value": round(samples_per_step * args.steps / dt_s / 1e6, 3), "ms_per_step": round(dt_s / args.steps * 1e3, 4)}
         ms, gms, nby, nsend, gby = [], [], 0, 0, 0
         for k in range(6):
             node.submit(full)
@@ -917,13 +903,14 @@ def run_node(args, launched_ranks=1):
             nby, nsend, gby = sst["bytes_from_ingest"], sst["sends"], gst["bytes"]
         bound = 7 * 153.0 * min(1.0, (N - 1) / 7.0)             # GB/s: the ingest GPU's xGMI links towards its N - 1 peers
         sms = sum(ms) / len(ms)
-        scatter = {"ingest": "sonde_node_submit: IQ of all channels on GPU 0 -> grouped ncclSend / ncclRecv straight into every peer's decoder rows "
-                             f"({'one send per peer, rows on the recommended stride (padding travels too)' if st_full != n else 'one send per peer of exactly the shard, rows back to back'})",
+        scatter = {"ingest": "sonde_node_submit: IQ of all channels on GPU 0 (rows back to back) -> grouped ncclSend / ncclRecv straight into every peer's decoder rows: "
+                             "one send per peer of exactly the shard's bytes",
                    "ms": round(sms, 3), "bytes_from_ingest": nby, "sends": nsend, "gbs": round(nby / (sms * 1e-3) / 1e9, 2) if sms > 0 else None,
                    "ingest_egress_bound_gbs": round(bound, 1), "frac_of_bound": round(nby / (sms * 1e-3) / 1e9 / bound, 4) if (sms > 0 and N > 1) else None,
                    "gather_ms": round(sum(gms) / len(gms), 3), "gather_bytes": gby, "frames_gathered": int(len(fr)),
-                   "note": "outside the timed region (the contract times resident inputs): averages of 5 steps after RCCL's first-call set-up; "
-                           "gather = frame records of every device copied to host memory (one process: nothing travels back over xGMI)"}
+                   "note": "per-step device time of the scatter alone and host time of the gather alone: averages of 5 steps after RCCL's first-call set-up; "
+                           "gather = frame records of every device copied to host memory (one process: nothing travels back over xGMI); "
+                           "value_with_scatter (top level) is the whole step with this scatter inside the timed region"}
     except Exception as e:                          # (never lets the line fail)
         scatter = {"error": f"{type(e).__name__}: {e}"}
     node.close()
@@ -932,10 +919,10 @@ def run_node(args, launched_ranks=1):
         "steps": args.steps, "warmup": args.warmup, "ramp_ms": args.ramp_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"RS41-SG x {C} channels/GPU x {n} samples per step (4800 Bd GFSK, 48 kS/s, Eb/N0 {args.ebn0} dB); {NB} consecutive blocks of a continuous signal resident in every GPU's HBM, cycled",
-                   "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{N} (contiguous ranges, sonde_shard_range)", "flags": args.flags,
+                   "channels_per_gpu": C, "samples_per_channel": n, "sharding": f"channels/{N} (contiguous ranges, sonde_node_shard_range)", "flags": args.flags,
                    "channel_stride_samples": int(shards[0][0].stride(0) // 2),
                    "host": f"ONE process, sonde_node_* (libsonde_rccl.so: ncclCommInitAll over {N} device(s), one SondeBatch per device); ranks launched by the caller: {launched_ranks}",
-                   "ingest": "resident shards (sonde_node_submit_local) in the timed region; scatter from GPU 0 measured beside it"},
+                   "ingest": "value: resident shards (sonde_node_submit_local) in the timed region; value_with_scatter: ingest on GPU 0, scatter inside the timed region"},
         "frames_per_s": round(nfr * args.steps / dt, 1), "frames_per_step_steady": round(nfr, 2),
         "realtime_channels": round(msps * 1e6 / 48000.0, 1),
         "kernel_ms": {"demod_per_device": [round(k[0], 4) if k else None for k in kern], "framer_fec_per_device": [round(k[1], 4) if k else None for k in kern],
@@ -950,6 +937,14 @@ def run_node(args, launched_ranks=1):
     }
     if scatter and "ms" in scatter:
         out["scatter_ms"], out["gather_ms"] = scatter["ms"], scatter["gather_ms"]
+    # BOTH figures, each labelled: `value` = the contract's (inputs resident in every GPU's HBM when the timed region
+    # starts); `value_with_scatter` = the same K steps with the IQ of all channels arriving on GPU 0 and scattered over xGMI inside the region
+    out["value_label"] = "shards RESIDENT in every GPU's HBM (sonde_node_submit_local): scatter outside the timed region"
+    if with_scatter is not None:
+        out["value_with_scatter"] = with_scatter["value"]
+        out["ms_per_step_with_scatter"] = with_scatter["ms_per_step"]
+        out["value_with_scatter_label"] = ("the same K steps, every step = sonde_node_submit of the ingest block on GPU 0: RCCL scatter over xGMI (exactly the "
+                                           "shards' bytes) + every device's decode INSIDE the timed region")
     return out
 
 

@@ -3,23 +3,25 @@
  * north_star: "C++ host code ... independent narrowband channels are batched one-per-workgroup and sharded across the 8 GPUs of
  * one node with an RCCL scatter of IQ blocks over xGMI".  The reference's unit is one module instance per channel, any number
  * of instances, no shared state (SDRPP_MOD_INFO max instances -1, /root/reference/src/main.cpp:18-24): a node-level host is an
- * object that owns ALL channels of the node, shards them in contiguous ranges (sonde_shard_range: device d of D gets
+ * object that owns ALL channels of the node, shards them in contiguous ranges (sonde_node_shard_range: device d of D gets
  * [d C / D, (d + 1) C / D), remainders to the first devices), and hands back SondeData fragments with node-wide channel numbers
  * (the callback of /root/reference/src/main.cpp:320-331, once per channel).
  *
  * Data path of one sonde_node_submit(): the IQ of all channels sits on the INGEST device (an SDR front-end attached to one
- * GPU); every other device receives its shard over xGMI straight into the rows its decoder reads -- rows on the recommended
- * channel stride (sonde_row_stride), no re-stride copy -- as ONE group of ncclSend (ingest device, one per peer and row run) and
- * ncclRecv (peers); the ingest device's own shard is a strided device copy, not a send to itself; then every device runs its
- * own sonde_batch_submit.  There is no other collective: channels are independent.  Frames come back per device straight to
+ * GPU); every other device receives its shard over xGMI straight into the rows its decoder reads, as groups of ncclSend (ingest
+ * device) / ncclRecv (peers); the ingest device's own shard is a strided device copy, not a send to itself; then every device runs
+ * its own sonde_batch_submit.  There is no other collective: channels are independent.  Frames come back per device straight to
  * host memory (one process: the host is shared; nothing travels back over xGMI).
  *
- * Shape of the transfer, by the layout of the ingest rows: on the recommended stride (channel_stride == sonde_row_stride(n_samples))
- * a peer's shard is one contiguous run, padding included: ONE send per peer, the rows land on that stride.  Back to back
- * (channel_stride == n_samples): ONE send per peer of exactly the shard's bytes, the rows land back to back and are decoded from
- * there (the decoder takes any stride; back-to-back rows cost it about 5 %, a re-stride copy on the peer would cost more).  Any other
- * stride: one send per row (256 rows of every peer per group).  Round 4 sent row by row whenever the ingest block was not on the
- * recommended stride: 57 344 sends per block of BASELINE config 5.
+ * ONLY THE ROWS' BYTES CROSS xGMI (round 6), whatever the layout of the ingest rows:
+ *   back to back (channel_stride == n_samples): ONE send per peer of exactly the shard's bytes, straight from the ingest buffer.
+ *   RECOMMENDED FOR INGEST: it needs no staging and no packing pass.
+ *   any other stride (sonde_row_stride's included): the rows are packed on the ingest device, four chunks per submit, chunk c + 1
+ *   copied into a staging buffer while chunk c is on the links; one send per peer and chunk of exactly the rows' bytes.
+ *   (Round 5 sent a strided shard as one run, padding included: 1.33 x the bytes over the slowest link of the system.)
+ * In both, a peer's rows land back to back and are decoded from there (the decoder takes any stride; back-to-back rows cost it
+ * 3-5 %).  scatter_mode 1: one send per row into rows on the recommended stride (no staging memory; 57 344 sends per block of
+ * BASELINE config 5: a fallback, not a recommendation).
  * The rows exist twice per device: submit t + 1 scatters while the decoders of submit t still read.
  *
  * All int / long calls: >= 0 ok, negative = error (text: sonde_node_last_error()).  Not thread-safe per object. */
@@ -43,11 +45,18 @@ typedef struct {
 	uint32_t       max_samples;   /* largest samples-per-channel of one submit (multiple of SONDE_TILE) */
 	int32_t        input_kind;    /* SONDE_INPUT_IQ, SONDE_INPUT_REAL, SONDE_INPUT_IQ16 or SONDE_INPUT_IQ8 (a half / a quarter of the bytes over xGMI) */
 	uint32_t       flags;         /* SONDE_FLAG_* of the per-device batches (SONDE_FLAG_PIPELINE is ignored: the node's row sets need the
-	                                 per-device streams joined with their decoders, which the default mode does one submit late) */
-	uint32_t       scatter_mode;  /* 0: by the ingest layout (below); 1: always one send per row into rows on the recommended stride */
+	                                 per-device streams joined with their decoders; SONDE_FLAG_LATE_JOIN is honoured) */
+	uint32_t       scatter_mode;  /* 0: by the ingest layout (above); 1: always one send per row into rows on the recommended stride.
+	                                 | SONDE_NODE_TEST_SHARED_DEVICES: test hook, see below */
 } SondeNodeConfig;
 
+/* TEST HOOK (tests/test_node_fake.py): a HIP device may be listed more than once in `devices`, so that a node of N > 1 shards can run on
+ * a box with one GPU against tests/cpp/fake_rccl.cpp.  The real RCCL refuses such a communicator: never set it in production. */
+#define SONDE_NODE_TEST_SHARED_DEVICES 0x100u
+
 int    sonde_node_create(const SondeNodeConfig *cfg, SondeNode **out);
+/* the contiguous channel range of device index d of nd (pure arithmetic): [first, first + count), remainders to the first devices */
+void   sonde_node_shard_range(uint32_t n_channels, uint32_t nd, uint32_t d, uint32_t *first, uint32_t *count);
 void   sonde_node_destroy(SondeNode *n);
 uint32_t sonde_node_devices(const SondeNode *n);
 /* channel range of device index d */

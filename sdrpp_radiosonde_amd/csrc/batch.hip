@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -139,6 +140,7 @@ struct SondeBatch {
 	uint8_t *d_gfexp = nullptr, *d_gflog = nullptr, *d_g64 = nullptr;
 	uint16_t *d_m10tab = nullptr;          // Meteomodem checksum as a GF(2) matrix product: rows A^k B, sd_fixed.h
 	uint32_t fuse_fec = 1;                 // RS41 FEC in the demod kernel's epilogue (default) or as its own kernel (SONDE_FLAG_SPLIT_FEC)
+	uint32_t fixed_epi = 1;                // the fixed-length framers' frames decoded in the demod kernel's epilogue too (round 6; not behind a channelizer: bins_kernel.hip)
 	SdFramerOut *d_fo2[2] = {};            // where the demod kernel's in-kernel sync search keeps its state and lists frames (device copies)
 	SdFramerOut h_fo2[2] = {};             // host copies: the bins decoder takes the descriptor by value (bins_kernel.hip)
 	SdModem h_modems[SONDE_NTYPES] = {};
@@ -177,6 +179,13 @@ struct SondeBatch {
 	bool pipeline = false;                 // join_mode != 0
 	hipStream_t done_stream = nullptr;
 	uint32_t granule = SONDE_TILE;         // submit sizes must be a multiple of this
+	// time slices (launch.h SdSlice): per-channel segment counters, the value they hold before the next sliced launch, the residency
+	// the policy works with (demod workgroups the GPU holds at once) and the knob (0: the library's choice; experiments: SONDE_SEG)
+	uint32_t *d_prog = nullptr;
+	uint32_t seg_base = 0;
+	uint32_t residency = 1024;
+	int seg_force = 0;
+	bool sliced_once = false;
 
 	static const int kEvSlots = 128;       // submits timed between two sonde_batch_kernel_ms() calls
 	hipEvent_t ev[3 * kEvSlots] = {};
@@ -211,7 +220,7 @@ extern "C" void sonde_batch_destroy(SondeBatch *b)
 	(void)hipFree(b->d_states); (void)hipFree(b->d_fstates); (void)hipFree(b->d_hist); (void)hipFree(b->d_bitring);
 	for (int k = 0; k < 2; k++) { (void)hipFree(b->d_frames2[k]); (void)hipFree(b->d_counts2[k]); (void)hipFree(b->d_fo2[k]); if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]); }
 	if (b->ev_xs) (void)hipEventDestroy(b->ev_xs);
-	(void)hipFree(b->d_taps); (void)hipFree(b->d_modems);
+	(void)hipFree(b->d_taps); (void)hipFree(b->d_modems); (void)hipFree(b->d_prog);
 	(void)hipFree(b->d_astates); (void)hipFree(b->d_wtab); (void)hipFree(b->d_wtab_c50); (void)hipFree(b->d_afq);
 	for (auto &u : b->units) { if (u.st) (void)hipStreamDestroy(u.st); for (int k = 0; k < 2; k++) if (u.ev_join[k]) (void)hipEventDestroy(u.ev_join[k]); }
 	for (int k = 0; k < 4; k++) (void)hipFree(b->d_cls[k]);
@@ -294,6 +303,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	}
 	ALLOC(b->d_taps, (size_t)SONDE_NTYPES * SD_NPHASE * SD_NTAPS * sizeof(float));
 	ALLOC(b->d_modems, SONDE_NTYPES * sizeof(SdModem));
+	ALLOC(b->d_prog, (C + 1) * sizeof(uint32_t));
 	ALLOC(b->d_gfexp, 2304);      // zero-absorbing antilog table of the RS decoder (GF_EXP2 in framer_kernel.hip)
 	ALLOC(b->d_gflog, 512);       // 256 x u16 logarithms, log 0 = 768
 	ALLOC(b->d_gfswar, 24 * 8 * sizeof(uint32_t));
@@ -436,7 +446,10 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			hipDeviceProp_t prop;
 			CHK(hipGetDeviceProperties(&prop, cfg->device));
 			const uint32_t loop_wg = 4u * (uint32_t)prop.multiProcessorCount;
-			const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts2[k], b->max_frames, b->fuse_fec, loop_wg, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames2[k] };
+			if (const char *e = getenv("SONDE_FIXED_EPI")) b->fixed_epi = atoi(e) ? 1u : 0u;       // (A/B experiment knob of round 6; removed once decided)
+			if (!b->fuse_fec) b->fixed_epi = 0;
+			const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts2[k], b->max_frames, b->fuse_fec, loop_wg, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames2[k],
+			                         b->d_m10tab, b->fixed_epi };
 			CHK(hipMemcpy(b->d_fo2[k], &fo, sizeof(fo), hipMemcpyHostToDevice));
 			b->h_fo2[k] = fo;
 			CHK(hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming));
@@ -455,6 +468,12 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	}
 	CHK(hipMemcpy(b->d_states, st.data(), C * sizeof(SdChanState), hipMemcpyHostToDevice));
 	CHK(hipMemset(b->d_fstates, 0, C * sizeof(SdFramerState)));
+	CHK(hipMemset(b->d_prog, 0, (C + 1) * sizeof(uint32_t)));
+	{
+		hipDeviceProp_t pr;
+		if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) b->residency = 4u * (uint32_t)pr.multiProcessorCount;
+		if (const char *e = getenv("SONDE_SEG")) b->seg_force = atoi(e);        // (experiment knob of round 6)
+	}
 	CHK(hipMemset(b->d_hist, 0, C * SD_HIST * sizeof(float)));
 	CHK(hipMemset(b->d_bitring, 0, C * (size_t)b->ring_words * sizeof(uint32_t)));
 	for (int k = 0; k < 2; k++) CHK(hipMemset(b->d_counts2[k], 0, C * sizeof(uint32_t)));
@@ -565,6 +584,27 @@ int sd_batch_submit_bins(SondeBatch *b, const SdBinsArgs *ba, size_t n_steps, vo
 	return submit_impl(b, ba->phases, n_out, ba->row_stride, stream_, ba);
 }
 
+// Time slices of one demod launch of n_wg workgroups that shares the GPU with total_wg workgroups in all (the submit's launch units run
+// side by side): the number of segments S (1: unsliced).  Cost model in tile-times: generations x tiles per segment, a generation being
+// one residency of workgroups; S among the divisors-ish {1, 2, 3, 4, 6, 8} with at least 6 tiles per segment; ties go to the smaller S.
+static int choose_segments(const SondeBatch *b, uint32_t n_wg, uint32_t total_wg, int n_tiles)
+{
+	if (b->seg_force > 0) return (b->seg_force <= n_tiles && total_wg > 0) ? b->seg_force : 1;
+	if (total_wg <= b->residency) return 1;                 // every workgroup is resident at once: nothing to balance
+	static const int cand[] = { 1, 2, 3, 4, 6, 8 };
+	int best = 1;
+	uint64_t best_cost = ~0ull;
+	for (int S : cand) {
+		const int st = (n_tiles + S - 1) / S;
+		if (S > 1 && (st < 6 || n_tiles % S)) continue;
+		const uint64_t gens = ((uint64_t)total_wg * (uint64_t)S + b->residency - 1) / b->residency;
+		const uint64_t cost = gens * (uint64_t)st * 16 + (uint64_t)S;      // (+ S: a segment's prologue / epilogue is not free)
+		if (cost < best_cost) { best_cost = cost; best = S; }
+	}
+	(void)n_wg;
+	return best;
+}
+
 static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, size_t channel_stride, void *stream_, const SdBinsArgs *bins_in)
 {
 	HIPCHK(hipSetDevice(b->device));
@@ -605,6 +645,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 		} else if (t == SONDE_IMET4) {
 			sd_launch_framer_imet(nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words, d_frames, d_counts, b->max_frames, list);
 		} else {
+			if (b->fixed_epi && !bins_in) return 0;      // decoded in the demod kernel's epilogue (the bins decoder behind a channelizer still takes the kernel)
 			sd_launch_framer_other(t, nch, sk, b->d_states, b->d_fstates, b->d_bitring, b->ring_words,
 				t == SONDE_M10 ? (const uint8_t *)b->d_m10tab : b->d_g64, b->d_descs, d_frames, d_counts, b->max_frames, b->type_frames[t], list,
 				/* with_sync = */ !b->fuse_fec);        // default: the demod kernel has run the sync search (K4) itself
@@ -614,13 +655,29 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 		return 0;
 	};
 	const bool one_launch = b->units.empty();
+	// time slices: every sliced launch of this submit shares seg_base (each channel belongs to exactly one launch)
+	uint32_t total_wg = b->n_channels;
+	if (!one_launch) { total_wg = 0; for (const SondeBatch::Unit &u : b->units) total_wg += u.n; }
+	int max_seg = 1;
+	auto slice_of = [&](uint32_t n_wg, int tiles, SdSlice &sl) -> const SdSlice * {
+		const int S = choose_segments(b, n_wg, total_wg, tiles);
+		if (S <= 1) return nullptr;
+		sl.seg_tiles = (tiles + S - 1) / S; sl.n_wg = n_wg; sl.seg_base = b->seg_base; sl.prog = b->d_prog; sl.err_index = b->n_channels;
+		sl.n_seg = (tiles + sl.seg_tiles - 1) / sl.seg_tiles;
+		max_seg = std::max(max_seg, (int)sl.n_seg);
+		b->sliced_once = true;
+		return &sl;
+	};
 	if (one_launch) {
 		if (bins_in)      // channelizer bins: one wave per bin (bins_kernel.hip); n_tiles = 3 per block of 2560 phases
 			sd_launch_bins(b->n_channels, stream, bins_in->phases, bins_in->row_stride, n_tiles / 3, bins_in->carry_rows, bins_in->carry_stride,
 				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->h_modems, &b->h_fo2[slot], bins_in->g_comp, b->cls_type[b->only_class]);
-		else
-		sd_launch_demod(iq, k_cls_decim[b->only_class], k_cls_nt[b->only_class], b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
-			b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, b->cls_type[b->only_class]);
+		else {
+			SdSlice sl;
+			sd_launch_demod(iq, k_cls_decim[b->only_class], k_cls_nt[b->only_class], b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
+				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, b->cls_type[b->only_class],
+				slice_of(b->n_channels, n_tiles, sl));
+		}
 		HIPCHK(hipGetLastError());
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
 		for (int t = 0; t < SONDE_NTYPES; t++) if (launch_framers(t, stream)) return -1;
@@ -644,9 +701,11 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 				sd_launch_demod(SD_IN_REAL, 1, 16, u.n, u.st, rows, nq, (int)(nq / SONDE_TILE),
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, b->d_chlist[u.type], true, fo, u.type);
 			} else {
+				SdSlice sl;
 				sd_launch_demod(iq, k_cls_decim[u.cls], k_cls_nt[u.cls], u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems,
-					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo, u.type < 0 ? b->cls_type[u.cls] : u.type);
+					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo, u.type < 0 ? b->cls_type[u.cls] : u.type,
+					slice_of(u.n, n_tiles, sl));
 			}
 			HIPCHK(hipGetLastError());
 			if (timed) HIPCHK(hipEventRecord(ec[1], u.st));
@@ -677,6 +736,9 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 		b->ev_has_framer[b->ev_used % SondeBatch::kEvSlots] = framer_launched;
 		b->ev_used++;
 	}
+	// time slices: segment s > 0 waits for the VALUE seg_base + s, which only segment s - 1 of the same launch writes; whatever a
+	// channel's counter holds from earlier submits is <= seg_base (sliced or not, whichever launch it was in): never waited for
+	if (max_seg > 1) b->seg_base += (uint32_t)max_seg;
 	b->ev_valid[slot] = b->ticketing;
 	if (b->ticketing) HIPCHK(hipEventRecord(b->ev_done[slot], stream));
 	b->tickets++;
@@ -777,6 +839,12 @@ static long sync_ticket(SondeBatch *b, uint64_t ticket)
 		if (ticket == b->tickets || !b->ev_valid[slot]) b->pending = false;
 		e = hipMemcpy(b->h_counts2[slot].data(), b->d_counts2[slot], b->n_channels * sizeof(uint32_t), hipMemcpyDeviceToHost);
 		if (e != hipSuccess) return fail("hipMemcpy counts", e);
+		if (b->sliced_once) {      // time slices: a workgroup whose predecessor never published gave up instead of hanging (launch.h SdSlice)
+			uint32_t gave_up = 0;
+			e = hipMemcpy(&gave_up, b->d_prog + b->n_channels, sizeof(uint32_t), hipMemcpyDeviceToHost);
+			if (e != hipSuccess) return fail("hipMemcpy prog", e);
+			if (gave_up) return fail("sonde_batch: a time-sliced demod launch found a segment whose predecessor never finished (workgroup dispatch out of order?); the batch's state is undefined -- recreate it");
+		}
 		long n = 0, over = 0;
 		for (uint32_t c = 0; c < b->n_channels; c++) {
 			n += std::min(b->h_counts2[slot][c], b->max_frames);

@@ -106,6 +106,7 @@ struct DemodLds {
 	uint32_t mirror[SD_MIRROR_WORDS];       // the newest 2048 bits of the bit ring, for the in-kernel sync search (K4)
 	SdSyncRun k4;                           // K4's state between steps (wave 3 only)
 	SdFecJob fec;                           // the in-loop decoder of clean RS41 frames (wave 2 only, sd_rsdec.h)
+	uint32_t nout0;                         // time slices: frames the channel's earlier segments listed in this submit (0 in an unsliced launch)
 };
 
 // samples (i, i+1) of a tile, i even, into buffer b
@@ -127,6 +128,7 @@ __device__ __forceinline__ void store_one(DemodLds &s, int b, uint32_t i, float 
 static_assert(SD_LH + SD_TILE / 2 + 4 <= SD_EPI_TAB_OFF, "the tables must stay clear of a 2:1 tile");
 static_assert(sizeof(EpiTabs) <= (SD_BUF - SD_EPI_TAB_OFF) * sizeof(float), "GF tables do not fit behind the tile");
 static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "per-wave FEC work areas do not fit into the tile buffers");
+static_assert(8 * sizeof(FixedLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "per-wave work areas of the fixed-length decoders do not fit into the tile buffers");
 
 // ---------------------------------------------------------------- the kernel
 // Wave specialisation: the discriminator (K1) is pure per-sample ALU work, the rounds (K2/K3) are a
@@ -142,11 +144,11 @@ static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "p
 template <int IN, bool LIST, int DEC, int NT>
 // (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU)
 __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
-	const float *__restrict__ in, size_t ch_stride, int n_tiles,
+	const float *__restrict__ in, size_t ch_stride, int n_tiles_all,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
 	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
-	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, int utype)
+	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, int utype, const SdSlice sl)
 {
 	// integer IQ rows: IQ16 = int16 pairs (SD_IN_IQ16) OR int8 pairs (SD_IN_IQ8): one code path, IQ8 picks the element size
 	constexpr bool IQ8 = IN == SD_IN_IQ8, IQ16 = IN == SD_IN_IQ16 || IQ8, IS_IQ = IN == SD_IN_IQ || IQ16;
@@ -162,14 +164,21 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const bool is_k = wave >= 4;           // wave-uniform role
 	const int t = tid & 255;               // index inside the role group
 	const int rwave = wave & 3;
-	const uint32_t ch = LIST ? chlist[blockIdx.x] : blockIdx.x;        // channel (state, bit ring)
-	const uint32_t row = (LIST && compact_in) ? blockIdx.x : ch;       // row of `in`
+	// time slices (launch.h SdSlice): block b works on segment b / n_wg of list entry b % n_wg; a segment is a submit of its own to
+	// everything below (its tiles start at `src`, n_tiles of them; the state comes from and goes back to HBM)
+	const bool sliced = sl.n_seg > 1;
+	const int seg = sliced ? (int)(blockIdx.x / sl.n_wg) : 0;
+	const uint32_t wgi = sliced ? blockIdx.x - (uint32_t)seg * sl.n_wg : blockIdx.x;
+	const int n_tiles = sliced ? min(sl.seg_tiles, n_tiles_all - seg * sl.seg_tiles) : n_tiles_all;
+	const uint32_t ch = LIST ? chlist[wgi] : wgi;                      // channel (state, bit ring)
+	const uint32_t row = (LIST && compact_in) ? wgi : ch;              // row of `in`
 
 	// ---- discriminator waves: the first two tiles' loads go out before anything else (see the prologue note below)
 	constexpr int NLD = (IS_IQ && !IQ16D4) ? 4 : 2;     // loads per thread per tile (float4; SD_IN_IQ16: 8 bytes, the same two samples, or 16 bytes, four)
 	constexpr int TILE_F4 = ((IS_IQ && !IQ16D4) ? 2 : 1) * SD_TILE / 4;      // load units (LoadT) per tile
 	// (ch_stride counts samples: 8 bytes each for complex64, 4 for real input and for 16-bit IQ)
-	const LoadT *src = reinterpret_cast<const LoadT *>(reinterpret_cast<const char *>(in) + (size_t)row * ch_stride * (IQ8 ? 2 : ((IS_IQ && !IQ16) ? 8 : 4)));
+	const LoadT *src = reinterpret_cast<const LoadT *>(reinterpret_cast<const char *>(in) + (size_t)row * ch_stride * (IQ8 ? 2 : ((IS_IQ && !IQ16) ? 8 : 4)))
+	                   + (sliced ? (size_t)seg * (size_t)sl.seg_tiles * TILE_F4 : 0);
 	LoadT va[NLD], vb[NLD];                // two register sets: tiles are prefetched two phases ahead
 	// Work split: wave kw of the four owns 256 consecutive float4s of the tile, load r covers 64 of them, so
 	// every load instruction is one contiguous 1 KB and the predecessor sample of lane 0 at r > 0 is lane 63
@@ -201,6 +210,28 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (n_tiles > 1) load_vec(1, vb);
 	}
 
+	// time slices: segment s > 0 starts where segment s - 1 of the same channel stopped: wait until that workgroup has published its
+	// state (its block index is lower: it was dispatched earlier).  One lane polls, the rest wait at the barrier; then every wave
+	// acquires at agent scope (the predecessor may have run on another XCD: its L2 wrote back on release, ours drops stale lines) and
+	// the scalar cache is emptied (this CU may have read the channel's state for an earlier segment).
+	if (sliced && seg > 0) {
+		if (tid == 0) {
+			const uint32_t want = sl.seg_base + (uint32_t)seg;
+			unsigned spins = 0;
+			bool ok = true;
+			while (__hip_atomic_load(&sl.prog[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+				__builtin_amdgcn_s_sleep(8);
+				if ((++spins & 1023u) == 0 && (spins >= (1u << 20) || __hip_atomic_load(&sl.prog[sl.err_index], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { ok = false; break; }
+			}
+			if (!ok) __hip_atomic_store(&sl.prog[sl.err_index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			s.pub.flag = ok ? 0u : 0xDEADu;
+		}
+		__syncthreads();
+		if (s.pub.flag == 0xDEADu) return;         // (workgroup-uniform; the host finds the error word: never a hang)
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		__builtin_amdgcn_s_dcache_inv();
+		__syncthreads();                           // (pub.flag is rewritten by the prologue below)
+	}
 	SdChanState st = states[ch];
 	// utype >= 0: every channel of this launch is of that sonde type (the host knows: one-type batches, per-type launch units), so
 	// the taps and modem parameters do not have to wait for the state
@@ -294,7 +325,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// once -- their epilogues coincide, nothing else streams meanwhile: 1024 x 96 tiles -1.6 % at 14 dB, -1.1 % at 9 dB -- and long
 	// enough (>= 48 tiles; at 24 the steps of the 1.6 frames a submit completes stall as much as they save).  In launches of several
 	// generations the epilogues overlap other workgroups' streaming for free and the steps only stall: 4096 x 96 tiles +7 %.
-	const bool fec_loop = fec_here && n_tiles >= 48 && gridDim.x <= fo->loop_fec_max_wg;
+	const bool fec_loop = fec_here && n_tiles >= 48 && gridDim.x <= fo->loop_fec_max_wg && !sliced;
 	FramerLds &loop_wl = *reinterpret_cast<FramerLds *>(&s.A[1][1100]);
 	static_assert(sizeof(FramerLds) <= (SD_BUF - 1100) * sizeof(float), "in-loop FEC work area");
 	if (tid == 3 * 64 - 1) { s.fec.frame = 0; s.fec.phase = 0; s.fec.done_mask = 0; }      // (wave 2: the wave that uses it)
@@ -624,7 +655,9 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	auto k4_load = [&]() {         // one lane: the channel's search state into LDS
 		const SdFramerState f0 = fo->fstates[ch];
 		s.k4.rpos = f0.rpos; s.k4.fstart = f0.fstart; s.k4.collecting = f0.collecting; s.k4.inv = f0.inv; s.k4.flen = f0.flen;
-		s.k4.nout = 0; s.k4.wp_seen = st.wpos;
+		// (time slices: a later segment appends to the frames its predecessors listed in this submit)
+		const uint32_t nout0 = (sliced && seg > 0) ? fo->counts[ch] : 0u;
+		s.k4.nout = nout0; s.nout0 = nout0; s.k4.wp_seen = st.wpos;
 	};
 	auto k4_run = [&](uint64_t wp) {   // one step of the channel's sync-search state machine (wave-uniform type dispatch)
 		SdFrameDesc *dch = (SdFrameDesc *)fo->descs + (size_t)ch * fo->max_frames;
@@ -774,7 +807,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		__syncthreads();           // (F) K4's catch-up is done (nout in LDS, descriptors in HBM); the tile buffers are dead
 		const uint32_t max_frames = fo->max_frames;
 		const uint32_t nfr = min((uint32_t)__builtin_amdgcn_readfirstlane((int)s.k4.nout), max_frames);
-		if ((uint32_t)wave < nfr) {
+		const uint32_t nf0 = sliced ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s.nout0) : 0u;      // (the earlier segments decoded theirs)
+		if (nf0 + (uint32_t)wave < nfr) {
 			FramerLds &wl = reinterpret_cast<FramerLds *>(&s.A[0][0])[wave];
 			GfSwar swar;
 			const uint32_t *sw = et.swar + 8 * (lane % RS_R);
@@ -782,7 +816,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			const unsigned long long *dg = reinterpret_cast<const unsigned long long *>((const SdFrameDesc *)fo->descs + (size_t)ch * max_frames);
 			SondeFrame *fout = fo->frames + (size_t)ch * max_frames;
 			const uint32_t done_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.fec.done_mask);      // records the loop has written
-			for (uint32_t k = (uint32_t)wave; k < nfr; k += SD_WGT / 64) {
+			for (uint32_t k = nf0 + (uint32_t)wave; k < nfr; k += SD_WGT / 64) {
 				if (k < 32u && ((done_mask >> k) & 1u)) continue;
 				// the descriptor: from K4's list in LDS, or (beyond its first entries) from HBM, where wave 3 of this workgroup
 				// stored it a moment ago: agent-scope loads (L2), like the ring words
@@ -802,16 +836,61 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			}
 		}
 	}
+
+	// ---- the fixed-length framers' frames (DFM / M10 / iMS-100 / MRZ-N1), round 6: decoded HERE as well, one frame per wave, instead of
+	// by a kernel of their own behind this one (sd_dec_fixed_kernel: one launch more per type and submit, 14-20 us that run alone at
+	// the end of a joined submit).  Manchester / biphase decode, de-interleaving, Hamming(8,4) / checksum / BCH(63,51): sd_fixed.h, the
+	// same device functions the stand-alone kernel calls, reading the bit ring this workgroup has just written (agent-scope loads).
+	const bool fixed_here = fuse && fo->fixed_epi != 0 && (is_dfm || is_ims || is_m10 || is_mrz);       // workgroup-uniform
+	if (fixed_here) {
+		__syncthreads();           // (F) K4's catch-up is done (nout in LDS, descriptors in HBM); the tile buffers are dead
+		const uint32_t max_frames = fo->max_frames;
+		const uint32_t nfr = min((uint32_t)__builtin_amdgcn_readfirstlane((int)s.k4.nout), max_frames);
+		const uint32_t nf0 = sliced ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s.nout0) : 0u;
+		if (nf0 + (uint32_t)wave < nfr) {
+			FixedLds &wl = reinterpret_cast<FixedLds *>(&s.A[0][0])[wave];
+			const unsigned long long *dg = reinterpret_cast<const unsigned long long *>((const SdFrameDesc *)fo->descs + (size_t)ch * max_frames);
+			SondeFrame *fout = fo->frames + (size_t)ch * max_frames;
+			for (uint32_t k = nf0 + (uint32_t)wave; k < nfr; k += SD_WGT / 64) {
+				unsigned long long d0, d1;
+				if (k < SD_K4_LIST) {
+					const unsigned long long *dl = reinterpret_cast<const unsigned long long *>(&s.k4.list[k]);
+					d0 = dl[0]; d1 = dl[1];
+				} else {
+					d0 = __hip_atomic_load(dg + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					d1 = __hip_atomic_load(dg + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				SdFrameDesc d;
+				d.fstart = sd_uniform64(d0);
+				d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);
+				d.inv = __builtin_amdgcn_readfirstlane((int)(d1 >> 32));
+				if (is_dfm) sd_dfm_decode_frame<true>(wl, ring_g, ring_mask, d, fout + k, ch, lane);
+				else if (is_m10) sd_m10_decode_frame<true>(wl, fo->m10tab, ring_g, ring_mask, d, fout + k, ch, lane);
+				else if (is_mrz) sd_mrz_decode_frame<true>(wl, ring_g, ring_mask, d, fout + k, ch, lane);
+				else sd_ims_decode_frame<true>(wl, fo->gf64, ring_g, ring_mask, d, fout + k, ch, lane);
+			}
+		}
+	}
+
+	// ---- time slices: hand the channel to its next segment.  Every wave releases what it wrote (state, history, ring words, framer
+	// state, descriptors, frame records) at agent scope, the barrier orders those releases before the one store that publishes.
+	if (sliced) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__syncthreads();
+		if (tid == 0) __hip_atomic_store(&sl.prog[ch], sl.seg_base + (uint32_t)seg + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	}
 }
 
 void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
-	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */, int utype)
+	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */, int utype, const SdSlice *slice)
 {
-	const dim3 g(n_channels), blk(SD_WGT);
+	SdSlice sl = { 1, n_tiles, n_channels, 0u, nullptr, 0u };
+	if (slice && slice->n_seg > 1) sl = *slice;
+	const dim3 g(n_channels * (uint32_t)sl.n_seg), blk(SD_WGT);
 	const int ci = compact_in ? 1 : 0;
-#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo, utype
+#define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo, utype, sl
 #define SD_DEMOD_LAUNCH(KIND, LS) do { \
 		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else if (decim == 2 && nt == 8) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \

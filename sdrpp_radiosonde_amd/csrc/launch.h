@@ -17,13 +17,35 @@ struct SdFramerOut {
 	const uint8_t *gf_exp, *gf_log; const uint32_t *gf_swar;
 	const uint8_t *gf64;                    // GF(2^6) tables of the iMS-100 BCH decoder
 	SondeFrame *frames;
+	const uint16_t *m10tab;                 // Meteomodem checksum matrix rows [99][8] (sd_fixed.h sd_m10_decode_frame)
+	uint32_t fixed_epi;                     // 1: the demod kernel also decodes the frames of the fixed-length framers (DFM / M10 / iMS-100 / MRZ-N1) in its
+	                                        // epilogue, one frame per wave, like RS41's; 0: sd_dec_fixed_kernel does, one launch more per type
+};
+// TIME SLICES (round 6).  A demod workgroup lives for its channel's whole submit, so a launch whose workgroup count is not a multiple of
+// one residency of the GPU ends with a part-filled generation running alone, and any launch ends with a ramp-down as long as a
+// workgroup's life.  With n_seg > 1 a channel's submit is cut into n_seg consecutive SEGMENTS of seg_tiles tiles, each its own
+// workgroup: grid = n_wg * n_seg, block b works on segment b / n_wg of list entry b % n_wg (segment-major: every channel's first
+// segment is dispatched before any second one).  A segment is what a submit is to the arithmetic -- the channel's whole state is
+// carried in HBM, the SPEC does not see where a submit is cut (tests: ragged submits) -- so the frames are those of the unsliced
+// launch, bit for bit.  Segment s of a channel waits (one lane polls an agent-scope word, the others sit at a barrier) until segment
+// s - 1 has published prog[channel] = seg_base + s; the predecessor has a lower block index, so it was dispatched earlier and is
+// running or done: no deadlock as long as workgroups are dispatched in index order per XCD.  Should that ever not hold, the poll
+// gives up after ~0.3 s, sets prog[err_index] and the workgroup leaves without touching the channel: the host reports it (never a hang).
+struct SdSlice {
+	int32_t   n_seg;        // segments per channel (1: unsliced: the fields below are not read)
+	int32_t   seg_tiles;    // tiles per segment (the last one takes what is left)
+	uint32_t  n_wg;         // list entries (channels) of the launch
+	uint32_t  seg_base;     // prog[channel] == seg_base when the launch starts (the host advances it by n_seg per sliced launch)
+	uint32_t *prog;         // [n_channels of the batch + 1]: per channel the segments completed so far; the last word: poll gave up
+	uint32_t  err_index;    // = n_channels of the batch
 };
 // in_kind: what the 48 kS/s rows hold (SD_IN_REAL / SD_IN_IQ / SD_IN_IQ16 / SD_IN_IQ8)
 void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */,
-	int utype /* >= 0: every channel of the launch is of this sonde type (taps / modem loads need not wait for the state); -1: per channel */);
+	int utype /* >= 0: every channel of the launch is of this sonde type (taps / modem loads need not wait for the state); -1: per channel */,
+	const SdSlice *slice = nullptr /* null or n_seg <= 1: one workgroup per channel for the whole submit */);
 // The decoder behind the filter bank (bins_kernel.hip): one wave per bin; rows of 16-bit phases [16 carried | n_steps]; the last 16
 // phases of the submit go to the head of carry_rows' rows (the buffer the next submit reads: the same one unless double-buffered)
 struct SdBinsArgs { const int16_t *phases; size_t row_stride; int16_t *carry_rows; size_t carry_stride; const float *g_comp /* [3][SD_RS_KT_LD], device */; };

@@ -9,7 +9,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import FRAME_DTYPE, INPUT_IQ
-from .shard import NativeShard
+
+TEST_SHARED_DEVICES = 0x100        # SONDE_NODE_TEST_SHARED_DEVICES (scatter_mode bit; tests/test_node_fake.py)
 
 
 class SondeNodeConfig(C.Structure):
@@ -17,15 +18,31 @@ class SondeNodeConfig(C.Structure):
                 ("types", C.POINTER(C.c_uint8)), ("max_samples", C.c_uint32), ("input_kind", C.c_int32), ("flags", C.c_uint32), ("scatter_mode", C.c_uint32)]
 
 
-NODE_SYMBOLS = ["sonde_node_create", "sonde_node_destroy", "sonde_node_devices", "sonde_node_range", "sonde_node_batch", "sonde_node_submit", "sonde_node_submit_on", "sonde_node_gather_stats",
+NODE_SYMBOLS = ["sonde_node_create", "sonde_node_shard_range", "sonde_node_destroy", "sonde_node_devices", "sonde_node_range", "sonde_node_batch", "sonde_node_submit", "sonde_node_submit_on", "sonde_node_gather_stats",
                 "sonde_node_submit_local", "sonde_node_scatter_done", "sonde_node_sync", "sonde_node_frames", "sonde_node_poll",
                 "sonde_node_scatter_stats", "sonde_node_last_error"]
 
 
-def lib():
-    L = NativeShard.lib()                      # libsonde_rccl.so (built on demand: csrc/Makefile `rccl`)
+_libs = {}
+
+
+def lib(path: str | None = None):
+    """libsonde_rccl.so (built on demand: csrc/Makefile `rccl`).  path: another build of csrc/node.cpp -- the test build linked against
+    tests/cpp/fake_rccl.cpp (tests/test_node_fake.py); the product never passes it."""
+    import os
+    import subprocess
+    _lib.load()
+    if path is None:
+        path = os.path.join(_lib.PKG_DIR, "libsonde_rccl.so")
+        if not os.path.exists(path):                 # only multi-GPU hosts need RCCL
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_lib.PKG_DIR, "csrc"), "rccl"])
+    if path not in _libs:
+        _libs[path] = C.CDLL(path)
+    L = _libs[path]
     if not getattr(L, "_node_ready", False):
         vp = C.c_void_p
+        L.sonde_node_shard_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.sonde_node_shard_range.restype = None
         L.sonde_node_create.argtypes = [C.POINTER(SondeNodeConfig), C.POINTER(vp)]
         L.sonde_node_destroy.argtypes = [vp]
         L.sonde_node_destroy.restype = None
@@ -59,8 +76,9 @@ class SondeNode:
     """All channels of one node: `devices` (HIP ordinals) each decode a contiguous channel range; submit() takes the IQ of ALL
     channels as a device tensor [C, n, 2] on devices[ingest]."""
 
-    def __init__(self, n_channels: int, max_samples: int, devices=(0,), ingest: int = 0, types=None, input_kind: int = INPUT_IQ, flags: int = 0, scatter_mode: int = 0):
-        self.L = lib()
+    def __init__(self, n_channels: int, max_samples: int, devices=(0,), ingest: int = 0, types=None, input_kind: int = INPUT_IQ, flags: int = 0, scatter_mode: int = 0,
+                 lib_path: str | None = None):
+        self.L = lib(lib_path)
         self._devs = (C.c_int32 * len(devices))(*devices)
         cfg = SondeNodeConfig()
         cfg.n_devices, cfg.devices, cfg.ingest = len(devices), self._devs, ingest
@@ -89,12 +107,12 @@ class SondeNode:
     def submit(self, iq, stream: int | None = None):
         """iq: device tensor [C, n, 2] on the ingest device.  The scatter starts behind the work queued on `stream` (a hipStream_t
         value; default: torch's current stream on the ingest device) -- the stream that produced iq."""
-        assert iq.is_cuda and iq.device.index == self.devices[self.ingest] and iq.shape[0] == self.n_channels and iq.stride(1) == 2
+        assert iq.is_cuda and iq.device.index == self.devices[self.ingest] and iq.shape[0] == self.n_channels and (iq.dim() == 2 or iq.stride(1) == 2)
         if stream is None:
             import torch
             stream = torch.cuda.current_stream(iq.device).cuda_stream
         self._keep = (iq, getattr(self, "_keep", (None, None))[0])
-        self._chk(self.L.sonde_node_submit_on(self.h, C.c_void_p(iq.data_ptr()), iq.shape[1], iq.stride(0) // 2, C.c_void_p(stream)))
+        self._chk(self.L.sonde_node_submit_on(self.h, C.c_void_p(iq.data_ptr()), iq.shape[1], iq.stride(0) // (2 if iq.dim() == 3 else 1), C.c_void_p(stream)))
 
     def submit_local(self, rows):
         """rows[d]: device tensor [count_d, n, 2] on devices[d] (all with the same channel stride)."""

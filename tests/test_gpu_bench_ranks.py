@@ -52,8 +52,8 @@ def test_bench_scatter_ingest_two_ranks_under_gloo():
 
 @pytest.mark.gpu
 def test_bench_native_scatter_two_gpus():
-    """world = 2 over RCCL with the native grouped ncclSend / ncclRecv scatter (csrc/shard_rccl.cpp) when the box has two GPUs:
-    `python bench.py --gpus 2` exactly as the driver types it."""
+    """`python bench.py --gpus 2` exactly as the driver types it, when the box has two GPUs: ONE process, the node host (csrc/node.cpp,
+    ncclCommInitAll, grouped ncclSend / ncclRecv scatter); both figures in the line, each labelled."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the one-GPU boxes run the gloo variant above)")
@@ -65,8 +65,9 @@ def test_bench_native_scatter_two_gpus():
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert j["config"]["ingest"].startswith("scatter from rank 0: libsonde_rccl (grouped ncclSend/ncclRecv") and j["scatter"]["rows_delivered_strided"]
-    assert j["nccl_ranks"] == {"backend": "rccl", "world": 2, "distinct_devices": 2}
+    assert j["config"]["host"].startswith("ONE process, sonde_node_") and j["nccl_ranks"]["world"] == 2
+    assert j["value_with_scatter"] > 0 and j["value"] >= j["value_with_scatter"] and "value_label" in j and "value_with_scatter_label" in j
+    assert j["scatter"]["bytes_from_ingest"] == 256 * 24 * 2048 * 8 and j["scatter"]["sends"] == 1
     assert j["frames_per_step_steady"] == pytest.approx(2 * 256 * 24 * 2048 / 10 / 3072, rel=0.02)
 
 
