@@ -476,3 +476,96 @@ def test_overlapped_submits_equal_serial(streams):
     ovl.close()
     for b in range(NBLK):
         assert got[b].tobytes() == want[b].tobytes(), b
+
+
+# ---- scenes of tools/wb_campaign.py's kind, fixed and in the driver's run: LOW signal-to-noise ratios, carriers
+# up to +-2 kHz off the bin centre, both stackings, integer blocks, a dense band.  (The campaign tool draws hundreds of such scenes at
+# random; its logs are under profiles/.  These ten are what every `pytest -m gpu` holds the front-end to.)
+WB_SCENES = [
+    # (name, seed, Eb/N0 dB, streams, blocks per submit, dual, carrier offset Hz, input bits, occupied bins)
+    ("snr8_1stream", 811, 8.0, 1, 1, False, 0.0, 0, 4),
+    ("snr10_plus2khz", 812, 10.0, 1, 2, False, 2000.0, 0, 4),
+    ("snr10_minus2khz", 813, 10.0, 2, 1, False, -2000.0, 0, 4),
+    ("snr12_3streams", 814, 12.0, 3, 2, False, 1300.0, 0, 5),
+    ("snr9_dual_halfbin", 815, 9.0, 1, 1, True, 9765.625, 0, 4),
+    ("snr11_dual_minus3khz", 816, 11.0, 2, 2, True, -3000.0, 0, 4),
+    ("snr9_int16", 817, 9.0, 1, 1, False, -1500.0, 16, 4),
+    ("snr12_int8", 818, 12.0, 2, 1, False, 800.0, 8, 4),
+    ("snr14_int16_dual", 819, 14.0, 1, 2, True, 2000.0, 16, 4),
+    ("snr13_dense256", 820, 13.0, 1, 1, False, 0.0, 0, 256),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", WB_SCENES, ids=[s[0] for s in WB_SCENES])
+def test_wideband_scenes_low_snr_offsets_dual_integer_blocks(oracle, scene):
+    """Fused mode against oracle/or_chan.c (composite path, SPEC 3.5b): the PHASES of the first block of every bin, and for every bin that
+    carries a signal (plus two silent DFM bins): frames, bit counts, the newest 4000 ring bits and the timing-loop state.
+    Reference chain: /root/reference/src/main.cpp:55-68 (VFO -> FM -> resampler -> decoder, per channel)."""
+    import torch
+    from sdrpp_radiosonde_amd.batch import SondeChannelizer
+    name, seed, ebn0, streams, bps, dual, offset, bits, occ = scene
+    nblk = 8
+    if occ > 64:
+        active = list(range(1, 512, 2))[:occ]
+        eb = ebn0 + 10.0 * np.log10(len(active) / 16.0)          # every transmitter brings its own white noise over the 10 MHz
+        dfm = []
+    else:
+        rng = np.random.default_rng(seed)
+        active = sorted(int(x) for x in rng.choice(np.arange(2, 510), size=occ, replace=False))
+        dfm = [int(x) for x in rng.choice([b for b in range(2, 510) if b not in active], size=2, replace=False)]
+        eb = ebn0
+    scenes = [synth.make_wideband_rs41(active, nblk * BLOCK, seed=seed + s, ebn0_db=eb, device="cuda:0", offset_hz=offset)[0] for s in range(streams)]
+    if occ > 64:
+        scenes = [sc * min(1.0, 4.0 / np.sqrt(len(active))) for sc in scenes]
+    q = None
+    if bits == 8:
+        q = [torch.clamp(torch.round(sc * 12.0), -128, 127).to(torch.int8) for sc in scenes]
+    elif bits == 16:
+        q = [torch.clamp(torch.round(sc * 2048.0), -32768, 32767).to(torch.int16) for sc in scenes]
+    if q is not None:
+        scenes = [x.to(torch.float32) for x in q]              # (the oracle sees the same integers as floats)
+    per = 1024 if dual else 512
+    types = np.zeros(per * streams, dtype=np.uint8)
+    for s_ in range(streams):
+        types[[per * s_ + k for k in dfm]] = 1
+        if dual:
+            types[[per * s_ + 512 + k for k in dfm]] = 1
+    chz = SondeChannelizer(types=types, blocks_per_submit=bps, n_streams=streams, dual=dual, input_kind=(3 if bits == 8 else 2) if bits else 0)
+    assert chz.fused
+    got, first_phases = [], None
+    for b in range(nblk // bps):
+        blk = [sc[b * bps * BLOCK: (b + 1) * bps * BLOCK] for sc in (q if q is not None else scenes)]
+        chz.submit(torch.stack(blk).contiguous() if streams > 1 else blk[0].contiguous())
+        if b == 0:
+            first_phases = chz.read()[0]
+        got.append(chz.frames())
+    got = np.concatenate(got)
+    key = lambda a: a[np.lexsort((a["bitpos"], a["channel"]))]
+    watch = active + dfm
+    refs = []
+    for s_, sc in enumerate(scenes):
+        for odd in ((False, True) if dual else (False,)):
+            dec, first = _oracle_decode_wideband(oracle, sc.cpu().numpy(), watch, types=types[:512], composite=True, odd=odd)
+            base = per * s_ + (512 if odd else 0)
+            # the filter bank's product, every bin of this stream and stacking, the first block (quadrants, bit for bit)
+            assert first_phases[base: base + 512, :STEPS].tobytes() == first[0].tobytes(), (name, s_, odd)
+            for k in watch:
+                r = dec[k].frames().copy()
+                r["channel"] = base + k
+                refs.append(r)
+                rb = dec[k].bits()
+                assert chz.batch.nbits(base + k) == len(rb), (name, s_, k)
+                tail = min(len(rb), 4000)
+                assert np.array_equal(chz.batch.read_bits(base + k, len(rb) - tail, tail), rb[-tail:]), (name, s_, k)
+                st, rs = chz.batch.state(base + k), dec[k].state()
+                assert (st["t_next"], st["period"], st["bias"], st["amp"]) == (rs["t_next"], rs["period"], rs["bias"], rs["amp"]), (name, s_, k)
+    ref = np.concatenate(refs)
+    sel = got[np.isin(got["channel"], [per * s_ + o + k for s_ in range(streams) for o in ((0, 512) if dual else (0,)) for k in watch])]
+    assert key(sel).tobytes() == key(ref).tobytes(), name
+    chz.close()
+    # the scenes are not vacuous: something decodes wherever the stacking can hear the carrier, and at these ratios the FEC has work
+    if not dual and abs(offset) <= 2000.0:
+        assert len(ref) >= (len(active) * streams) // 2, (name, len(ref))
+    if ebn0 <= 10.0 and len(ref):
+        assert (ref["nerr"] != 0).any(), name

@@ -103,3 +103,114 @@ def test_config5_shard_8192_rs41_channels(oracle):
     assert got.tobytes() == ref.tobytes()
     hit, good = _tx_match_fraction(sb, got)
     assert hit == good and good >= 0.97 * len(got)
+
+
+def test_config5_all_65536_channels_on_one_gpu(oracle):
+    """BASELINE configs[4] at its FULL size -- 65 536 RS41 channels x 49 152 samples (T = 1 s): 25.8 GB of complex64 -- on ONE MI355X,
+    through the product's node host (sonde_node with devices = (0,): the object that shards the same block over 8 GPUs), twice:
+    as complex64 rows and as 16-bit integer rows (12.9 GB).  Two consecutive seconds per pass (state carried; both row sets of the
+    node in use).  Against the oracle: (a) every frame record of a STRIDED SAMPLE of 4096 channels byte for byte, (b) the bit count
+    of EVERY channel, (c) on ALL channels: frames ordered, every frame whose FEC succeeded is a transmitted frame, almost every
+    transmitted frame is received.  (the 8-GPU split of the same block is the driver's run.)
+    Reference: one module instance per channel, /root/reference/src/main.cpp:18-24,62-68."""
+    import ctypes
+    import gc
+    from sdrpp_radiosonde_amd import _lib
+    from sdrpp_radiosonde_amd.batch import row_stride
+    from sdrpp_radiosonde_amd.node import SondeNode
+    C, n, NS, CH = 65536, 24 * TILE, 2, 8192
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < 200 * 2 ** 30:
+        pytest.skip(f"needs ~190 GB of free HBM, this device has {free / 2 ** 30:.0f} GB")
+    st = row_stride(n)                                                  # 512 KiB rows: the recommended stride
+    blocks = [torch.empty((C, st, 2), dtype=torch.float32, device="cuda:0")[:, :n] for _ in range(NS)]      # 34 GB each
+    tx, cfo = [], []
+    for c0 in range(0, C, CH):                                          # generated 8192 channels at a time (one GPU shard's worth)
+        sb = synth.make_rs41_batch(CH, NS * n, seed=65, ebn0_db=14.0, device="cuda:0", first_channel=c0)
+        for k in range(NS):
+            blocks[k][c0: c0 + CH] = sb.iq[:, k * n: (k + 1) * n]
+        tx += sb.frames
+        del sb
+    sample = np.arange(5, C, 16)                                        # 4096 channels for the byte-for-byte comparison
+    sidx = torch.from_numpy(sample).to("cuda:0")
+    host = torch.cat([blocks[k][sidx] for k in range(NS)], dim=1).cpu().numpy()
+    ref = oracle.batch_run(0, host, nthreads=CORES)
+    ref["channel"] = sample[ref["channel"]]
+    assert len(ref) >= 2 * len(sample)
+    L = _lib.load()
+
+    def run(kind, blks):
+        nd = SondeNode(C, n, devices=(0,), input_kind=kind)
+        parts = []
+        for k in range(NS):
+            nd.submit(blks[k])
+            parts.append(nd.frames().copy())
+        got = np.concatenate(parts)
+        got = got[np.lexsort((got["bitpos"], got["channel"]))]
+        bh = ctypes.c_void_p(nd.L.sonde_node_batch(nd.h, 0))
+        nb = np.array([L.sonde_batch_nbits(bh, c) for c in range(C)], dtype=np.int64)
+        nd.close()
+        return got, nb
+
+    got, nb = run(_lib.INPUT_IQ, blocks)
+    _check_order(got)
+    sel = got[np.isin(got["channel"], sample)]
+    assert sel.tobytes() == ref.tobytes()                               # (a)
+    assert np.abs(nb - NS * n // 10).max() <= 16                        # (b) 4800 Bd at 48 kS/s, minus the FIR look-ahead, EVERY channel
+    good = got[(got["nerr"] >= 0).all(axis=1)]                          # (c)
+    assert len(good) >= 0.97 * len(got)
+    for f in good:
+        assert any(np.array_equal(t[8:], f["data"][8: f["len"]]) for _, t in tx[f["channel"]]), int(f["channel"])
+    sent = sum(len(f) for f in tx)
+    assert len(got) >= sent - C and np.unique(got["channel"]).size >= 0.99 * C
+    # ---- the same block as 16-bit integer rows (full scale 8192 per unit amplitude): the float blocks are converted in place, chunk-wise
+    st16 = row_stride(n, kind=_lib.INPUT_IQ16)
+    blocks16 = [torch.empty((C, st16, 2), dtype=torch.int16, device="cuda:0")[:, :n] for _ in range(NS)]
+    for k in range(NS):
+        for c0 in range(0, C, CH):
+            blocks16[k][c0: c0 + CH] = torch.clamp(torch.round(blocks[k][c0: c0 + CH] * 8192.0), -32768, 32767).to(torch.int16)
+    del blocks
+    gc.collect()
+    torch.cuda.empty_cache()
+    host16 = torch.cat([blocks16[k][sidx] for k in range(NS)], dim=1).to(torch.float32).cpu().numpy()
+    ref16 = oracle.batch_run(0, host16, nthreads=CORES)
+    ref16["channel"] = sample[ref16["channel"]]
+    got16, nb16 = run(_lib.INPUT_IQ16, blocks16)
+    _check_order(got16)
+    assert got16[np.isin(got16["channel"], sample)].tobytes() == ref16.tobytes()
+    assert np.abs(nb16 - NS * n // 10).max() <= 16
+    good16 = got16[(got16["nerr"] >= 0).all(axis=1)]
+    assert len(good16) >= 0.97 * len(got16) and np.unique(got16["channel"]).size >= 0.99 * C
+    for f in good16[::7]:
+        assert any(np.array_equal(t[8:], f["data"][8: f["len"]]) for _, t in tx[f["channel"]]), int(f["channel"])
+
+
+def test_config1_single_channel_cpu_plumbing_equals_the_gpu_decoder(oracle):
+    """BASELINE configs[0]: ONE RS41 channel, 480 000 samples (10 s; 481 280 = whole tiles) through the CPU restatement, one thread
+    -- and the SAME discriminator stream through the B1 triple on the GPU (rs41_decoder_init / rs41_decode, the exact signature the
+    reference's Decoder<> template binds, /root/reference/src/decode/decoder.hpp:22,59-117, with its re-entrancy contract: the same
+    (src, len) re-passed until PROCEED, 0.1 s buffers as a dsp::stream hands them over): the SondeData fragments are the oracle's
+    frames parsed, one by one; 10 frames are expected (one per second)."""
+    import ctypes
+    from sdrpp_radiosonde_amd import _lib
+    from test_gpu_b1 import _discriminate, _run_b1
+    n = 480000 // TILE * TILE + TILE
+    sb = synth.make_rs41_batch(1, n, seed=4100, ebn0_db=15.0)
+    d = _discriminate(oracle, sb.iq.numpy()[0])
+    ch = oracle.Channel(0, 0)                                          # the CPU path, single-threaded by construction
+    ch.feed(d, is_iq=False)
+    ref = ch.frames()
+    assert len(ref) >= 9 and (ref["nerr"] >= 0).all()
+    frags = _run_b1("rs41", d, 4800)
+    L = _lib.load()
+    expect, out = [], (_lib.SondeData * 8)()
+    for f in ref:
+        fr = _lib.SondeFrame.from_buffer_copy(f.tobytes())
+        for i in range(L.sonde_parse_frame(ctypes.byref(fr), out, 8)):
+            expect.append({k: getattr(out[i], k) for k, _ in _lib.SondeData._fields_})
+    assert len(frags) == len(expect) and all(a == b for a, b in zip(frags, expect))
+    seqs = [f["seq"] for f in frags if f["fields"] & _lib.DATA_SEQ]
+    assert len(seqs) >= 9 and seqs == list(range(seqs[0], seqs[0] + len(seqs)))
+    # ... and every frame the CPU path decoded is one the generator transmitted
+    for f in ref:
+        assert any(np.array_equal(t[8:], f["data"][8: f["len"]]) for _, t in sb.frames[0])
