@@ -99,6 +99,7 @@ def parse_args():
                     "(profiles/r2_notes.md), inside the timed region: every 8th costs 0.6 %% of the step")
     ap.add_argument("--flags", type=int, default=None, help="SondeBatchConfig.flags (1: wide, 2: FEC as its own kernel, 4: never-joined launch units, 32: launch units joined "
                     "one submit late; default 0 = ordinary stream semantics)")
+    ap.add_argument("--time-slices", type=int, default=0, help="experiment: SondeBatchConfig.time_slices (0: the library's choice, 1: never, n: n segments per channel and submit)")
     ap.add_argument("--iq16", action="store_true", help="experiment: ONLY the 16-bit integer IQ entry at --channels x --tiles (prints its record)")
     ap.add_argument("--iq8", action="store_true", help="experiment: ONLY the 8-bit integer IQ entry at --channels x --tiles (prints its record)")
     ap.add_argument("--no-others", action="store_true", help="headline only: skip the other BASELINE configurations (other_configs), the low-SNR "

@@ -96,11 +96,12 @@ def measure(blocks, types, flags, args, local_rank, barrier, stream, input_kind=
     from sdrpp_radiosonde_amd.batch import SondeBatch
     C, n = blocks[0].shape[0], blocks[0].shape[1]
     # frames of a FIRST submit from a fresh decoder: the quantity the CPU baseline's `frames_per_pass` counts
-    fresh = SondeBatch(C, n, device=local_rank, types=types, flags=flags, input_kind=input_kind)
+    ts = int(getattr(args, "time_slices", 0) or 0)
+    fresh = SondeBatch(C, n, device=local_rank, types=types, flags=flags, input_kind=input_kind, time_slices=ts)
     fresh.submit(blocks[0], stream)
     nfr_first = int(fresh.sync())
     fresh.close()
-    batch = SondeBatch(C, n, device=local_rank, types=types, flags=flags, input_kind=input_kind)
+    batch = SondeBatch(C, n, device=local_rank, types=types, flags=flags, input_kind=input_kind, time_slices=ts)
     launch = batch.launch_info()                   # launch units per submit and how they are joined (the library's choice at these flags)
     turn = [0]
 
@@ -291,7 +292,7 @@ def config1_run(args):
     import oracle_lib
     from sdrpp_radiosonde_amd import _lib, synth
     n = 480000 // 2048 * 2048 + 2048
-    sb = synth.make_rs41_batch(1, n, seed=4100, ebn0_db=15.0)
+    sb = synth.make_rs41_batch(1, n, seed=4100, ebn0_db=22.0)
     iq = sb.iq.numpy()
     oracle_lib.batch_run(0, iq[:, :8192], nthreads=1)
     t0 = time.perf_counter()
@@ -365,7 +366,7 @@ def other_configs(args, rank, local_rank, world, dev, barrier, reduce_max_sum, s
         others["rt1250_host_e2e_cs8"]["workload"] = "the same from 8-bit integer IQ in host memory (SONDE_INPUT_IQ8)"
     except Exception as e:                    # (never lets the line fail: the headline above does not depend on it)
         others["rt1250_host_e2e"] = {"error": f"{type(e).__name__}: {e}"}
-    for name, S, B in (("wideband", 1, 1), ("wideband8", 8, 1), ("wideband8_dense", 8, 1), ("wideband8x4", 8, 4), ("wideband4_dual", 4, 1), ("wideband8_cs16", 8, 1)):
+    for name, S, B in (("wideband", 1, 1), ("wideband1x8", 1, 8), ("wideband8", 8, 1), ("wideband8_dense", 8, 1), ("wideband8x4", 8, 4), ("wideband4_dual", 4, 1), ("wideband8_cs16", 8, 1)):
         import copy
         a = copy.copy(args)
         a.wb_streams, a.wb_blocks = S, B

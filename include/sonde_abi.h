@@ -127,9 +127,13 @@ typedef struct {
 	uint32_t       struct_size;      /* sizeof(SondeBatchConfig) as the caller compiled it (SONDE_BATCH_CONFIG_INIT sets it).  sonde_batch_create
 	                                    REFUSES any other value: a caller built against an older, shorter header, or one that did not zero the
 	                                    struct, fails loudly instead of handing over garbage in the members it does not know */
+	uint32_t       time_slices;      /* 0 = the library's choice; 1 = never; n = cut every channel's submit into n consecutive segments, each its own
+	                                    workgroup (round 6: a launch whose workgroup count does not fill whole residencies of the GPU no longer ends with
+	                                    a part-filled generation running alone; same frames, bit for bit: a segment is to the arithmetic what a submit is;
+	                                    DESIGN 5).  Measurements and tests set it; hosts leave it 0 */
 } SondeBatchConfig;
 /* SondeBatchConfig cfg = SONDE_BATCH_CONFIG_INIT;  -- everything zero (= defaults), struct_size filled in */
-#define SONDE_BATCH_CONFIG_INIT { 0, NULL, 0, 0, 0, 0, 0, (uint32_t)sizeof(SondeBatchConfig) }
+#define SONDE_BATCH_CONFIG_INIT { 0, NULL, 0, 0, 0, 0, 0, (uint32_t)sizeof(SondeBatchConfig), 0 }
 
 /* One decimation step less before the discriminator for every GFSK sonde (RS41 / DFM / iMS-100 / MRZ-N1 2:1 instead of 4:1:
  * 24 kS/s internally; M10 none instead of 2:1: 48 kS/s): tolerates about twice the carrier offset (+-5 kHz instead of +-2 kHz

@@ -42,6 +42,11 @@ void or_chan_twiddles(float *tw /* 2*256, (re, im) */)
 		tw[2 * k] = (float)cos(2.0 * CH_PI * (double)k / (double)OR_CH_M);
 		tw[2 * k + 1] = (float)(-sin(2.0 * CH_PI * (double)k / (double)OR_CH_M));
 	}
+	/* SPEC 3.5 (round 6): the TRIVIAL twiddles are exact.  tw[0] = (1, -0) already is; tw[128] = exp(-j pi / 2) is (0, -1), not the
+	 * (6.1e-17, -1) that cos(pi / 2) in double rounds to: multiplying by it is then a swap with one sign change, exactly (up to the sign
+	 * of a zero, which no later stage can turn into a different phase), and the GPU's wave-uniform butterflies of stages 1-3 use
+	 * additions only (csrc/channelizer.hip pfb_fft512n: 40 of a wave's ~800 vector instructions per step). */
+	tw[2 * 128] = 0.0f;
 }
 
 /* Rational resampler prototype (polyphase, `up` phases of OR_RS_T taps): Blackman-windowed sinc at up * rate_in with the

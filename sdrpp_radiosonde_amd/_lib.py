@@ -42,7 +42,7 @@ class SondeData(C.Structure):
 class SondeBatchConfig(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("types", C.POINTER(C.c_uint8)), ("max_samples", C.c_uint32),
                 ("input_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32), ("launch_units", C.c_uint32),
-                ("struct_size", C.c_uint32)]
+                ("struct_size", C.c_uint32), ("time_slices", C.c_uint32)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -104,7 +104,8 @@ def load() -> C.CDLL:
     L.sonde_batch_submit_host.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
     L.sonde_batch_sync.argtypes = [vp]
     L.sonde_batch_sync.restype = C.c_long
-    L.sonde_batch_wait_input.argtypes = [vp, vp]
+    if hasattr(L, "sonde_batch_wait_input"):              # absent only in older A/B builds loaded through SONDE_MI355_LIB
+        L.sonde_batch_wait_input.argtypes = [vp, vp]
     L.sonde_batch_frames.argtypes = [vp, vp, C.c_size_t]
     L.sonde_batch_frames.restype = C.c_long
     if hasattr(L, "sonde_batch_frames_of"):

@@ -21,7 +21,7 @@ class SondeBatch:
     [C, n, 2] float32 (IQ) or [C, n] float32 (discriminator samples), n % 2048 == 0.
     """
 
-    def __init__(self, n_channels: int, max_samples: int, *, types=None, input_kind: int = INPUT_IQ, device: int = 0, flags: int = 0):
+    def __init__(self, n_channels: int, max_samples: int, *, types=None, input_kind: int = INPUT_IQ, device: int = 0, flags: int = 0, time_slices: int = 0):
         self.L = _lib.load()
         self.n_channels = int(n_channels)
         self.max_samples = int(max_samples)
@@ -36,6 +36,7 @@ class SondeBatch:
             cfg.types = self._types.ctypes.data_as(C.POINTER(C.c_uint8))
         cfg.max_samples = self.max_samples
         cfg.flags = flags
+        cfg.time_slices = time_slices          # 0: the library's choice (SondeBatchConfig.time_slices)
         cfg.input_kind = input_kind
         cfg.device = device
         h = C.c_void_p()

@@ -180,12 +180,16 @@ struct SondeBatch {
 	hipStream_t done_stream = nullptr;
 	uint32_t granule = SONDE_TILE;         // submit sizes must be a multiple of this
 	// time slices (launch.h SdSlice): per-channel segment counters, the value they hold before the next sliced launch, the residency
-	// the policy works with (demod workgroups the GPU holds at once) and the knob (0: the library's choice; experiments: SONDE_SEG)
+	// the policy works with (demod workgroups the GPU holds at once) and the knob (SondeBatchConfig.time_slices; 0: the library's choice)
 	uint32_t *d_prog = nullptr;
 	uint32_t seg_base = 0;
 	uint32_t residency = 1024;
 	int seg_force = 0;
 	bool sliced_once = false;
+	// round 6: a batch of exactly the two default classes -- (4, 8): RS41 / DFM / iMS-100 / MRZ-N1 and (2, 8): M10; BASELINE config 3 --
+	// at the default completion mode is ONE launch on the caller's stream (sd_demod_mixed_kernel: the classes interleaved block by
+	// block), frame decoders in its epilogue: no fork, no join, no launch units
+	bool mixed_one = false;
 
 	static const int kEvSlots = 128;       // submits timed between two sonde_batch_kernel_ms() calls
 	hipEvent_t ev[3 * kEvSlots] = {};
@@ -242,6 +246,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	if (cfg->struct_size != sizeof(SondeBatchConfig))
 		return fail("sonde_batch_create: SondeBatchConfig.struct_size != sizeof(SondeBatchConfig) -- initialise with SONDE_BATCH_CONFIG_INIT (a host built against an older sonde_abi.h must be recompiled)");
 	if (cfg->launch_units > 16) return fail("sonde_batch_create: launch_units must be 0 (the library's choice) or 1..16");
+	if (cfg->time_slices > 16) return fail("sonde_batch_create: time_slices must be 0 (the library's choice) or 1..16");
 	if (cfg->n_channels == 0) return fail("sonde_batch_create: n_channels == 0");
 	if (cfg->max_samples == 0 || cfg->max_samples % SONDE_TILE) return fail("sonde_batch_create: max_samples must be a positive multiple of SONDE_TILE");
 	if (cfg->input_kind != SONDE_INPUT_IQ && cfg->input_kind != SONDE_INPUT_REAL && cfg->input_kind != SONDE_INPUT_IQ16 && cfg->input_kind != SONDE_INPUT_IQ8)
@@ -446,7 +451,6 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			hipDeviceProp_t prop;
 			CHK(hipGetDeviceProperties(&prop, cfg->device));
 			const uint32_t loop_wg = 4u * (uint32_t)prop.multiProcessorCount;
-			if (const char *e = getenv("SONDE_FIXED_EPI")) b->fixed_epi = atoi(e) ? 1u : 0u;       // (A/B experiment knob of round 6; removed once decided)
 			if (!b->fuse_fec) b->fixed_epi = 0;
 			const SdFramerOut fo = { b->d_fstates, b->d_descs, b->d_counts2[k], b->max_frames, b->fuse_fec, loop_wg, b->d_gfexp, b->d_gflog, b->d_gfswar, b->d_g64, b->d_frames2[k],
 			                         b->d_m10tab, b->fixed_epi };
@@ -472,7 +476,7 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 	{
 		hipDeviceProp_t pr;
 		if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) b->residency = 4u * (uint32_t)pr.multiProcessorCount;
-		if (const char *e = getenv("SONDE_SEG")) b->seg_force = atoi(e);        // (experiment knob of round 6)
+		b->seg_force = (int)cfg->time_slices;
 	}
 	CHK(hipMemset(b->d_hist, 0, C * SD_HIST * sizeof(float)));
 	CHK(hipMemset(b->d_bitring, 0, C * (size_t)b->ring_words * sizeof(uint32_t)));
@@ -521,6 +525,12 @@ extern "C" int sonde_batch_create(const SondeBatchConfig *cfg, SondeBatch **out)
 			if (b->chlist[t].empty()) continue;
 			b->units.push_back({ t, 0, 0, (uint32_t)b->chlist[t].size(), row0, nullptr, { nullptr, nullptr } });
 			row0 += b->chlist[t].size();
+		}
+		{
+			if (b->join_mode == 0 && n_afsk == 0 && b->n_classes == 2 && b->n_cls[2] && b->n_cls[3] && b->fuse_fec && b->fixed_epi) {
+				b->mixed_one = true;
+				b->units.clear();              // (d_cls[2], d_cls[3] stay: the kernel's two channel lists)
+			}
 		}
 		for (auto &u : b->units) {
 			CHK(hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking));
@@ -584,24 +594,34 @@ int sd_batch_submit_bins(SondeBatch *b, const SdBinsArgs *ba, size_t n_steps, vo
 	return submit_impl(b, ba->phases, n_out, ba->row_stride, stream_, ba);
 }
 
-// Time slices of one demod launch of n_wg workgroups that shares the GPU with total_wg workgroups in all (the submit's launch units run
-// side by side): the number of segments S (1: unsliced).  Cost model in tile-times: generations x tiles per segment, a generation being
-// one residency of workgroups; S among the divisors-ish {1, 2, 3, 4, 6, 8} with at least 6 tiles per segment; ties go to the smaller S.
+// Time slices of one demod launch that shares the GPU with total_wg workgroups in all: the number of segments S (1: unsliced).
+// Cost model fitted to measurements (profiles/r6_ab_seg.txt, MI355X), in units of one tile of a fully occupied GPU (2.69 us): a
+// generation of workgroups costs its tiles -- at the rate of its occupancy, a workgroup in a part-filled generation running up to
+// 1 / 0.67 times faster -- plus 2.6 tile-times of start and epilogue (7 us: state -> taps -> first tile's round trip; the last rounds,
+// K4's catch-up, the frame decoders).  Short segments lose to that overhead: at least 12 tiles per segment.  What it buys: 1280 x 96
+// tiles 0.636 -> 0.713 of the HBM peak (S = 2 or 4), 1250 x 24 0.551 -> 0.58 (S = 2); launches that fill whole residencies, and the
+// one-residency headline, stay unsliced (S = 2 there: -5 %).  Only at the default completion mode: the late-joined modes hide the tail
+// behind the next submit instead.
 static int choose_segments(const SondeBatch *b, uint32_t n_wg, uint32_t total_wg, int n_tiles)
 {
+	(void)n_wg;
 	if (b->seg_force > 0) return (b->seg_force <= n_tiles && total_wg > 0) ? b->seg_force : 1;
-	if (total_wg <= b->residency) return 1;                 // every workgroup is resident at once: nothing to balance
-	static const int cand[] = { 1, 2, 3, 4, 6, 8 };
+	if (b->join_mode != 0 || total_wg <= b->residency) return 1;
+	static const int cand[] = { 1, 2, 4, 8 };
 	int best = 1;
-	uint64_t best_cost = ~0ull;
+	double best_cost = 1e30;
 	for (int S : cand) {
 		const int st = (n_tiles + S - 1) / S;
-		if (S > 1 && (st < 6 || n_tiles % S)) continue;
-		const uint64_t gens = ((uint64_t)total_wg * (uint64_t)S + b->residency - 1) / b->residency;
-		const uint64_t cost = gens * (uint64_t)st * 16 + (uint64_t)S;      // (+ S: a segment's prologue / epilogue is not free)
-		if (cost < best_cost) { best_cost = cost; best = S; }
+		if (S > 1 && (st < 12 || n_tiles % S)) continue;
+		double cost = 0.0;
+		for (uint64_t left = (uint64_t)total_wg * (uint64_t)S; left > 0;) {
+			const uint64_t g = left < b->residency ? left : b->residency;
+			const double occ = (double)g / (double)b->residency;
+			cost += (double)st * (occ < 0.67 ? 0.67 : occ) + 2.6;
+			left -= g;
+		}
+		if (cost < best_cost * 0.98) { best_cost = cost; best = S; }      // (a larger S must win by 2 %)
 	}
-	(void)n_wg;
 	return best;
 }
 
@@ -668,7 +688,12 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 		b->sliced_once = true;
 		return &sl;
 	};
-	if (one_launch) {
+	if (b->mixed_one && !bins_in) {
+		sd_launch_demod_mixed(iq, b->n_cls[2], b->d_cls[2], b->cls_type[2], b->n_cls[3], b->d_cls[3], b->cls_type[3], stream, (const float *)samples, channel_stride,
+			n_tiles, b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, fo);
+		HIPCHK(hipGetLastError());
+		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
+	} else if (one_launch) {
 		if (bins_in)      // channelizer bins: one wave per bin (bins_kernel.hip); n_tiles = 3 per block of 2560 phases
 			sd_launch_bins(b->n_channels, stream, bins_in->phases, bins_in->row_stride, n_tiles / 3, bins_in->carry_rows, bins_in->carry_stride,
 				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->h_modems, &b->h_fo2[slot], bins_in->g_comp, b->cls_type[b->only_class]);

@@ -93,6 +93,20 @@ __device__ __forceinline__ void pfb_bfly(float2 &a, float2 &b, const float2 w)
 // (Round 4 wrote the window bit-reversed -- a 4-way conflicting scatter that cost as much LDS time as the fold, r5_notes.md.)
 // The twiddles of passes 2 and 3 depend on the lane alone: tw2 / tw3 hold them in registers (read from global memory at the head
 // of the kernel, L1 hits), pass 1's are three wave-uniform values.
+// The two TRIVIAL twiddles, exact (SPEC 3.5, round 6): t = b * (1, -0) = b and t = b * (0, -1) = (b.im, -b.re): additions only.  With the
+// table's entries 0 and 128 exact these are what pfb_bfly computes, up to the sign of a zero (which cannot change a phase).
+__device__ __forceinline__ void pfb_bfly_one(float2 &a, float2 &b)
+{
+	const float2 a0 = a, b0 = b;
+	a = make_float2(a0.x + b0.x, a0.y + b0.y);
+	b = make_float2(a0.x - b0.x, a0.y - b0.y);
+}
+__device__ __forceinline__ void pfb_bfly_mj(float2 &a, float2 &b)
+{
+	const float2 a0 = a, b0 = b;
+	a = make_float2(a0.x + b0.y, a0.y - b0.x);
+	b = make_float2(a0.x - b0.y, a0.y + b0.x);
+}
 struct PfbTw { float2 a2, b2[2], c2[4], a3, b3[2], c3[4]; };
 __device__ __forceinline__ PfbTw pfb_load_tw(const float2 *__restrict__ tw, int lane)
 {
@@ -115,15 +129,15 @@ __device__ __forceinline__ void pfb_fft512n(float2 *fb, const float2 w64 /* tw[6
                                             const PfbTw &t, int lane, float2 (&e)[8])
 {
 	constexpr int BR3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-	const float2 w0 = make_float2(1.0f, -0.0f);                  // tw[0] = (cos 0, -sin 0)
+	(void)w128;                                                  // (exact since round 6: pfb_bfly_mj)
 	// pass 1
 #pragma unroll
 	for (int j = 0; j < 8; j++) e[j] = fb[lane + 64 * BR3[j]];
 #pragma unroll
-	for (int j = 0; j < 8; j += 2) pfb_bfly(e[j], e[j + 1], w0);
+	for (int j = 0; j < 8; j += 2) pfb_bfly_one(e[j], e[j + 1]);
 #pragma unroll
-	for (int j = 0; j < 8; j++) if ((j & 2) == 0) pfb_bfly(e[j], e[j + 2], (j & 1) ? w128 : w0);
-	pfb_bfly(e[0], e[4], w0); pfb_bfly(e[1], e[5], w64); pfb_bfly(e[2], e[6], w128); pfb_bfly(e[3], e[7], w192);
+	for (int j = 0; j < 8; j++) if ((j & 2) == 0) { if (j & 1) pfb_bfly_mj(e[j], e[j + 2]); else pfb_bfly_one(e[j], e[j + 2]); }
+	pfb_bfly_one(e[0], e[4]); pfb_bfly(e[1], e[5], w64); pfb_bfly_mj(e[2], e[6]); pfb_bfly(e[3], e[7], w192);
 	PFB_WSYNC();
 #pragma unroll
 	for (int j = 0; j < 8; j++) fb[72 * j + lane] = e[j];
@@ -463,6 +477,7 @@ static void make_tables(std::vector<float> &h, std::vector<float> &tw, std::vect
 		tw[2 * k] = (float)cos(2.0 * PI * (double)k / (double)CH_M);
 		tw[2 * k + 1] = (float)(-sin(2.0 * PI * (double)k / (double)CH_M));
 	}
+	tw[2 * 128] = 0.0f;          // SPEC 3.5 (round 6): exp(-j pi / 2) = (0, -1) exactly (oracle or_chan_twiddles: the same line)
 	{
 		const int N = RS_UP * RS_TAPS;
 		const double fc = 9000.0 / 240000.0;         // 0.45 x the 20 kS/s input rate: the VFO front-end's 20 kS/s taps (vfo.hip)

@@ -77,6 +77,35 @@ static __device__ __forceinline__ float4 sd_cs16_f4(uint2 q)
 	return make_float4((float)(int16_t)(q.x & 0xffffu), (float)((int32_t)q.x >> 16), (float)(int16_t)(q.y & 0xffffu), (float)((int32_t)q.y >> 16));
 }
 
+// ---- carried per-channel data (state, history, bit-ring words, framer state, frame count).  In a time-sliced launch (launch.h SdSlice)
+// it crosses from one workgroup to the next of the same channel INSIDE the launch, possibly from one XCD's L2 to another's.  Fencing that
+// hand-over at agent scope costs an L2-wide write-back per release and an invalidate per acquire -- measured: 8 fences per workgroup made a
+// sliced launch 3-10 x slower (profiles/r6_notes.md).  So the data itself is accessed coherently instead: agent-scope relaxed atomic loads
+// and stores (the sc1 bit: served at the device's coherence point, never from a stale L1 / L2 line; stores write through), the few hundred
+// bytes per workgroup that they are.  Every launch does it (sliced or not: a cold miss either way), so there is one code path.
+template <typename T> static __device__ __forceinline__ T sd_ld_coh(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> static __device__ __forceinline__ void sd_st_coh(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ float sd_ld_coh_f(const float *p) { return __builtin_bit_cast(float, sd_ld_coh(reinterpret_cast<const uint32_t *>(p))); }
+static __device__ __forceinline__ void sd_st_coh_f(float *p, float v) { sd_st_coh(reinterpret_cast<uint32_t *>(p), __builtin_bit_cast(uint32_t, v)); }
+template <typename S> static __device__ __forceinline__ S sd_ld_coh_struct(const S *p)
+{
+	static_assert(sizeof(S) % 8 == 0, "whole qwords");
+	unsigned long long w[sizeof(S) / 8];
+#pragma unroll
+	for (unsigned i = 0; i < sizeof(S) / 8; i++) w[i] = sd_ld_coh(reinterpret_cast<const unsigned long long *>(p) + i);
+	S s;
+	__builtin_memcpy(&s, w, sizeof(S));
+	return s;
+}
+template <typename S> static __device__ __forceinline__ void sd_st_coh_struct(S *p, const S &s)
+{
+	static_assert(sizeof(S) % 8 == 0, "whole qwords");
+	unsigned long long w[sizeof(S) / 8];
+	__builtin_memcpy(w, &s, sizeof(S));
+#pragma unroll
+	for (unsigned i = 0; i < sizeof(S) / 8; i++) sd_st_coh(reinterpret_cast<unsigned long long *>(p) + i, w[i]);
+}
+
 #define SD_BUF     (SD_LH + SD_TILE + 4)
 #define SD_WGT     512    // workgroup: waves 0-3 run the timing-loop rounds, waves 4-7 the discriminator
 // K4 (sync search) runs on round wave 3; on a discriminator wave it measured equal for RS41 and 40 % slower for DFM (profiles/r2_notes.md)
@@ -141,9 +170,11 @@ static_assert(8 * sizeof(FixedLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "pe
 // (2, 8) M10, (2, 16) and (1, 16) the same two groups under SONDE_FLAG_WIDE, (1, 16) also the 6 kS/s AFSK streams.
 // IN: what `in` holds per channel: SD_IN_REAL 48 kS/s discriminator samples, SD_IN_IQ 48 kS/s complex samples, SD_IN_IQ16 / SD_IN_IQ8 the
 // same as 16- / 8-bit integer pairs.  (Channelizer bins have their own kernel: bins_kernel.hip, one wave per bin.)
+// The kernel's BODY, a device function so that two classes can share one launch (sd_demod_mixed_kernel below): bidx = the workgroup's
+// index in ITS launch (or in its class's share of a mixed launch), grid_wg = the workgroups that share the GPU with it (the in-loop FEC's
+// one-residency test), s = the workgroup's LDS (declared once, by the __global__ wrapper).
 template <int IN, bool LIST, int DEC, int NT>
-// (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU)
-__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
+__device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, const uint32_t grid_wg,
 	const float *__restrict__ in, size_t ch_stride, int n_tiles_all,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
 	uint32_t *__restrict__ bitring, uint32_t ring_words,
@@ -156,7 +187,6 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// what one lane holds per load: two input samples (IQ; four in the integer 4:1 classes), four (real)
 	using LoadT = typename std::conditional<IQ8, typename std::conditional<IQ16D4, uint2, uint32_t>::type,
 	              typename std::conditional<IQ16, typename std::conditional<IQ16D4, uint4, uint2>::type, float4>::type>::type;
-	__shared__ __attribute__((aligned(16))) DemodLds s;
 
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
@@ -167,8 +197,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// time slices (launch.h SdSlice): block b works on segment b / n_wg of list entry b % n_wg; a segment is a submit of its own to
 	// everything below (its tiles start at `src`, n_tiles of them; the state comes from and goes back to HBM)
 	const bool sliced = sl.n_seg > 1;
-	const int seg = sliced ? (int)(blockIdx.x / sl.n_wg) : 0;
-	const uint32_t wgi = sliced ? blockIdx.x - (uint32_t)seg * sl.n_wg : blockIdx.x;
+	const int seg = sliced ? (int)(bidx / sl.n_wg) : 0;
+	const uint32_t wgi = sliced ? bidx - (uint32_t)seg * sl.n_wg : bidx;
 	const int n_tiles = sliced ? min(sl.seg_tiles, n_tiles_all - seg * sl.seg_tiles) : n_tiles_all;
 	const uint32_t ch = LIST ? chlist[wgi] : wgi;                      // channel (state, bit ring)
 	const uint32_t row = (LIST && compact_in) ? wgi : ch;              // row of `in`
@@ -211,9 +241,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	}
 
 	// time slices: segment s > 0 starts where segment s - 1 of the same channel stopped: wait until that workgroup has published its
-	// state (its block index is lower: it was dispatched earlier).  One lane polls, the rest wait at the barrier; then every wave
-	// acquires at agent scope (the predecessor may have run on another XCD: its L2 wrote back on release, ours drops stale lines) and
-	// the scalar cache is emptied (this CU may have read the channel's state for an earlier segment).
+	// state (its block index is lower: it was dispatched earlier).  One lane polls, the rest wait at the barrier.
 	if (sliced && seg > 0) {
 		if (tid == 0) {
 			const uint32_t want = sl.seg_base + (uint32_t)seg;
@@ -228,11 +256,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		}
 		__syncthreads();
 		if (s.pub.flag == 0xDEADu) return;         // (workgroup-uniform; the host finds the error word: never a hang)
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		__builtin_amdgcn_s_dcache_inv();
 		__syncthreads();                           // (pub.flag is rewritten by the prologue below)
+		// no acquire fence: everything the predecessor handed over is read through coherent loads (sd_ld_coh) below
 	}
-	SdChanState st = states[ch];
+	SdChanState st = sd_ld_coh_struct(states + ch);
 	// utype >= 0: every channel of this launch is of that sonde type (the host knows: one-type batches, per-type launch units), so
 	// the taps and modem parameters do not have to wait for the state
 	int stype;
@@ -264,8 +291,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			// by every round wave: unconditional loads (256 bytes each, L2 hits for three of the four waves) keep the three requests of a
 			// wave back to back; predicated ones made the compiler wait for the taps before the next request (register reuse)
 			const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(63 - lane);
-			const float hv = hist[(size_t)ch * SD_HIST + lane];
-			const uint32_t xw = ring_g[w & ring_mask];
+			const float hv = sd_ld_coh_f(hist + (size_t)ch * SD_HIST + lane);
+			const uint32_t xw = sd_ld_coh(ring_g + (w & ring_mask));
 			asm volatile("" :: "v"(hv), "v"(xw));      // (a use right here: without it the compiler sinks each load into the branch that stores it)
 			// pair-swapped rows (T[2i] = H[2i+1], T[2i+1] = H[2i]), see interp()
 			*reinterpret_cast<float4 *>(&s.taps[(tid >> 3) * SD_TAPS_LD + 4 * (tid & 7)]) = make_float4(tv.y, tv.x, tv.w, tv.z);
@@ -285,12 +312,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 			*reinterpret_cast<float4 *>(&s.taps[(tid >> 3) * SD_TAPS_LD + 4 * (tid & 7)]) = make_float4(tv.y, tv.x, tv.w, tv.z);
 			// restore the carried history in front of the first tile
 			if (tid < SD_LH) {
-				const float hv = hist[(size_t)ch * SD_HIST + tid];
+				const float hv = sd_ld_coh_f(hist + (size_t)ch * SD_HIST + tid);
 				s.A[0][tid] = hv;
 			}
 			if (tid == 0) {
 				s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
-				s.partial[0] = ((uint32_t)st.wpos & 31u) ? ring_g[(uint32_t)(st.wpos >> 5) & ring_mask] : 0u;
+				s.partial[0] = ((uint32_t)st.wpos & 31u) ? sd_ld_coh(ring_g + ((uint32_t)(st.wpos >> 5) & ring_mask)) : 0u;
 				s.pub.flag = 0;
 				s.pub.wpos = st.wpos;
 				s.afc_u[0] = st.afc[0]; s.afc_u[1] = st.afc[1]; s.afc_u[2] = st.afc[2];
@@ -311,7 +338,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10 || is_mrz));   // workgroup-uniform
 	if (!JOIN && framing && !is_k && tid >= SD_WG - SD_MIRROR_WORDS) {                      // round wave 3, the wave that runs K4
 		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WG - 1 - tid);       // the words up to and including wpos's
-		s.mirror[w & (SD_MIRROR_WORDS - 1)] = ring_g[w & ring_mask];
+		s.mirror[w & (SD_MIRROR_WORDS - 1)] = sd_ld_coh(ring_g + (w & ring_mask));
 	}
 
 	// K5/K6 in this kernel's epilogue: RS41 only (few, heavy frames per submit).  The short frames of the fixed-length
@@ -325,7 +352,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// once -- their epilogues coincide, nothing else streams meanwhile: 1024 x 96 tiles -1.6 % at 14 dB, -1.1 % at 9 dB -- and long
 	// enough (>= 48 tiles; at 24 the steps of the 1.6 frames a submit completes stall as much as they save).  In launches of several
 	// generations the epilogues overlap other workgroups' streaming for free and the steps only stall: 4096 x 96 tiles +7 %.
-	const bool fec_loop = fec_here && n_tiles >= 48 && gridDim.x <= fo->loop_fec_max_wg && !sliced;
+	const bool fec_loop = fec_here && n_tiles >= 48 && grid_wg <= fo->loop_fec_max_wg && !sliced;
 	FramerLds &loop_wl = *reinterpret_cast<FramerLds *>(&s.A[1][1100]);
 	static_assert(sizeof(FramerLds) <= (SD_BUF - 1100) * sizeof(float), "in-loop FEC work area");
 	if (tid == 3 * 64 - 1) { s.fec.frame = 0; s.fec.phase = 0; s.fec.done_mask = 0; }      // (wave 2: the wave that uses it)
@@ -566,7 +593,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 				vv = sh ? ((lo << sh) | (pvw >> (32u - sh))) : lo;
 				const uint32_t idx = (w0 + lane) & ring_mask;
 				if (lane == 0 && sh) vv |= s.partial[par] & ((1u << sh) - 1u);
-				ring_g[idx] = vv;
+				sd_st_coh(ring_g + idx, vv);
 				s.mirror[idx & (SD_MIRROR_WORDS - 1)] = vv;
 			}
 			// whoever owns the word the next round starts in publishes it (read after a barrier)
@@ -653,10 +680,10 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	// ---- the two roles run separate loops (so that neither carries the other's live registers) with the
 	// same number of s_barriers: one after the prologue, then `rounds` per tile.  is_k is wave-uniform.
 	auto k4_load = [&]() {         // one lane: the channel's search state into LDS
-		const SdFramerState f0 = fo->fstates[ch];
+		const SdFramerState f0 = sd_ld_coh_struct(fo->fstates + ch);
 		s.k4.rpos = f0.rpos; s.k4.fstart = f0.fstart; s.k4.collecting = f0.collecting; s.k4.inv = f0.inv; s.k4.flen = f0.flen;
 		// (time slices: a later segment appends to the frames its predecessors listed in this submit)
-		const uint32_t nout0 = (sliced && seg > 0) ? fo->counts[ch] : 0u;
+		const uint32_t nout0 = (sliced && seg > 0) ? sd_ld_coh(fo->counts + ch) : 0u;
 		s.k4.nout = nout0; s.nout0 = nout0; s.k4.wp_seen = st.wpos;
 	};
 	auto k4_run = [&](uint64_t wp) {   // one step of the channel's sync-search state machine (wave-uniform type dispatch)
@@ -673,8 +700,8 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		if (lane == 0) {
 			SdFramerState f1;
 			f1.rpos = s.k4.rpos; f1.fstart = s.k4.fstart; f1.collecting = s.k4.collecting; f1.inv = s.k4.inv; f1.flen = s.k4.flen; f1.pad = 0;
-			fo->fstates[ch] = f1;
-			fo->counts[ch] = s.k4.nout;
+			sd_st_coh_struct(fo->fstates + ch, f1);
+			sd_st_coh(fo->counts + ch, s.k4.nout);
 		}
 	};
 	if (is_k) {
@@ -794,12 +821,12 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 
 	// ---- common epilogue (after barrier E): carry history and state to the next submit
 	const int bl = (n_tiles - 1) & 1;
-	if (tid < SD_LH) hist[(size_t)ch * SD_HIST + tid] = s.A[bl][IT + tid];
+	if (tid < SD_LH) sd_st_coh_f(hist + (size_t)ch * SD_HIST + tid, s.A[bl][IT + tid]);
 	if (tid == 0) {
 		st.n0 = n0;
 		if (IS_IQ) { st.iq_last[0] = s.iq_last[0]; st.iq_last[1] = s.iq_last[1]; }
 		if (IS_IQ) { st.afc[0] = s.afc_u[n_tiles & 3]; st.afc[1] = s.afc_u[(n_tiles + 1) & 3]; st.afc[2] = s.afc_u[(n_tiles + 2) & 3]; }
-		states[ch] = st;
+		sd_st_coh_struct(states + ch, st);
 	}
 
 	// ---- K5/K6 (RS41 channels): the frames K4 listed in this submit, one per wave
@@ -872,13 +899,64 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 		}
 	}
 
-	// ---- time slices: hand the channel to its next segment.  Every wave releases what it wrote (state, history, ring words, framer
-	// state, descriptors, frame records) at agent scope, the barrier orders those releases before the one store that publishes.
+	// ---- time slices: hand the channel to its next segment.  What it will read (state, history, ring words, framer state, frame
+	// count) went out through write-through stores (sd_st_coh); every wave waits until its own have been acknowledged, the barrier
+	// collects the waves, one store publishes.  No release fence (an L2-wide write-back per workgroup: see sd_ld_coh above).
 	if (sliced) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 		__syncthreads();
-		if (tid == 0) __hip_atomic_store(&sl.prog[ch], sl.seg_base + (uint32_t)seg + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		if (tid == 0) sd_st_coh(&sl.prog[ch], sl.seg_base + (uint32_t)seg + 1u);
 	}
+}
+
+// (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU)
+template <int IN, bool LIST, int DEC, int NT>
+__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
+	const float *__restrict__ in, size_t ch_stride, int n_tiles_all,
+	SdChanState *__restrict__ states, float *__restrict__ hist,
+	uint32_t *__restrict__ bitring, uint32_t ring_words,
+	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
+	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, int utype, const SdSlice sl)
+{
+	__shared__ __attribute__((aligned(16))) DemodLds s;
+	sd_demod_body<IN, LIST, DEC, NT>(s, blockIdx.x, gridDim.x, in, ch_stride, n_tiles_all, states, hist, bitring, ring_words, taps_all, modems, chlist, compact_in, fo, utype, sl);
+}
+
+// ONE launch for a batch of the two default classes (round 6): (4, 8) -- RS41, DFM, iMS-100, MRZ-N1 -- and (2, 8) -- M10 --, i.e. BASELINE
+// config 3's mixed batch.  Rounds 2-5 launched one kernel per class (or per sonde type) on streams of their own, forked from and joined
+// back into the caller's stream: two cross-stream event hops per submit (tens of microseconds of command-processor latency at the
+// default, joined completion mode) and two tails.  Here block b takes the next channel of class B whenever floor((b + 1) nB / N) steps
+// (a Bresenham walk: the classes are interleaved in proportion, every CU holds both kinds of workgroup -- the M10 class is bound by the
+// vector ALU, the other by HBM --), else the next channel of class A.  The body of each class is the very code of its own kernel.
+template <int IN>
+__global__ __launch_bounds__(SD_WGT, 8) void sd_demod_mixed_kernel(
+	const float *__restrict__ in, size_t ch_stride, int n_tiles_all,
+	SdChanState *__restrict__ states, float *__restrict__ hist,
+	uint32_t *__restrict__ bitring, uint32_t ring_words,
+	const float *__restrict__ taps_all, const SdModem *__restrict__ modems,
+	const uint32_t *__restrict__ list_a, uint32_t n_a, int utype_a, const uint32_t *__restrict__ list_b, uint32_t n_b, int utype_b,
+	const SdFramerOut *__restrict__ fo)
+{
+	__shared__ __attribute__((aligned(16))) DemodLds s;
+	const uint32_t b = blockIdx.x, N = n_a + n_b;
+	const uint32_t ib = (uint32_t)(((unsigned long long)b * n_b) / N);                 // class-B blocks in front of this one
+	const bool is_b = (uint32_t)(((unsigned long long)(b + 1u) * n_b) / N) > ib;
+	const SdSlice sl = { 1, n_tiles_all, N, 0u, nullptr, 0u };
+	if (is_b) sd_demod_body<IN, true, 2, 8>(s, ib, N, in, ch_stride, n_tiles_all, states, hist, bitring, ring_words, taps_all, modems, list_b, 0, fo, utype_b, sl);
+	else sd_demod_body<IN, true, 4, 8>(s, b - ib, N, in, ch_stride, n_tiles_all, states, hist, bitring, ring_words, taps_all, modems, list_a, 0, fo, utype_a, sl);
+}
+
+void sd_launch_demod_mixed(int in_kind, uint32_t n_a, const uint32_t *list_a, int utype_a, uint32_t n_b, const uint32_t *list_b, int utype_b, hipStream_t stream,
+	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist, uint32_t *bitring, uint32_t ring_words,
+	const float *taps_all, const SdModem *modems, const SdFramerOut *fo)
+{
+	const dim3 g(n_a + n_b), blk(SD_WGT);
+#define SD_MIXED_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, list_a, n_a, utype_a, list_b, n_b, utype_b, fo
+	if (in_kind == SD_IN_IQ8) hipLaunchKernelGGL((sd_demod_mixed_kernel<SD_IN_IQ8>), g, blk, 0, stream, SD_MIXED_ARGS);
+	else if (in_kind == SD_IN_IQ16) hipLaunchKernelGGL((sd_demod_mixed_kernel<SD_IN_IQ16>), g, blk, 0, stream, SD_MIXED_ARGS);
+	else if (in_kind == SD_IN_IQ) hipLaunchKernelGGL((sd_demod_mixed_kernel<SD_IN_IQ>), g, blk, 0, stream, SD_MIXED_ARGS);
+	else hipLaunchKernelGGL((sd_demod_mixed_kernel<SD_IN_REAL>), g, blk, 0, stream, SD_MIXED_ARGS);
+#undef SD_MIXED_ARGS
 }
 
 void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,

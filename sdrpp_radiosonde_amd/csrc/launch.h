@@ -46,6 +46,11 @@ void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStr
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* DEVICE memory: the kernel reads it on demand */,
 	int utype /* >= 0: every channel of the launch is of this sonde type (taps / modem loads need not wait for the state); -1: per channel */,
 	const SdSlice *slice = nullptr /* null or n_seg <= 1: one workgroup per channel for the whole submit */);
+// One launch over the channels of the two default classes: list_a = the (4, 8) class's channels (RS41, DFM, iMS-100, MRZ-N1), list_b = the
+// (2, 8) class's (M10); utype_x >= 0: every channel of that list is of this sonde type (demod_kernel.hip sd_demod_mixed_kernel)
+void sd_launch_demod_mixed(int in_kind, uint32_t n_a, const uint32_t *list_a, int utype_a, uint32_t n_b, const uint32_t *list_b, int utype_b, hipStream_t stream,
+	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist, uint32_t *bitring, uint32_t ring_words,
+	const float *taps_all, const SdModem *modems, const SdFramerOut *fo /* DEVICE memory */);
 // The decoder behind the filter bank (bins_kernel.hip): one wave per bin; rows of 16-bit phases [16 carried | n_steps]; the last 16
 // phases of the submit go to the head of carry_rows' rows (the buffer the next submit reads: the same one unless double-buffered)
 struct SdBinsArgs { const int16_t *phases; size_t row_stride; int16_t *carry_rows; size_t carry_stride; const float *g_comp /* [3][SD_RS_KT_LD], device */; };

@@ -36,8 +36,9 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.SondeFrame) == 560 and _lib.FRAME_DTYPE.itemsize == 560
     assert _lib.SondeFrame.bitpos.offset == 24 and _lib.SondeFrame.data.offset == 32
-    assert C.sizeof(_lib.SondeBatchConfig) == 40 and _lib.SondeBatchConfig.launch_units.offset == 32      # (round 5: + launch_units)
-    assert _lib.SondeBatchConfig.struct_size.offset == 36 and _lib.SondeBatchConfig().struct_size == 40  # (round 6: + struct_size, in what was tail padding)
+    assert C.sizeof(_lib.SondeBatchConfig) == 48 and _lib.SondeBatchConfig.launch_units.offset == 32      # (round 5: + launch_units)
+    assert _lib.SondeBatchConfig.struct_size.offset == 36 and _lib.SondeBatchConfig().struct_size == 48  # (round 6: + struct_size, time_slices)
+    assert _lib.SondeBatchConfig.time_slices.offset == 40
     assert (_lib.FLAG_JOIN, _lib.FLAG_LATE_JOIN, _lib.FLAG_PIPELINE) == (16, 32, 4)
 
 
@@ -47,12 +48,14 @@ def test_config_struct_size_is_checked(lib):
     h = C.c_void_p()
     cfg = _lib.SondeBatchConfig()
     cfg.n_channels, cfg.max_samples = 4, 2048
-    for bad in (0, 32, 36, 0xDEADBEEF):
+    for bad in (0, 32, 40, 0xDEADBEEF):
         cfg.struct_size = bad
         assert lib.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0 and b"struct_size" in lib.sonde_last_error()
     cfg.struct_size = C.sizeof(cfg)
     cfg.launch_units = 17
     assert lib.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0 and b"launch_units" in lib.sonde_last_error()
+    cfg.launch_units, cfg.time_slices = 0, 99
+    assert lib.sonde_batch_create(C.byref(cfg), C.byref(h)) != 0 and b"time_slices" in lib.sonde_last_error()
 
 
 def test_tap_tables_equal_oracle_bit_for_bit(lib, oracle):

@@ -508,13 +508,13 @@ def test_wideband_scenes_low_snr_offsets_dual_integer_blocks(oracle, scene):
     nblk = 8
     if occ > 64:
         active = list(range(1, 512, 2))[:occ]
-        eb = ebn0 + 10.0 * np.log10(len(active) / 16.0)          # every transmitter brings its own white noise over the 10 MHz
+        eb = ebn0 + 10.0 * np.log10(len(active))                 # every transmitter brings its own white noise over the 10 MHz
         dfm = []
     else:
         rng = np.random.default_rng(seed)
         active = sorted(int(x) for x in rng.choice(np.arange(2, 510), size=occ, replace=False))
         dfm = [int(x) for x in rng.choice([b for b in range(2, 510) if b not in active], size=2, replace=False)]
-        eb = ebn0
+        eb = ebn0 + 10.0 * np.log10(len(active))                 # (the generator adds white noise once PER transmitter: this makes ebn0 the ratio a bin sees)
     scenes = [synth.make_wideband_rs41(active, nblk * BLOCK, seed=seed + s, ebn0_db=eb, device="cuda:0", offset_hz=offset)[0] for s in range(streams)]
     if occ > 64:
         scenes = [sc * min(1.0, 4.0 / np.sqrt(len(active))) for sc in scenes]

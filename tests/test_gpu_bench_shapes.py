@@ -68,7 +68,8 @@ def test_mix4096_five_blocks_back_to_back(oracle, flags):
     # (a) tickets, two submits in flight
     b = SondeBatch(C, n, types=types, flags=flags)
     info = b.launch_info()
-    assert info["join"] == _join_of(flags) and info["units"] >= 2
+    # (default flags: ONE launch over both classes, sd_demod_mixed_kernel; the opt-in modes: one unit per sonde type on its own stream)
+    assert info["join"] == _join_of(flags) and (info["units"] == 3 if flags else info["units"] == 1)
     b.ticket()
     per_ticket = []
     for k in range(NB):

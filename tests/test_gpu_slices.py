@@ -22,22 +22,6 @@ def _key(a):
     return a[np.lexsort((a["bitpos"], a["channel"]))]
 
 
-class _Slices:
-    """the segment count the library is told to use (the experiment / test knob SONDE_SEG, read at sonde_batch_create)"""
-    def __init__(self, n):
-        self.n = n
-
-    def __enter__(self):
-        self.old = os.environ.get("SONDE_SEG")
-        os.environ["SONDE_SEG"] = str(self.n)
-
-    def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("SONDE_SEG", None)
-        else:
-            os.environ["SONDE_SEG"] = self.old
-
-
 @pytest.mark.parametrize("sonde,C,tiles,seg", [(0, 1250, 24, 2), (0, 1250, 24, 4), (0, 300, 20, 3), (0, 2100, 12, 2), (1, 1100, 24, 4), (3, 1100, 24, 3), (2, 600, 24, 4), (6, 600, 24, 2)])
 def test_sliced_launch_equals_oracle(oracle, sonde, C, tiles, seg):
     """One sonde type, three consecutive submits (the third shorter: its tile count is not a multiple of the segment length)."""
@@ -46,8 +30,7 @@ def test_sliced_launch_equals_oracle(oracle, sonde, C, tiles, seg):
     total = 2 * n + short
     sb = synth.make_batch(sonde, C, total, seed=40 + sonde + seg, ebn0_db=13.0 if sonde == 0 else 15.0, device="cuda:0")
     types = None if sonde == 0 else np.full(C, sonde, dtype=np.uint8)
-    with _Slices(seg):
-        b = SondeBatch(C, n, types=types)
+    b = SondeBatch(C, n, types=types, time_slices=seg)
     parts = []
     for lo, ln in ((0, n), (n, n), (2 * n, short)):
         b.submit(strided_rows(sb.iq[:, lo: lo + ln].contiguous()))
@@ -61,14 +44,16 @@ def test_sliced_launch_equals_oracle(oracle, sonde, C, tiles, seg):
         ch.feed(host[c])
         rs, gs = ch.state(), b.state(c)
         assert (gs["t_next"], gs["period"], gs["bias"], gs["amp"]) == (rs["t_next"], rs["period"], rs["bias"], rs["amp"]), c
-        assert b.nbits(c) == len(ch.bits()) and np.array_equal(b.read_bits(c, 0, b.nbits(c))[-4000:], ch.bits()[-4000:])
+        nb = b.nbits(c)
+        assert nb == len(ch.bits()) and np.array_equal(b.read_bits(c, nb - 4000, 4000), ch.bits()[-4000:])
     b.close()
 
 
-@pytest.mark.parametrize("flags,seg,bits", [(0, 2, 0), (0, 4, 0), (32, 3, 0), (4, 2, 0), (0, 4, 16)])
+@pytest.mark.parametrize("flags,seg,bits", [(32, 2, 0), (32, 3, 0), (4, 2, 0), (4, 4, 16), (0, 0, 0), (0, 0, 16)])
 def test_sliced_mixed_batch_equals_oracle(oracle, flags, seg, bits):
-    """RS41 / M10 / DFM09 by channel % 3 (one launch per class or per type, each sliced), default flags, late-joined and never joined;
-    once as 16-bit integer rows."""
+    """RS41 / M10 / DFM09 by channel % 3.  Late-joined and never joined: one launch unit per sonde type on its own stream, each sliced
+    as told.  Default flags (seg 0): ONE launch over both demodulator classes (sd_demod_mixed_kernel, round 6; never sliced), float and
+    16-bit integer rows."""
     from sdrpp_radiosonde_amd import _lib
     C, tiles, NS = 3072, 24, 3
     n = tiles * TILE
@@ -92,8 +77,7 @@ def test_sliced_mixed_batch_equals_oracle(oracle, flags, seg, bits):
         r["channel"] = idx[r["channel"]]
         refs.append(r)
     ref = _key(np.concatenate(refs))
-    with _Slices(seg):
-        b = SondeBatch(C, n, types=types, flags=flags, input_kind=_lib.INPUT_IQ16 if bits else _lib.INPUT_IQ)
+    b = SondeBatch(C, n, types=types, flags=flags, input_kind=_lib.INPUT_IQ16 if bits else _lib.INPUT_IQ, time_slices=seg)
     b.ticket()
     st = torch.cuda.current_stream().cuda_stream
     blocks = [strided_rows(dev[:, k * n: (k + 1) * n].contiguous()) for k in range(NS)]

@@ -66,7 +66,7 @@ def test_node_of_several_shards_on_one_gpu(oracle, nd, ingest, layout, mode):
     import torch
     from sdrpp_radiosonde_amd import node, synth
     from sdrpp_radiosonde_amd.batch import row_stride, strided_rows
-    Cn, tiles, NS = 16 * nd + 5, 12, 3                  # 16 * nd + 5: unequal shards
+    Cn, tiles, NS = 16 * nd + 1, 12, 3                  # 16 * nd + 1: unequal shards (the first device takes the extra channel)
     n = tiles * TILE
     sb = synth.make_rs41_batch(Cn, NS * n, seed=70 + nd, ebn0_db=14.0, device="cuda:0")
     nd_obj = node.SondeNode(Cn, n, devices=(0,) * nd, ingest=ingest, scatter_mode=mode | node.TEST_SHARED_DEVICES, lib_path=build_fake_node_lib())
@@ -75,7 +75,7 @@ def test_node_of_several_shards_on_one_gpu(oracle, nd, ingest, layout, mode):
     assert spans[0][0] == 0 and spans[-1][1] == Cn and len({b - a for a, b in spans}) == 2
     peers_rows = Cn - (spans[ingest][1] - spans[ingest][0])
     _fake_stats(L)
-    parts = []
+    parts, frags = [], []
     for k in range(NS):
         blk = sb.iq[:, k * n: (k + 1) * n].contiguous()
         if layout == "reco":
@@ -84,6 +84,7 @@ def test_node_of_several_shards_on_one_gpu(oracle, nd, ingest, layout, mode):
             blk = strided_rows(blk, n + 6144)
         nd_obj.submit(blk)
         parts.append(nd_obj.frames().copy())
+        frags += nd_obj.poll()
         st = nd_obj.scatter_stats()
         sends, byts, groups = _fake_stats(L)
         assert st["bytes_from_ingest"] == peers_rows * n * 8 == byts, (k, st, byts)      # exactly the rows' bytes: no padding travels
@@ -98,7 +99,6 @@ def test_node_of_several_shards_on_one_gpu(oracle, nd, ingest, layout, mode):
     got = got[np.lexsort((got["bitpos"], got["channel"]))]
     ref = oracle.batch_run(0, sb.iq.cpu().numpy(), nthreads=os.cpu_count() or 4)
     assert len(ref) >= Cn and got.tobytes() == ref.tobytes()
-    frags = nd_obj.poll()
     assert len(frags) > 0 and max(c for c, _ in frags) >= spans[-1][0]                    # fragments carry node-wide channel numbers
     nd_obj.close()
 
