@@ -679,7 +679,8 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	uint32_t total_wg = b->n_channels;
 	if (!one_launch) { total_wg = 0; for (const SondeBatch::Unit &u : b->units) total_wg += u.n; }
 	int max_seg = 1;
-	auto slice_of = [&](uint32_t n_wg, int tiles, SdSlice &sl) -> const SdSlice * {
+	auto slice_of = [&](uint32_t n_wg, int tiles, SdSlice &sl, int decim, int nt) -> const SdSlice * {
+		if (!sd_slices_supported(iq, decim, nt)) return nullptr;
 		const int S = choose_segments(b, n_wg, total_wg, tiles);
 		if (S <= 1) return nullptr;
 		sl.seg_tiles = (tiles + S - 1) / S; sl.n_wg = n_wg; sl.seg_base = b->seg_base; sl.prog = b->d_prog; sl.err_index = b->n_channels;
@@ -701,7 +702,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 			SdSlice sl;
 			sd_launch_demod(iq, k_cls_decim[b->only_class], k_cls_nt[b->only_class], b->n_channels, stream, (const float *)samples, channel_stride, n_tiles,
 				b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems, nullptr, false, fo, b->cls_type[b->only_class],
-				slice_of(b->n_channels, n_tiles, sl));
+				slice_of(b->n_channels, n_tiles, sl, k_cls_decim[b->only_class], k_cls_nt[b->only_class]));
 		}
 		HIPCHK(hipGetLastError());
 		if (timed) HIPCHK(hipEventRecord(ev[1], stream));
@@ -730,7 +731,7 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 				sd_launch_demod(iq, k_cls_decim[u.cls], k_cls_nt[u.cls], u.n, u.st, (const float *)samples, channel_stride, n_tiles,
 					b->d_states, b->d_hist, b->d_bitring, b->ring_words, b->d_taps, b->d_modems,
 					u.type < 0 ? b->d_cls[u.cls] : b->d_chlist[u.type] + u.off, false, fo, u.type < 0 ? b->cls_type[u.cls] : u.type,
-					slice_of(u.n, n_tiles, sl));
+					slice_of(u.n, n_tiles, sl, k_cls_decim[u.cls], k_cls_nt[u.cls]));
 			}
 			HIPCHK(hipGetLastError());
 			if (timed) HIPCHK(hipEventRecord(ec[1], u.st));

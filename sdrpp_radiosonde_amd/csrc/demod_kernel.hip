@@ -82,13 +82,17 @@ static __device__ __forceinline__ float4 sd_cs16_f4(uint2 q)
 // hand-over at agent scope costs an L2-wide write-back per release and an invalidate per acquire -- measured: 8 fences per workgroup made a
 // sliced launch 3-10 x slower (profiles/r6_notes.md).  So the data itself is accessed coherently instead: agent-scope relaxed atomic loads
 // and stores (the sc1 bit: served at the device's coherence point, never from a stale L1 / L2 line; stores write through), the few hundred
-// bytes per workgroup that they are.  Every launch does it (sliced or not: a cold miss either way), so there is one code path.
-template <typename T> static __device__ __forceinline__ T sd_ld_coh(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> static __device__ __forceinline__ void sd_st_coh(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static __device__ __forceinline__ float sd_ld_coh_f(const float *p) { return __builtin_bit_cast(float, sd_ld_coh(reinterpret_cast<const uint32_t *>(p))); }
-static __device__ __forceinline__ void sd_st_coh_f(float *p, float v) { sd_st_coh(reinterpret_cast<uint32_t *>(p), __builtin_bit_cast(uint32_t, v)); }
-template <typename S> static __device__ __forceinline__ S sd_ld_coh_struct(const S *p)
+// bytes per workgroup that they are.  ONLY sliced launches do it (the `coh` argument, launch-uniform): a write-through store is
+// acknowledged later than a write-back one, and the round wave that appends the bits waits for its stores at every tile's barrier --
+// with coherent stores everywhere the unsliced headline lost 2.5 % and 8192 x 24 tiles 4.8 % (interleaved A/B against round 5's
+// library on one box, profiles/r6_ab_r5_vs_r6.txt).
+template <typename T> static __device__ __forceinline__ T sd_ld_coh(const T *p, bool coh = true) { return coh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; }
+template <typename T> static __device__ __forceinline__ void sd_st_coh(T *p, T v, bool coh = true) { if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; }
+static __device__ __forceinline__ float sd_ld_coh_f(const float *p, bool coh) { return coh ? __builtin_bit_cast(float, sd_ld_coh(reinterpret_cast<const uint32_t *>(p))) : *p; }
+static __device__ __forceinline__ void sd_st_coh_f(float *p, float v, bool coh) { if (coh) sd_st_coh(reinterpret_cast<uint32_t *>(p), __builtin_bit_cast(uint32_t, v)); else *p = v; }
+template <typename S> static __device__ __forceinline__ S sd_ld_coh_struct(const S *p, bool coh)
 {
+	if (!coh) return *p;
 	static_assert(sizeof(S) % 8 == 0, "whole qwords");
 	unsigned long long w[sizeof(S) / 8];
 #pragma unroll
@@ -97,8 +101,9 @@ template <typename S> static __device__ __forceinline__ S sd_ld_coh_struct(const
 	__builtin_memcpy(&s, w, sizeof(S));
 	return s;
 }
-template <typename S> static __device__ __forceinline__ void sd_st_coh_struct(S *p, const S &s)
+template <typename S> static __device__ __forceinline__ void sd_st_coh_struct(S *p, const S &s, bool coh)
 {
+	if (!coh) { *p = s; return; }
 	static_assert(sizeof(S) % 8 == 0, "whole qwords");
 	unsigned long long w[sizeof(S) / 8];
 	__builtin_memcpy(w, &s, sizeof(S));
@@ -173,7 +178,9 @@ static_assert(8 * sizeof(FixedLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "pe
 // The kernel's BODY, a device function so that two classes can share one launch (sd_demod_mixed_kernel below): bidx = the workgroup's
 // index in ITS launch (or in its class's share of a mixed launch), grid_wg = the workgroups that share the GPU with it (the in-loop FEC's
 // one-residency test), s = the workgroup's LDS (declared once, by the __global__ wrapper).
-template <int IN, bool LIST, int DEC, int NT>
+// SLICED: the time-sliced instantiation (launch.h SdSlice): a compile-time flag, so that an unsliced launch carries none of it -- with a
+// launch-uniform runtime flag the one-residency headline was 2.2 % slower than round 5's kernel (profiles/r6_ab_r5_vs_r6.txt).
+template <int IN, bool LIST, int DEC, int NT, bool SLICED = false>
 __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, const uint32_t grid_wg,
 	const float *__restrict__ in, size_t ch_stride, int n_tiles_all,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
@@ -196,7 +203,7 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 	const int rwave = wave & 3;
 	// time slices (launch.h SdSlice): block b works on segment b / n_wg of list entry b % n_wg; a segment is a submit of its own to
 	// everything below (its tiles start at `src`, n_tiles of them; the state comes from and goes back to HBM)
-	const bool sliced = sl.n_seg > 1;
+	constexpr bool sliced = SLICED;
 	const int seg = sliced ? (int)(bidx / sl.n_wg) : 0;
 	const uint32_t wgi = sliced ? bidx - (uint32_t)seg * sl.n_wg : bidx;
 	const int n_tiles = sliced ? min(sl.seg_tiles, n_tiles_all - seg * sl.seg_tiles) : n_tiles_all;
@@ -259,7 +266,7 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 		__syncthreads();                           // (pub.flag is rewritten by the prologue below)
 		// no acquire fence: everything the predecessor handed over is read through coherent loads (sd_ld_coh) below
 	}
-	SdChanState st = sd_ld_coh_struct(states + ch);
+	SdChanState st = sd_ld_coh_struct(states + ch, sliced);
 	// utype >= 0: every channel of this launch is of that sonde type (the host knows: one-type batches, per-type launch units), so
 	// the taps and modem parameters do not have to wait for the state
 	int stype;
@@ -291,8 +298,8 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 			// by every round wave: unconditional loads (256 bytes each, L2 hits for three of the four waves) keep the three requests of a
 			// wave back to back; predicated ones made the compiler wait for the taps before the next request (register reuse)
 			const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(63 - lane);
-			const float hv = sd_ld_coh_f(hist + (size_t)ch * SD_HIST + lane);
-			const uint32_t xw = sd_ld_coh(ring_g + (w & ring_mask));
+			const float hv = sd_ld_coh_f(hist + (size_t)ch * SD_HIST + lane, sliced);
+			const uint32_t xw = sd_ld_coh(ring_g + (w & ring_mask), sliced);
 			asm volatile("" :: "v"(hv), "v"(xw));      // (a use right here: without it the compiler sinks each load into the branch that stores it)
 			// pair-swapped rows (T[2i] = H[2i+1], T[2i+1] = H[2i]), see interp()
 			*reinterpret_cast<float4 *>(&s.taps[(tid >> 3) * SD_TAPS_LD + 4 * (tid & 7)]) = make_float4(tv.y, tv.x, tv.w, tv.z);
@@ -312,12 +319,12 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 			*reinterpret_cast<float4 *>(&s.taps[(tid >> 3) * SD_TAPS_LD + 4 * (tid & 7)]) = make_float4(tv.y, tv.x, tv.w, tv.z);
 			// restore the carried history in front of the first tile
 			if (tid < SD_LH) {
-				const float hv = sd_ld_coh_f(hist + (size_t)ch * SD_HIST + tid);
+				const float hv = sd_ld_coh_f(hist + (size_t)ch * SD_HIST + tid, sliced);
 				s.A[0][tid] = hv;
 			}
 			if (tid == 0) {
 				s.chunk[0][0] = 0; s.chunk[0][9] = 0; s.chunk[1][0] = 0; s.chunk[1][9] = 0; s.chunk[0][17] = 0; s.chunk[1][17] = 0;
-				s.partial[0] = ((uint32_t)st.wpos & 31u) ? sd_ld_coh(ring_g + ((uint32_t)(st.wpos >> 5) & ring_mask)) : 0u;
+				s.partial[0] = ((uint32_t)st.wpos & 31u) ? sd_ld_coh(ring_g + ((uint32_t)(st.wpos >> 5) & ring_mask), sliced) : 0u;
 				s.pub.flag = 0;
 				s.pub.wpos = st.wpos;
 				s.afc_u[0] = st.afc[0]; s.afc_u[1] = st.afc[1]; s.afc_u[2] = st.afc[2];
@@ -338,7 +345,7 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 	const bool framing = is_rs41 || (fuse && (is_dfm || is_ims || is_m10 || is_mrz));   // workgroup-uniform
 	if (!JOIN && framing && !is_k && tid >= SD_WG - SD_MIRROR_WORDS) {                      // round wave 3, the wave that runs K4
 		const uint32_t w = (uint32_t)(st.wpos >> 5) - (uint32_t)(SD_WG - 1 - tid);       // the words up to and including wpos's
-		s.mirror[w & (SD_MIRROR_WORDS - 1)] = sd_ld_coh(ring_g + (w & ring_mask));
+		s.mirror[w & (SD_MIRROR_WORDS - 1)] = sd_ld_coh(ring_g + (w & ring_mask), sliced);
 	}
 
 	// K5/K6 in this kernel's epilogue: RS41 only (few, heavy frames per submit).  The short frames of the fixed-length
@@ -593,7 +600,7 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 				vv = sh ? ((lo << sh) | (pvw >> (32u - sh))) : lo;
 				const uint32_t idx = (w0 + lane) & ring_mask;
 				if (lane == 0 && sh) vv |= s.partial[par] & ((1u << sh) - 1u);
-				sd_st_coh(ring_g + idx, vv);
+				sd_st_coh(ring_g + idx, vv, sliced);
 				s.mirror[idx & (SD_MIRROR_WORDS - 1)] = vv;
 			}
 			// whoever owns the word the next round starts in publishes it (read after a barrier)
@@ -680,7 +687,7 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 	// ---- the two roles run separate loops (so that neither carries the other's live registers) with the
 	// same number of s_barriers: one after the prologue, then `rounds` per tile.  is_k is wave-uniform.
 	auto k4_load = [&]() {         // one lane: the channel's search state into LDS
-		const SdFramerState f0 = sd_ld_coh_struct(fo->fstates + ch);
+		const SdFramerState f0 = sd_ld_coh_struct(fo->fstates + ch, sliced);
 		s.k4.rpos = f0.rpos; s.k4.fstart = f0.fstart; s.k4.collecting = f0.collecting; s.k4.inv = f0.inv; s.k4.flen = f0.flen;
 		// (time slices: a later segment appends to the frames its predecessors listed in this submit)
 		const uint32_t nout0 = (sliced && seg > 0) ? sd_ld_coh(fo->counts + ch) : 0u;
@@ -700,8 +707,8 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 		if (lane == 0) {
 			SdFramerState f1;
 			f1.rpos = s.k4.rpos; f1.fstart = s.k4.fstart; f1.collecting = s.k4.collecting; f1.inv = s.k4.inv; f1.flen = s.k4.flen; f1.pad = 0;
-			sd_st_coh_struct(fo->fstates + ch, f1);
-			sd_st_coh(fo->counts + ch, s.k4.nout);
+			sd_st_coh_struct(fo->fstates + ch, f1, sliced);
+			sd_st_coh(fo->counts + ch, s.k4.nout, sliced);
 		}
 	};
 	if (is_k) {
@@ -821,12 +828,12 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 
 	// ---- common epilogue (after barrier E): carry history and state to the next submit
 	const int bl = (n_tiles - 1) & 1;
-	if (tid < SD_LH) sd_st_coh_f(hist + (size_t)ch * SD_HIST + tid, s.A[bl][IT + tid]);
+	if (tid < SD_LH) sd_st_coh_f(hist + (size_t)ch * SD_HIST + tid, s.A[bl][IT + tid], sliced);
 	if (tid == 0) {
 		st.n0 = n0;
 		if (IS_IQ) { st.iq_last[0] = s.iq_last[0]; st.iq_last[1] = s.iq_last[1]; }
 		if (IS_IQ) { st.afc[0] = s.afc_u[n_tiles & 3]; st.afc[1] = s.afc_u[(n_tiles + 1) & 3]; st.afc[2] = s.afc_u[(n_tiles + 2) & 3]; }
-		sd_st_coh_struct(states + ch, st);
+		sd_st_coh_struct(states + ch, st, sliced);
 	}
 
 	// ---- K5/K6 (RS41 channels): the frames K4 listed in this submit, one per wave
@@ -910,7 +917,7 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 }
 
 // (every instantiation: 8 waves per SIMD = 64 VGPRs, four workgroups per CU)
-template <int IN, bool LIST, int DEC, int NT>
+template <int IN, bool LIST, int DEC, int NT, bool SLICED = false>
 __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const float *__restrict__ in, size_t ch_stride, int n_tiles_all,
 	SdChanState *__restrict__ states, float *__restrict__ hist,
@@ -919,7 +926,7 @@ __global__ __launch_bounds__(SD_WGT, 8) void sd_demod_kernel(
 	const uint32_t *__restrict__ chlist, int compact_in, const SdFramerOut *__restrict__ fo, int utype, const SdSlice sl)
 {
 	__shared__ __attribute__((aligned(16))) DemodLds s;
-	sd_demod_body<IN, LIST, DEC, NT>(s, blockIdx.x, gridDim.x, in, ch_stride, n_tiles_all, states, hist, bitring, ring_words, taps_all, modems, chlist, compact_in, fo, utype, sl);
+	sd_demod_body<IN, LIST, DEC, NT, SLICED>(s, blockIdx.x, gridDim.x, in, ch_stride, n_tiles_all, states, hist, bitring, ring_words, taps_all, modems, chlist, compact_in, fo, utype, sl);
 }
 
 // ONE launch for a batch of the two default classes (round 6): (4, 8) -- RS41, DFM, iMS-100, MRZ-N1 -- and (2, 8) -- M10 --, i.e. BASELINE
@@ -959,16 +966,35 @@ void sd_launch_demod_mixed(int in_kind, uint32_t n_a, const uint32_t *list_a, in
 #undef SD_MIXED_ARGS
 }
 
+bool sd_slices_supported(int in_kind, int decim, int nt)
+{
+	return (in_kind == SD_IN_IQ || in_kind == SD_IN_IQ16 || in_kind == SD_IN_IQ8) && nt == 8 && (decim == 4 || decim == 2);
+}
+
 void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
 	uint32_t *bitring, uint32_t ring_words, const float *taps_all, const SdModem *modems,
 	const uint32_t *chlist, bool compact_in, const SdFramerOut *fo /* device memory */, int utype, const SdSlice *slice)
 {
 	SdSlice sl = { 1, n_tiles, n_channels, 0u, nullptr, 0u };
-	if (slice && slice->n_seg > 1) sl = *slice;
-	const dim3 g(n_channels * (uint32_t)sl.n_seg), blk(SD_WGT);
 	const int ci = compact_in ? 1 : 0;
 #define SD_DEMOD_ARGS in, ch_stride, n_tiles, states, hist, bitring, ring_words, taps_all, modems, chlist, ci, fo, utype, sl
+	if (slice && slice->n_seg > 1 && sd_slices_supported(in_kind, decim, nt)) {
+		// the time-sliced instantiations: the two default classes, IQ input of every kind (the classes BASELINE's configurations run)
+		sl = *slice;
+		const dim3 gs(n_channels * (uint32_t)sl.n_seg), blks(SD_WGT);
+#define SD_SLICED_LAUNCH(KIND) do { \
+		if (decim == 4 && chlist) hipLaunchKernelGGL((sd_demod_kernel<KIND, true, 4, 8, true>), gs, blks, 0, stream, SD_DEMOD_ARGS); \
+		else if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<KIND, false, 4, 8, true>), gs, blks, 0, stream, SD_DEMOD_ARGS); \
+		else if (chlist) hipLaunchKernelGGL((sd_demod_kernel<KIND, true, 2, 8, true>), gs, blks, 0, stream, SD_DEMOD_ARGS); \
+		else hipLaunchKernelGGL((sd_demod_kernel<KIND, false, 2, 8, true>), gs, blks, 0, stream, SD_DEMOD_ARGS); } while (0)
+		if (in_kind == SD_IN_IQ8) SD_SLICED_LAUNCH(SD_IN_IQ8);
+		else if (in_kind == SD_IN_IQ16) SD_SLICED_LAUNCH(SD_IN_IQ16);
+		else SD_SLICED_LAUNCH(SD_IN_IQ);
+#undef SD_SLICED_LAUNCH
+		return;
+	}
+	const dim3 g(n_channels), blk(SD_WGT);
 #define SD_DEMOD_LAUNCH(KIND, LS) do { \
 		if (decim == 4) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 4, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \
 		else if (decim == 2 && nt == 8) hipLaunchKernelGGL((sd_demod_kernel<KIND, LS, 2, 8>), g, blk, 0, stream, SD_DEMOD_ARGS); \

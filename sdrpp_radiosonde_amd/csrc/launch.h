@@ -39,6 +39,8 @@ struct SdSlice {
 	uint32_t *prog;         // [n_channels of the batch + 1]: per channel the segments completed so far; the last word: poll gave up
 	uint32_t  err_index;    // = n_channels of the batch
 };
+// which launches have a time-sliced instantiation (the two default classes, IQ input of every kind); the host asks before it slices
+bool sd_slices_supported(int in_kind, int decim, int nt);
 // in_kind: what the 48 kS/s rows hold (SD_IN_REAL / SD_IN_IQ / SD_IN_IQ16 / SD_IN_IQ8)
 void sd_launch_demod(int in_kind, int decim, int nt, uint32_t n_channels, hipStream_t stream,
 	const float *in, size_t ch_stride, int n_tiles, SdChanState *states, float *hist,
