@@ -681,6 +681,10 @@ static int submit_impl(SondeBatch *b, const void *samples, size_t n_samples, siz
 	int max_seg = 1;
 	auto slice_of = [&](uint32_t n_wg, int tiles, SdSlice &sl, int decim, int nt) -> const SdSlice * {
 		if (!sd_slices_supported(iq, decim, nt)) return nullptr;
+		// the library slices by itself only a submit that is ONE launch: the no-deadlock argument of launch.h (a segment's predecessor
+		// has a lower block index of the same grid) is about one grid; several sliced grids side by side (launch units) run only when
+		// SondeBatchConfig.time_slices asks for them (tests), under the poll's give-up guard
+		if (!one_launch && b->seg_force <= 0) return nullptr;
 		const int S = choose_segments(b, n_wg, total_wg, tiles);
 		if (S <= 1) return nullptr;
 		sl.seg_tiles = (tiles + S - 1) / S; sl.n_wg = n_wg; sl.seg_base = b->seg_base; sl.prog = b->d_prog; sl.err_index = b->n_channels;

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5: every float class alone -- step times (4096 channels x 24 tiles and 1024 x 96) and SQ counters (LDS bank conflicts, VALU, waits)
-# usage (GPU box): TAG=r5 tools/r5_classes.sh  -> gpurun_out/${TAG}_class_counters.csv, ${TAG}_classes.txt
+# every float class alone -- step times (4096 channels x 24 tiles and 1024 x 96) and SQ counters (LDS bank conflicts, VALU, waits)
+# usage (GPU box): TAG=r6 tools/class_counters.sh  -> gpurun_out/${TAG}_class_counters.csv, ${TAG}_classes.txt
 export TMPDIR=/tmp
 R=$PWD
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 mkdir -p gpurun_out
 : > gpurun_out/${TAG}_classes.txt
 for t in 0 1 3; do

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""DESIGN.md section 6's table, from the files of ONE evidence run (tools/r5_evidence.sh on one box).
+"""DESIGN.md section 6's table, from the files of ONE evidence run (tools/evidence.sh on one box).
 
-  python tools/design_table.py profiles/r5           # prints the markdown
-  python tools/design_table.py profiles/r5 --write   # replaces the region between the r5-table markers of DESIGN.md
+  python tools/design_table.py profiles/r6           # prints the markdown
+  python tools/design_table.py profiles/r6 --write   # replaces the region between the table markers of DESIGN.md
 
 Reads <prefix>_bench.json (python bench.py), <prefix>_bench_driver_args.json (--steps 20 --warmup 5), <prefix>_rocprof.csv,
 <prefix>_wb_rocprof.csv, <prefix>_counters.csv, <prefix>_wb_counters.csv, <prefix>_pytest_gpu.log.  Nothing is typed in by hand."""
@@ -16,7 +16,12 @@ PARITY = {
     "contiguous_layout": "`test_rows_on_the_recommended_stride_and_host_staging`",
     "low_snr": "`test_headline_shape_at_9_db`",
     "mix4096": "`test_mix4096_five_blocks_back_to_back[0]`, `test_config3_4096_mixed_channels_full_size[0]`",
-    "mix4096_joined": "`test_config3_4096_mixed_channels_full_size[16]`",
+    "mix4096_late_join": "`test_mix4096_five_blocks_back_to_back[32]`, `test_config3_4096_mixed_channels_full_size[32]`",
+    "rt1250_late_join": "`test_part_filled_last_generation[1250-24-32]`",
+    "ch1280x96_late_join": "`test_part_filled_last_generation[1280-96-32]`",
+    "wideband1x8": "`test_fused_channelizer_frames_equal_oracle[5-1]` (5 blocks per submit; 8: the bench's)",
+    "config5_full_1gpu": "`test_config5_all_65536_channels_on_one_gpu`",
+    "config1_cpu_plumbing": "`test_config1_single_channel_cpu_plumbing_equals_the_gpu_decoder`",
     "shard8192": "`test_config5_shard_8192_rs41_channels`",
     "rt1250": "`test_part_filled_last_generation[1250-24-0]`",
     "ch1280x96": "`test_part_filled_last_generation[1280-96-0]`",
@@ -88,15 +93,22 @@ def main():
         rows.append(("`%s`" % k, shape, v["ms_per_step"], samples / v["ms_per_step"] / 1e6, "%.3f" % v["step_frac"], PARITY[k]))
     oc = d["other_configs"]
     for k, v in oc.items():
-        if k.startswith("rt1250_host_e2e"):
+        if k.startswith("rt1250_host_e2e") or k == "mix4096_joined" or "error" in v or "skipped" in v:
+            continue
+        if k == "config1_cpu_plumbing":
+            rows.append(("`%s`" % k, "1 RS41 channel x 481280 samples: the CPU port on one thread; beside it the B1 triple on the GPU", "%.2f (CPU)" % v["cpu"]["ms"],
+                         "%.3f (CPU)" % (v["cpu"]["value"] / 1e3), "B1: %.1f us per 0.1 s call" % v["gpu_b1"]["per_call_us_median"], PARITY[k]))
+            continue
+        if k == "config5_full_1gpu":
+            rows.append(("`%s`" % k, "65536 ch x 24 tiles through sonde_node, one device", v["ms_per_step"], v["value"] / 1e3, "%.3f" % v["step_frac"], PARITY[k]))
             continue
         if "channels" in v:
             shape = "%d ch x %d tiles, flags %d: %d unit%s, %s" % (v["channels"], v["samples_per_channel"] // 2048, v["flags"], v["launch_units"],
                                                                   "" if v["launch_units"] == 1 else "s", v["join"])
         else:
             m = re.search(r"(\d+) x 10 MS/s", v["workload"])
-            shape = "%s stream%s x %d block%s, %d of 512 bins occupied" % (m.group(1), "" if m.group(1) == "1" else "s", 4 if k.endswith("x4") else 1,
-                                                                        "s" if k.endswith("x4") else "", v["occupied_bins_per_stream"])
+            nb = 4 if k.endswith("x4") else (8 if k.endswith("x8") else 1)
+            shape = "%s stream%s x %d block%s, %d of 512 bins occupied" % (m.group(1), "" if m.group(1) == "1" else "s", nb, "s" if nb > 1 else "", v["occupied_bins_per_stream"])
             km = v["kernel_ms"]
             shape += "; filter bank %.1f + decoder %.1f us" % (1e3 * km.get("pfb_fft", 0), 1e3 * km.get("demod", 0))
         rows.append(("`%s`" % k, shape, v["ms_per_step"], v["value"] / 1e3, "%.3f" % v["step_frac"], PARITY.get(k, "")))
@@ -152,7 +164,7 @@ def main():
         p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "DESIGN.md")
         with open(p) as f:
             s = f.read()
-        a, b = "<!-- r5-table-begin -->", "<!-- r5-table-end -->"
+        a, b = "<!-- r6-table-begin -->", "<!-- r6-table-end -->"
         i, j = s.index(a) + len(a), s.index(b)
         with open(p, "w") as f:
             f.write(s[:i] + "\n" + text + "\n" + s[j:])

@@ -1,10 +1,10 @@
 #!/bin/bash
-# round-5 evidence run (one box): smoke, the GPU suite, the default bench line and the line with the driver's arguments, the rocprofv3
+# the round's evidence run (one box; TAG=r6 by default): smoke, the GPU suite, the default bench line and the line with the driver's arguments, the rocprofv3
 # kernel trace + stats of the headline command, separate --pmc passes (HBM traffic, SQ, LDS), the wideband traces and counters, the
 # yardstick and sensitivity tables from the HIP path.  Results land in gpurun_out/ (copy to profiles/).
 export TMPDIR=/tmp
 R=$PWD
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > gpurun_out/${TAG}_smoke.log 2>&1
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1
@@ -25,7 +25,7 @@ python tools/rocprof_summary.py $(find /tmp/p_trace -name '*.db') > gpurun_out/$
 python tools/rocprof_summary.py $(find /tmp/p_fetch /tmp/p_write /tmp/p_sq /tmp/p_lds -name '*.db') > gpurun_out/${TAG}_counters.csv 2>> gpurun_out/rocprof.err
 python tools/rocprof_summary.py $(find /tmp/p_wb -name '*.db') $(find /tmp/p_wb8 -name '*.db') > gpurun_out/${TAG}_wb_rocprof.csv 2>> gpurun_out/rocprof.err
 cp $(find /tmp/p_trace -name '*kernel_stats.csv' | head -1) gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
-TAG=${TAG} bash tools/r5_wb_counters.sh > /dev/null 2>&1
+TAG=${TAG} bash tools/wb_counters.sh > /dev/null 2>&1
 python tools/yardstick_study.py --gpu > gpurun_out/${TAG}_yardstick.md 2> gpurun_out/${TAG}_yardstick.err
 python tools/sensitivity.py > gpurun_out/${TAG}_sensitivity.md 2> gpurun_out/${TAG}_sensitivity.err
 cat gpurun_out/${TAG}_bench_driver_args.json | head -c 3000; echo; cat gpurun_out/${TAG}_rocprof.csv; grep -v read_probe gpurun_out/${TAG}_counters.csv; cat gpurun_out/${TAG}_wb_rocprof.csv

@@ -2,7 +2,7 @@
 # SQ / TCC counters of the filter-bank and decoder kernels of the wideband configuration (8 streams, 1 block per submit)
 export TMPDIR=/tmp
 R=$PWD
-out=gpurun_out/${TAG:-r5}_wb_counters.csv
+out=gpurun_out/${TAG:-r6}_wb_counters.csv
 : > $out
 i=0
 for pass in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
