@@ -271,16 +271,20 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		st.period += dper;
 		if (st.period < md.pmin) st.period = md.pmin;
 		if (st.period > md.pmax) st.period = md.pmax;
-		// ---- K4: the sync search over the bits that are now in the mirror
-		if (framing) {
-			WAVE_SYNC();
-			SdFrameDesc *dch = (SdFrameDesc *)P.fo.descs + (size_t)ch * P.fo.max_frames;
-			const uint32_t mf = P.fo.max_frames;
-			if (is_rs41) sd_rs41_sync_step<true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
-			else if (is_dfm) sd_fixed_sync_step<SONDE_DFM09, true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
-			else if (is_ims) sd_fixed_sync_step<SONDE_IMS100, true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
-			else sd_fixed_sync_step<SONDE_MRZN1, true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
-		}
+	};
+	// ---- K4: the sync search over the bits that are now in the mirror.  ONCE PER BLOCK (round 6; per tile before): a block adds at most
+	// 3 x 256 bits, the mirror holds the newest 2048, and what the search finds does not depend on how its calls are cut -- three calls
+	// of ~2 000 ns each (tools/bk_ts.py: mostly the latency of the state machine's scalar control flow, not its 64 positions per lane)
+	// were a fifth of a wave's life
+	auto k4_block = [&]() {
+		if (!framing) return;
+		WAVE_SYNC();
+		SdFrameDesc *dch = (SdFrameDesc *)P.fo.descs + (size_t)ch * P.fo.max_frames;
+		const uint32_t mf = P.fo.max_frames;
+		if (is_rs41) sd_rs41_sync_step<true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
+		else if (is_dfm) sd_fixed_sync_step<SONDE_DFM09, true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
+		else if (is_ims) sd_fixed_sync_step<SONDE_IMS100, true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
+		else sd_fixed_sync_step<SONDE_MRZN1, true>(k4, wpos, w.mirror, lane, dch, mf, w.k4list);
 	};
 	// the tile is consumed: its last 64 samples become the history, what the last pass produced beyond it the head of the next tile
 	auto roll = [&]() {
@@ -313,6 +317,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void sd_bins_kernel(
 		if (gp + 9 < n_pass) load_pass(gp + 9, ph[1]);    pass(ph[2], SD_LH + 128);   
 		if (gp + 10 < n_pass) load_pass(gp + 10, ph[2]);  pass(ph[3], SD_LH + 320);   BK_STAMP(13);
 		tile_rounds(); BK_STAMP(14); roll();
+		k4_block();
 	}
 
 	// ---- epilogue: history, state, the carried phases, K4's state; RS41: the frames listed in this submit

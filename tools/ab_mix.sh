@@ -4,7 +4,7 @@
 p() { python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[0]); print('$1', d['ms_per_step'], d['roofline']['step_frac'], d['kernel_ms'].get('demod'), d['kernel_ms'].get('framer_fec'))"; }
 for rep in 1 2; do for v in "$@"; do
-  export SONDE_MI355_LIB=$PWD/ab/lib_$v.so
+  export SONDE_MI355_LIB=$PWD/tools/ab_libs/lib_$v.so
   python bench.py --mix --channels 4096 --tiles 24 --flags 0 --steps 100 --warmup 20 --no-cpu 2>/dev/null | p "$v joined   "
   python bench.py --mix --channels 4096 --tiles 24 --flags 4 --steps 100 --warmup 20 --no-cpu 2>/dev/null | p "$v pipelined"
   python bench.py --sonde-type 1 --steps 60 --warmup 15 --no-cpu --no-others 2>/dev/null | p "$v DFM 1024x96"
