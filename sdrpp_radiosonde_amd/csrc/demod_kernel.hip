@@ -164,6 +164,22 @@ static_assert(sizeof(EpiTabs) <= (SD_BUF - SD_EPI_TAB_OFF) * sizeof(float), "GF 
 static_assert(8 * sizeof(FramerLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "per-wave FEC work areas do not fit into the tile buffers");
 static_assert(8 * sizeof(FixedLds) <= (2 * SD_BUF + SD_BUF) * sizeof(float), "per-wave work areas of the fixed-length decoders do not fit into the tile buffers");
 
+// The epilogue's RS41 frame decoder as a REAL call (round 6): their own register allocation instead of the kernel's 64-register squeeze -- the
+// inlined RS41 decoder was what put three hoisted LDS addresses into scratch (16 B per lane: the only private memory of this kernel;
+// VERDICT r5 item 7) -- and one copy of the code per instantiation less: 8192 x 24 tiles -3.6 %, mixed 4096 x 24 -1.8 %, the headline
+// -0.3 % (interleaved A/B, profiles/r6_ab_epicall.txt).
+static __device__ __attribute__((noinline)) void sd_rs41_decode_frame_call(const FramerTabs &tabs, FramerLds &s, const uint32_t *__restrict__ swar_row,
+	const uint32_t *__restrict__ ring, uint32_t mask, unsigned long long d0, unsigned long long d1, SondeFrame *__restrict__ fr, uint32_t ch, int lane)
+{
+	GfSwar swar;
+	swar.a_lo = swar_row[0]; swar.a_hi = swar_row[1]; swar.b_lo = swar_row[2]; swar.b_hi = swar_row[3]; swar.c = swar_row[4];
+	SdFrameDesc d;
+	d.fstart = sd_uniform64(d0);
+	d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);
+	d.inv = __builtin_amdgcn_readfirstlane((int)(d1 >> 32));
+	sd_rs41_decode_frame<true>(tabs, s, swar, ring, mask, d, fr, ch, lane);
+}
+
 // ---------------------------------------------------------------- the kernel
 // Wave specialisation: the discriminator (K1) is pure per-sample ALU work, the rounds (K2/K3) are a
 // latency-bound chain (loop update -> FIR reads -> reduction).  Running them as different waves of the
@@ -862,11 +878,7 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 					d0 = __hip_atomic_load(dg + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					d1 = __hip_atomic_load(dg + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-				SdFrameDesc d;
-				d.fstart = sd_uniform64(d0);
-				d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);
-				d.inv = __builtin_amdgcn_readfirstlane((int)(d1 >> 32));
-				sd_rs41_decode_frame<true>(et.tabs, wl, swar, ring_g, ring_mask, d, fout + k, ch, lane);
+				sd_rs41_decode_frame_call(et.tabs, wl, sw, ring_g, ring_mask, d0, d1, fout + k, ch, lane);
 			}
 		}
 	}
@@ -898,6 +910,8 @@ __device__ __forceinline__ void sd_demod_body(DemodLds &s, const uint32_t bidx, 
 				d.fstart = sd_uniform64(d0);
 				d.flen = __builtin_amdgcn_readfirstlane((int)(uint32_t)d1);
 				d.inv = __builtin_amdgcn_readfirstlane((int)(d1 >> 32));
+				// (inlined: as a real call like RS41's these short decoders keep their small arrays on the stack and cost 7 %: DFM 4096 x 24
+				// 0.2886 -> 0.3122 ms, mixed 0.298 -> 0.319)
 				if (is_dfm) sd_dfm_decode_frame<true>(wl, ring_g, ring_mask, d, fout + k, ch, lane);
 				else if (is_m10) sd_m10_decode_frame<true>(wl, fo->m10tab, ring_g, ring_mask, d, fout + k, ch, lane);
 				else if (is_mrz) sd_mrz_decode_frame<true>(wl, ring_g, ring_mask, d, fout + k, ch, lane);
