@@ -342,11 +342,11 @@ def other_configs(args, rank, local_rank, world, dev, barrier, reduce_max_sum, s
     others["shard8192"]["workload"] = "BASELINE configs[4], one GPU's shard: 8192 RS41 channels x 49152 samples (T = 1 s) per step"
     others["rt1250"] = small_run("rs41", 1250, 24, 5, 0, args, local_rank, dev, barrier, stream)
     others["rt1250"]["workload"] = ("north_star's per-GPU share of 10^4 channels on 8 GPUs: 1250 RS41 channels x 49152 samples (T = 1 s) per step "
-                                    "(1.22 residencies of 4 workgroups x 256 CUs); DEFAULT flags (ordinary stream semantics)")
+                                    "(1.22 residencies of 4 workgroups x 256 CUs); DEFAULT flags (ordinary stream semantics): one launch, two time slices")
     others["rt1250_late_join"] = small_run("rs41", 1250, 24, 5, FLAG_LATE_JOIN, args, local_rank, dev, barrier, stream)
     others["rt1250_late_join"]["workload"] = "the same with SONDE_FLAG_LATE_JOIN: two launch units on their own streams joined one submit late, the tail of one overlaps the next submit of the other"
     others["ch1280x96"] = small_run("rs41", 1280, 96, 5, 0, args, local_rank, dev, barrier, stream)
-    others["ch1280x96"]["workload"] = "1280 RS41 channels x 196608 samples per step: the headline's rows, 1.25 residencies; DEFAULT flags (ordinary stream semantics)"
+    others["ch1280x96"]["workload"] = "1280 RS41 channels x 196608 samples per step: the headline's rows, 1.25 residencies; DEFAULT flags (ordinary stream semantics): one launch, time-sliced"
     others["ch1280x96_late_join"] = small_run("rs41", 1280, 96, 5, FLAG_LATE_JOIN, args, local_rank, dev, barrier, stream)
     others["ch1280x96_late_join"]["workload"] = "the same with SONDE_FLAG_LATE_JOIN (two launch units, joined one submit late)"
     others["cs16_1024x96"] = small_run("rs41", 1024, 96, 5, 0, args, local_rank, dev, barrier, stream, iq16=True)
