@@ -4,6 +4,8 @@ bench.py entry                      test here
 other_configs.mix4096 / _late_join  test_mix4096_five_blocks_back_to_back[0 / 32]     (default flags: joined at every submit; [32]: SONDE_FLAG_LATE_JOIN; [4]: SONDE_FLAG_PIPELINE)
 low_snr                             test_headline_shape_at_9_db                        (1024 x 96 tiles, Eb/N0 9 dB)
 other_configs.rt1250, ch1280x96     test_part_filled_last_generation[1250-24-0 / 1280-96-0] and [..-32] (not a multiple of one residency; default and late-joined)
+other_configs.config5_full_1gpu     tests/test_gpu_full_size.py::test_config5_all_65536_channels_on_one_gpu            (65 536 channels x 24 tiles through sonde_node, float and 16-bit rows)
+other_configs.config1_cpu_plumbing  tests/test_gpu_full_size.py::test_config1_single_channel_cpu_plumbing_equals_the_gpu_decoder
 other_configs.wideband8x4           tests/test_channelizer.py::test_fused_channelizer_frames_equal_oracle[4-8]
 other_configs.rt1250_host_e2e       test_host_path_at_the_target_shape                 (1250 channels x 1 s from host memory to SondeData fragments)
 other_configs.cs16_1024x96, cs16_8192x24   test_16_bit_rows_at_the_bench_shapes[1024-96 / 8192-24]  (SONDE_INPUT_IQ16 rows on the recommended stride)

@@ -24,7 +24,7 @@ def test_mixed_batch_as_16_bit_iq_bit_exact(ebn0, seed, flags, bits):
     run_mixed(ebn0, seed, check_coverage=False, flags=flags, cfo_max_hz=1500.0, iq16=bits if bits == 8 else True)
 
 
-def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0, iq16=False):
+def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0, iq16=False, time_slices=0):
     """(also driven by tools/fuzz_campaign.py over many seeds)  flags & 4 (SONDE_FLAG_PIPELINE) or 32 (SONDE_FLAG_LATE_JOIN): the submits are queued with two
     in flight and the frames fetched per ticket; the state is compared at the end.  cfo_max_hz: carrier offsets up to this
     (the AFC of SPEC 3.0b at work; beyond +-2 kHz frames are lost on both sides alike).  iq16: the rows go to the GPU as 16-bit
@@ -50,7 +50,8 @@ def run_mixed(ebn0, seed, check_coverage, flags=0, cfo_max_hz=500.0, iq16=False)
     elif iq16:
         q = torch.clamp(torch.round(iq * 4096.0), -32768, 32767).to(torch.int16)
         iq = q.to(torch.float32)
-    b = SondeBatch(C, n, types=types, flags=flags, input_kind=(3 if iq16 == 8 else 2) if iq16 else 0)
+    # (time_slices: SondeBatchConfig.time_slices, round 6 -- forced segment counts for the campaign; default flags run the two classes as ONE launch)
+    b = SondeBatch(C, n, types=types, flags=flags, input_kind=(3 if iq16 == 8 else 2) if iq16 else 0, time_slices=time_slices)
     dev = q.cuda() if iq16 else iq.cuda()
     chs = [oracle_lib.Channel(int(types[c]), c) for c in range(C)]
     x = iq.numpy()

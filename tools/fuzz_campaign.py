@@ -21,8 +21,9 @@ for i in range(n):
     flags = int(rng.choice([0, 0, 4, 32]))                              # the default (joined at every submit), SONDE_FLAG_PIPELINE, SONDE_FLAG_LATE_JOIN
     cfo = float(rng.choice([500.0, 1500.0, 2500.0]))                    # carrier offsets: the AFC of SPEC 3.0b
     iq16 = (False, False, True, 8)[int(rng.integers(0, 4))]              # a quarter of the batches as 16-bit integer IQ rows (SONDE_INPUT_IQ16), a quarter as 8-bit (IQ8)
-    total = fz.run_mixed(ebn0, seed, check_coverage=False, flags=flags, cfo_max_hz=cfo, iq16=iq16)      # raises on the first differing bit, state or frame
-    print(f"[{i + 1}/{n}] Eb/N0 {ebn0:5.2f} dB seed {seed} flags {flags} cfo +-{cfo:.0f} Hz{' int8' if iq16 == 8 else (' int16' if iq16 else '')}: {total} frames, identical to the oracle", flush=True)
+    slices = int(rng.choice([0, 0, 2, 3, 4]))                           # SondeBatchConfig.time_slices (round 6): the library's choice, or forced
+    total = fz.run_mixed(ebn0, seed, check_coverage=False, flags=flags, cfo_max_hz=cfo, iq16=iq16, time_slices=slices)      # raises on the first differing bit, state or frame
+    print(f"[{i + 1}/{n}] Eb/N0 {ebn0:5.2f} dB seed {seed} flags {flags} slices {slices} cfo +-{cfo:.0f} Hz{' int8' if iq16 == 8 else (' int16' if iq16 else '')}: {total} frames, identical to the oracle", flush=True)
 for snr in (6.0, 10.0, 20.0):
     fz.test_afsk_low_snr_bit_exact(snr)
     print(f"afsk {snr} dB: identical", flush=True)
